@@ -1,0 +1,311 @@
+/*
+ * petr_hip.h — C ABI of libpetr_hip.so: the MI355X (gfx950) implementation of the PETRHead hot path.
+ *
+ * The reference (sty61010/PETR) is pure Python and has no FFI for this path; what it calls are
+ * PyTorch operators.  Each entry point below therefore names the reference call site whose
+ * arithmetic it replaces (paths relative to projects/mmdet3d_plugin/ of the reference) — a
+ * maintainer binds them with ctypes from the reference's own modules.
+ *
+ * Conventions
+ *  - plain C: raw DEVICE pointers + explicit sizes/strides (in elements), no torch types;
+ *  - every function enqueues work on `stream` (a hipStream_t passed as void*) and returns
+ *    immediately; it never synchronises the device, never allocates, keeps no mutable global
+ *    state; the caller owns all buffers including workspaces (sizes via *_workspace_bytes);
+ *  - return value: 0 on success, negative petr_status on error; text via petr_last_error()
+ *    (thread-local);
+ *  - all tensors are fp32 unless stated; masks are uint8 (non-zero = ignore, as
+ *    key_padding_mask in models/utils/petr_transformer.py:318).
+ */
+#ifndef PETR_HIP_H_
+#define PETR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PETR_HIP_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+  PETR_OK = 0,
+  PETR_ERR_INVALID = -1,   /* bad argument (shape, alignment, null pointer)      */
+  PETR_ERR_UNSUPPORTED = -2, /* configuration outside what the kernels implement */
+  PETR_ERR_LAUNCH = -3,    /* hipLaunch / runtime failure                        */
+  PETR_ERR_WORKSPACE = -4  /* workspace too small                                */
+} petr_status;
+
+int petr_version(void);
+const char* petr_last_error(void);
+/* multiProcessorCount, gcnArchName ("gfx950...") of the current device; arch buffer >= 64 bytes */
+int petr_device_caps(int* num_cu, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  camera-frustum -> LiDAR coordinate volume
+ *     replaces models/dense_heads/petr_head.py:290-331 (PETRHead.position_embeding up to and
+ *     including inverse_sigmoid; twin at petrv2_head.py:348-394).
+ *     out    [B*N, 3*D, H, W]  channel c = 3*d + axis  (petr_head.py:330)
+ *     cmask  [B, N, H, W] uint8 or NULL: (#coords outside [0,1] over D*3) > D/2  (petr_head.py:327-328),
+ *            NOT yet OR-ed with the padding mask
+ *     img2lidar [B*N, 16] fp32 row-major = float32(inv_fp64(lidar2img)) computed by the host as
+ *            the reference does (petr_head.py:308-315)
+ *     depth  [D] fp32 depth bins (petr_head.py:293-301), computed by the host
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* img2lidar;
+  const float* depth;
+  float* out;
+  uint8_t* cmask;
+  int B, N, H, W, D;
+  float pad_h, pad_w;        /* img_metas[0]['pad_shape'][0][:2] */
+  float range[6];            /* position_range */
+  float eps;                 /* 1e-5 (petr_head.py:287) */
+} petr_coords3d_args;
+int petr_coords3d_fwd(const petr_coords3d_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3a SinePositionalEncoding3D.forward  (models/utils/positional_encoding.py:58-100)
+ *     mask [B,N,H,W] uint8 -> out [B,N,3*F,H,W]; dim_t [F] fp32 table (positional_encoding.py:82-84)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const uint8_t* mask;
+  const float* dim_t;
+  float* out;
+  int B, N, H, W, F;
+  int normalize;
+  float scale, eps, offset;
+} petr_sine3d_args;
+int petr_sine3d_fwd(const petr_sine3d_args* a, void* stream);
+
+/* K3b pos2posemb3d (models/dense_heads/petr_head.py:31-43): pos [n,3] -> out [n,3*F], order (y,x,z).
+ *     bwd: dpos [n,3] = d out / d pos contracted with dout [n,3*F]                         */
+int petr_posemb3d_fwd(const float* pos, const float* dim_t, float* out, int n, int F, void* stream);
+int petr_posemb3d_bwd(const float* pos, const float* dim_t, const float* dout, float* dpos, int n, int F,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense contraction  C[z][m, n] (+)= act( alpha * sum_k A(m,k) * B(n,k) + bias[n] + R[m,n] )
+ *     replaces every nn.Conv2d(1x1) / nn.Linear / F.linear on the path:
+ *     petr_head.py:220-274 (input_proj, position_encoder, adapt_pos3d, query_embedding, branches),
+ *     torch.nn.MultiheadAttention in-/out-projections (petr_transformer.py:271,357-362), mmcv FFN,
+ *     and their gradients (the same contraction with transposed operand layouts).
+ *     fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 products).
+ *
+ *     A(m,k) = a_kcontig ? a[m*lda + k] : a[k*lda + m];   B(n,k) likewise with b/ldb/b_kcontig.
+ *     a2: optional addend to A with A's layout (query + query_pos, key + key_pos:
+ *         petr_transformer.py:341-344); a2 row = m % a2_rows if a2_rows>0; applied only for output
+ *         columns n < a2_ncols if a2_ncols>0.
+ *     Two batch dimensions z = z0*nb1 + z1 with element strides for every operand.
+ *     k_seg > 0: the K axis is cut into K/k_seg segments at different base addresses,
+ *         k = s*k_seg + kk  ->  A(m,kk) at a + s*a_seg_stride, B(n,kk) at b + s*b_seg_stride
+ *         (sums over (layer, channel), (view, pixel), (batch, token) in the gradients).
+ *     C store: c[(n / c_nblk) * c_nblk_stride + m*ldc + (n % c_nblk)] if c_nblk>0 (head-split
+ *         K/V layout), else c[m*ldc + n].
+ *     flags: PETR_GEMM_RELU, PETR_GEMM_ACCUMULATE (C += ...), PETR_GEMM_RELU_MASK (multiply the
+ *         result by (relu_mask[m,n] > 0); relu_mask indexed like R) , PETR_GEMM_SIGMOID_MUL
+ *         (C = mul[m,n] * sigmoid(value); mul indexed like R; PETRv2 SELayer petrv2_head.py:48-60).
+ *     split_k > 1: slice z2 of K writes its partial to c + z2*c_split_stride (bias/residual are NOT
+ *         applied; reduce with petr_layernorm_fwd or petr_reduce_partials).
+ * ------------------------------------------------------------------------------------------ */
+enum { PETR_GEMM_RELU = 1, PETR_GEMM_ACCUMULATE = 2, PETR_GEMM_RELU_MASK = 4, PETR_GEMM_SIGMOID_MUL = 8 };
+typedef struct {
+  const float* a; long lda; int a_kcontig; long a_bs0, a_bs1;
+  const float* a2; int a2_rows; int a2_ncols;
+  const float* b; long ldb; int b_kcontig; long b_bs0, b_bs1;
+  float* c; long ldc; long c_bs0, c_bs1; int c_nblk; long c_nblk_stride;
+  const float* bias; long bias_bs0, bias_bs1;
+  const float* r; long ldr; long r_bs0, r_bs1;      /* residual / relu-mask / mul operand */
+  int M, N, K, nb0, nb1;
+  int split_k; long c_split_stride;
+  int k_seg; long a_seg_stride, b_seg_stride;
+  int flags;
+  float alpha;
+} petr_gemm_args;
+int petr_gemm(const petr_gemm_args* g, void* stream);
+
+/* column sums: out[n] (+)= sum_m x[m*ld + n]  (bias gradients). accumulate: 0 overwrite, 1 add.
+ * ws: petr_colsum_workspace_bytes(N) bytes of scratch (deterministic two-stage sum, no atomics) */
+size_t petr_colsum_workspace_bytes(int N);
+int petr_colsum(const float* x, long ld, int M, int N, float* out, int accumulate, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (C <= 1024, multiple of 4), eps as given (nn.LayerNorm, 1e-5):
+ *     z[m,:] = sum_{p<n_partials} x[p*partial_stride + m*C ..] + bias + residual[m,:]
+ *     y[m,:] = (z - mean)/sqrt(var+eps) * gamma + beta ; optional ReLU; optional nan_to_num on y
+ *     replaces norms.{0,1,2} / post_norm (petr_transformer.py:418-419,444; mmcv layer 'norm' op),
+ *     the LayerNorms of cls_branches (petr_head.py:229) and torch.nan_to_num (petr_head.py:435).
+ *     z_out / mean / rstd may be NULL (inference).
+ * ------------------------------------------------------------------------------------------ */
+enum { PETR_LN_RELU = 1, PETR_LN_NAN_TO_NUM = 2 };
+typedef struct {
+  const float* x; int n_partials; long partial_stride;
+  const float* bias; const float* residual;
+  const float* gamma; const float* beta;
+  float* y; float* z_out; float* mean; float* rstd;
+  int M, C; float eps; int flags;
+  /* optional second output y2[m,:] = y[m,:] + add2[m % add2_rows,:]  (query + query_pos for the next
+   * attention, petr_transformer.py:341-342, emitted while the row is still in registers) */
+  float* y2; const float* add2; int add2_rows;
+} petr_layernorm_args;
+int petr_layernorm_fwd(const petr_layernorm_args* a, void* stream);
+/* dz = LN backward given z (pre-norm input), mean, rstd, gamma, dy (and y if PETR_LN_RELU was used:
+ * dy is masked by y>0). dgamma/dbeta [C] accumulated (+=) via per-block partials in `ws`
+ * (petr_layernorm_bwd_workspace_bytes). dz may alias dy. dz_accumulate: dz += result.      */
+typedef struct {
+  const float* z; const float* mean; const float* rstd; const float* gamma;
+  const float* dy; const float* y;
+  float* dz; float* dgamma; float* dbeta;
+  void* ws;
+  int M, C; int flags; int dz_accumulate;
+} petr_layernorm_bwd_args;
+size_t petr_layernorm_bwd_workspace_bytes(int M, int C);
+int petr_layernorm_bwd(const petr_layernorm_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head attention core  O = softmax(scale * Q K^T + mask) V,  head_dim = 32
+ *     replaces the scaled-dot-product inside torch.nn.MultiheadAttention called at
+ *     models/utils/petr_transformer.py:357-362 (cross-attention, PETRMultiheadAttention) and by
+ *     mmcv MultiheadAttention (self-attention).  Flash-style: scores are never written; fp32 MFMA
+ *     (v_mfma_f32_32x32x2_f32) for QK^T and PV, fp32 online softmax in registers.
+ *     q[b,h,i,:] at q + b*q_bs + h*q_hs + i*q_rs (+d);  k, v, o likewise.  lse [B,H,Q] (natural log)
+ *     or NULL.  kpm [B,L] uint8 (non-zero = ignore) or NULL.  A fully masked row yields NaN, as
+ *     the reference does (cleared later by nan_to_num).
+ *     n_split>1 splits L over workgroups; partials go to `ws` (petr_mha_fwd_workspace_bytes) and a
+ *     second kernel merges them.  n_split=0 lets the library choose.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* q; long q_bs, q_hs, q_rs;
+  const float* k; long k_bs, k_hs, k_rs;
+  const float* v; long v_bs, v_hs, v_rs;
+  float* o; long o_bs, o_hs, o_rs;
+  float* lse;
+  const uint8_t* kpm;
+  int B, H, Q, L;
+  float scale;
+  int n_split;
+  void* ws; size_t ws_bytes;
+} petr_mha_fwd_args;
+size_t petr_mha_fwd_workspace_bytes(int B, int H, int Q, int L, int n_split);
+int petr_mha_choose_split(int B, int H, int Q, int L);
+int petr_mha_fwd(const petr_mha_fwd_args* a, void* stream);
+
+/* backward: dq, dk, dv from q,k,v,o,do,lse (same stride conventions).  dq/dk/dv are ACCUMULATED
+ * (+=): the caller zero-fills them.  dq (and dk/dv when the query range is split over workgroups)
+ * use float atomics, so low-order bits depend on arrival order.  delta = rowsum(do*o) goes to ws. */
+typedef struct {
+  const float* q; long q_bs, q_hs, q_rs;
+  const float* k; long k_bs, k_hs, k_rs;
+  const float* v; long v_bs, v_hs, v_rs;
+  const float* o; long o_bs, o_hs, o_rs;
+  const float* d_o; long do_bs, do_hs, do_rs;
+  const float* lse;
+  const uint8_t* kpm;
+  float* dq; long dq_bs, dq_hs, dq_rs;
+  float* dk; long dk_bs, dk_hs, dk_rs;
+  float* dv; long dv_bs, dv_hs, dv_rs;
+  int B, H, Q, L;
+  float scale;
+  void* ws; size_t ws_bytes;
+} petr_mha_bwd_args;
+size_t petr_mha_bwd_workspace_bytes(int B, int H, int Q, int L);
+int petr_mha_bwd(const petr_mha_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Box epilogue (models/dense_heads/petr_head.py:441-460; petrv2_head.py:513-531):
+ *     t = reg[lvl,b,q,:]; t[0:2] = sigmoid(t[0:2] + logit(ref[q,0:2])); t[4] = sigmoid(t[4] + logit(ref[q,2]));
+ *     t[8:] /= mean_time_stamp (if time_div != 0); then ch 0,1,4 scaled by pc_range.
+ *     reg/out [rows, code] with rows = n_lvl*B*Q (row -> q = row % Q); in-place allowed.
+ *     bwd: dreg (in-place on dout allowed) and dref [Q,3] accumulated (+=).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* reg; const float* ref; float* out;
+  int rows, Q, code;
+  float pc_range[6];
+  float time_div;  /* 0 = no division */
+  float eps;       /* 1e-5, inverse_sigmoid */
+} petr_bbox_args;
+int petr_bbox_epilogue_fwd(const petr_bbox_args* a, void* stream);
+/* out = forward OUTPUT (post-scale); dout -> dreg; dref += */
+int petr_bbox_epilogue_bwd(const petr_bbox_args* a, const float* dout, float* dreg, float* dref, void* stream);
+
+/* small helpers used by the host executor */
+/* out[m,:] = x[m,:] + e[m % e_rows,:]   (key + key_pos, petr_transformer.py:343-344) */
+int petr_add_rows(const float* x, const float* e, float* out, long M, int e_rows, int C, void* stream);
+int petr_fill(float* p, float v, long n, void* stream);
+int petr_axpy(float* y, const float* x, float alpha, long n, void* stream); /* y += alpha*x */
+/* out[m,:] = sum_p x[p*stride + m*C..] (+ bias) (+ residual); generic partial reducer */
+int petr_reduce_partials(const float* x, int n_partials, long stride, const float* bias, const float* residual,
+                         float* out, long M, int C, void* stream);
+/* sum over batch copies: out[r,:] (+)= sum_b x[(b*rows + r)*C ..]   (query_pos gradient over the batch) */
+int petr_reduce_batch(const float* x, int B, long rows, int C, float* out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-path executor: PETRHead.forward (petr_head.py:366-468) / PETRv2Head.forward
+ * (petrv2_head.py:429-540) and its gradient as ONE call each, all kernels enqueued on `stream`.
+ * Parameters live in one flat fp32 buffer; `petr_head_layout` reports offsets (in floats) of every
+ * reference state_dict tensor inside it so the host can alias its nn.Parameters onto the buffer.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int B, N, C_in, H, W;        /* mlvl_feats[position_level] = [B,N,C_in,H,W]            */
+  int num_query, num_layers, num_heads, embed_dims, ffn_dims, depth_num, num_classes, code_size;
+  int v2, with_fpe, with_time, with_multi;   /* PETRv2Head switches (petrv2_head.py:92-95) */
+  int shared_branches;          /* 1: PETRHead aliasing (petr_head.py:244-247); 0: deep copies */
+  int LID;
+  float depth_start;
+  float position_range[6];
+  float pc_range[6];
+  float pad_h, pad_w;
+  int has_mask;                 /* 0: padding mask known all-False (host closed form)      */
+  int training;                 /* 1: keep what backward needs                              */
+} petr_head_config;
+
+#define PETR_MAX_PARAMS 512
+typedef struct {
+  int count;
+  long total;                          /* floats in the flat buffer */
+  char name[PETR_MAX_PARAMS][96];      /* reference state_dict key  */
+  long offset[PETR_MAX_PARAMS];
+  int ndim[PETR_MAX_PARAMS];
+  int shape[PETR_MAX_PARAMS][4];
+  int alias_of[PETR_MAX_PARAMS];       /* index of the entry whose storage this key shares, or -1 */
+} petr_head_layout_t;
+int petr_head_layout(const petr_head_config* cfg, petr_head_layout_t* out);
+
+typedef struct {
+  const float* params;          /* flat parameter buffer                                   */
+  const float* feats;           /* [B,N,C_in,H,W]                                          */
+  const float* img2lidar;       /* [B*N,16]                                                */
+  const float* depth;           /* [D]                                                     */
+  const float* dim_t;           /* [embed_dims/2]                                          */
+  const uint8_t* mask;          /* [B,N,H,W] padding mask (uint8)                          */
+  float time_div;               /* mean_time_stamp (v2 with_time), else 0                  */
+  float* all_cls_scores;        /* [num_layers,B,Q,num_classes]                            */
+  float* all_bbox_preds;        /* [num_layers,B,Q,code_size]                              */
+  void* ws; size_t ws_bytes;    /* activations + scratch (petr_head_workspace_bytes)       */
+} petr_head_io;
+size_t petr_head_workspace_bytes(const petr_head_config* cfg);
+int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io, void* stream);
+
+typedef struct {
+  const float* d_cls;           /* [num_layers,B,Q,num_classes] upstream gradient          */
+  const float* d_bbox;          /* [num_layers,B,Q,code_size]                              */
+  float* d_params;              /* flat, same layout as params; ACCUMULATED (+=)           */
+  float* d_feats;               /* [B,N,C_in,H,W] or NULL; overwritten                     */
+} petr_head_grads;
+/* stage_begin/stage_end select a contiguous range of backward stages so the host can interleave
+ * gradient all-reduce buckets; petr_head_bwd_num_stages() stages in total; after stage s completes,
+ * the gradients of flat range [petr_head_bwd_stage_range(s)] are final.                      */
+int petr_head_bwd_num_stages(const petr_head_config* cfg);
+int petr_head_bwd_stage_range(const petr_head_config* cfg, int stage, long* begin, long* end);
+int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io, const petr_head_grads* g,
+                  int stage_begin, int stage_end, void* stream);
+
+/* named views into the forward workspace, for tests and for the per-module Python API
+ * ("memory", "pos_embed", "query_embed", "outs_dec", "coords3d", "sine", "k_all", "v_all", ...)   */
+int petr_head_ws_view(const petr_head_config* cfg, const char* name, long* offset_floats, long* numel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PETR_HIP_H_ */

@@ -1,0 +1,204 @@
+"""ctypes binding of libpetr_hip.so (include/petr_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, an exception
+is raised.  Nothing under ``oracle/`` is ever imported from here.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpetr_hip.so')
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class PetrHipError(RuntimeError):
+    pass
+
+
+def _fields(*spec):
+    return [(n, t) for n, t in spec]
+
+
+class Coords3dArgs(C.Structure):
+    _fields_ = _fields(('img2lidar', C.c_void_p), ('depth', C.c_void_p), ('out', C.c_void_p), ('cmask', C.c_void_p),
+                       ('B', C.c_int), ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('D', C.c_int),
+                       ('pad_h', C.c_float), ('pad_w', C.c_float), ('range', C.c_float * 6), ('eps', C.c_float))
+
+
+class Sine3dArgs(C.Structure):
+    _fields_ = _fields(('mask', C.c_void_p), ('dim_t', C.c_void_p), ('out', C.c_void_p),
+                       ('B', C.c_int), ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('F', C.c_int),
+                       ('normalize', C.c_int), ('scale', C.c_float), ('eps', C.c_float), ('offset', C.c_float))
+
+
+class GemmArgs(C.Structure):
+    _fields_ = _fields(
+        ('a', C.c_void_p), ('lda', C.c_long), ('a_kcontig', C.c_int), ('a_bs0', C.c_long), ('a_bs1', C.c_long),
+        ('a2', C.c_void_p), ('a2_rows', C.c_int), ('a2_ncols', C.c_int),
+        ('b', C.c_void_p), ('ldb', C.c_long), ('b_kcontig', C.c_int), ('b_bs0', C.c_long), ('b_bs1', C.c_long),
+        ('c', C.c_void_p), ('ldc', C.c_long), ('c_bs0', C.c_long), ('c_bs1', C.c_long), ('c_nblk', C.c_int),
+        ('c_nblk_stride', C.c_long),
+        ('bias', C.c_void_p), ('bias_bs0', C.c_long), ('bias_bs1', C.c_long),
+        ('r', C.c_void_p), ('ldr', C.c_long), ('r_bs0', C.c_long), ('r_bs1', C.c_long),
+        ('M', C.c_int), ('N', C.c_int), ('K', C.c_int), ('nb0', C.c_int), ('nb1', C.c_int),
+        ('split_k', C.c_int), ('c_split_stride', C.c_long), ('k_seg', C.c_int), ('a_seg_stride', C.c_long),
+        ('b_seg_stride', C.c_long), ('flags', C.c_int), ('alpha', C.c_float))
+
+
+GEMM_RELU, GEMM_ACCUMULATE, GEMM_RELU_MASK, GEMM_SIGMOID_MUL = 1, 2, 4, 8
+LN_RELU, LN_NAN_TO_NUM = 1, 2
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = _fields(('x', C.c_void_p), ('n_partials', C.c_int), ('partial_stride', C.c_long),
+                       ('bias', C.c_void_p), ('residual', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
+                       ('y', C.c_void_p), ('z_out', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p),
+                       ('M', C.c_int), ('C', C.c_int), ('eps', C.c_float), ('flags', C.c_int),
+                       ('y2', C.c_void_p), ('add2', C.c_void_p), ('add2_rows', C.c_int))
+
+
+class LayerNormBwdArgs(C.Structure):
+    _fields_ = _fields(('z', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('gamma', C.c_void_p),
+                       ('dy', C.c_void_p), ('y', C.c_void_p), ('dz', C.c_void_p), ('dgamma', C.c_void_p),
+                       ('dbeta', C.c_void_p), ('ws', C.c_void_p), ('M', C.c_int), ('C', C.c_int), ('flags', C.c_int),
+                       ('dz_accumulate', C.c_int))
+
+
+class MhaFwdArgs(C.Structure):
+    _fields_ = _fields(
+        ('q', C.c_void_p), ('q_bs', C.c_long), ('q_hs', C.c_long), ('q_rs', C.c_long),
+        ('k', C.c_void_p), ('k_bs', C.c_long), ('k_hs', C.c_long), ('k_rs', C.c_long),
+        ('v', C.c_void_p), ('v_bs', C.c_long), ('v_hs', C.c_long), ('v_rs', C.c_long),
+        ('o', C.c_void_p), ('o_bs', C.c_long), ('o_hs', C.c_long), ('o_rs', C.c_long),
+        ('lse', C.c_void_p), ('kpm', C.c_void_p),
+        ('B', C.c_int), ('H', C.c_int), ('Q', C.c_int), ('L', C.c_int), ('scale', C.c_float),
+        ('n_split', C.c_int), ('ws', C.c_void_p), ('ws_bytes', C.c_size_t))
+
+
+class MhaBwdArgs(C.Structure):
+    _fields_ = _fields(
+        ('q', C.c_void_p), ('q_bs', C.c_long), ('q_hs', C.c_long), ('q_rs', C.c_long),
+        ('k', C.c_void_p), ('k_bs', C.c_long), ('k_hs', C.c_long), ('k_rs', C.c_long),
+        ('v', C.c_void_p), ('v_bs', C.c_long), ('v_hs', C.c_long), ('v_rs', C.c_long),
+        ('o', C.c_void_p), ('o_bs', C.c_long), ('o_hs', C.c_long), ('o_rs', C.c_long),
+        ('d_o', C.c_void_p), ('do_bs', C.c_long), ('do_hs', C.c_long), ('do_rs', C.c_long),
+        ('lse', C.c_void_p), ('kpm', C.c_void_p),
+        ('dq', C.c_void_p), ('dq_bs', C.c_long), ('dq_hs', C.c_long), ('dq_rs', C.c_long),
+        ('dk', C.c_void_p), ('dk_bs', C.c_long), ('dk_hs', C.c_long), ('dk_rs', C.c_long),
+        ('dv', C.c_void_p), ('dv_bs', C.c_long), ('dv_hs', C.c_long), ('dv_rs', C.c_long),
+        ('B', C.c_int), ('H', C.c_int), ('Q', C.c_int), ('L', C.c_int), ('scale', C.c_float),
+        ('ws', C.c_void_p), ('ws_bytes', C.c_size_t))
+
+
+class BboxArgs(C.Structure):
+    _fields_ = _fields(('reg', C.c_void_p), ('ref', C.c_void_p), ('out', C.c_void_p),
+                       ('rows', C.c_int), ('Q', C.c_int), ('code', C.c_int),
+                       ('pc_range', C.c_float * 6), ('time_div', C.c_float), ('eps', C.c_float))
+
+
+class HeadConfig(C.Structure):
+    _fields_ = _fields(
+        ('B', C.c_int), ('N', C.c_int), ('C_in', C.c_int), ('H', C.c_int), ('W', C.c_int),
+        ('num_query', C.c_int), ('num_layers', C.c_int), ('num_heads', C.c_int), ('embed_dims', C.c_int),
+        ('ffn_dims', C.c_int), ('depth_num', C.c_int), ('num_classes', C.c_int), ('code_size', C.c_int),
+        ('v2', C.c_int), ('with_fpe', C.c_int), ('with_time', C.c_int), ('with_multi', C.c_int),
+        ('shared_branches', C.c_int), ('LID', C.c_int), ('depth_start', C.c_float),
+        ('position_range', C.c_float * 6), ('pc_range', C.c_float * 6), ('pad_h', C.c_float), ('pad_w', C.c_float),
+        ('has_mask', C.c_int), ('training', C.c_int))
+
+
+MAX_PARAMS = 512
+
+
+class HeadLayout(C.Structure):
+    _fields_ = _fields(('count', C.c_int), ('total', C.c_long), ('name', (C.c_char * 96) * MAX_PARAMS),
+                       ('offset', C.c_long * MAX_PARAMS), ('ndim', C.c_int * MAX_PARAMS),
+                       ('shape', (C.c_int * 4) * MAX_PARAMS), ('alias_of', C.c_int * MAX_PARAMS))
+
+
+class HeadIO(C.Structure):
+    _fields_ = _fields(('params', C.c_void_p), ('feats', C.c_void_p), ('img2lidar', C.c_void_p), ('depth', C.c_void_p),
+                       ('dim_t', C.c_void_p), ('mask', C.c_void_p), ('time_div', C.c_float),
+                       ('all_cls_scores', C.c_void_p), ('all_bbox_preds', C.c_void_p),
+                       ('ws', C.c_void_p), ('ws_bytes', C.c_size_t))
+
+
+class HeadGrads(C.Structure):
+    _fields_ = _fields(('d_cls', C.c_void_p), ('d_bbox', C.c_void_p), ('d_params', C.c_void_p), ('d_feats', C.c_void_p))
+
+
+_lib = None
+
+
+def lib():
+    """Load libpetr_hip.so (once).  Raises PetrHipError if it is not built — there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PetrHipError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C petr_amd/csrc`. petr_amd has no CPU fallback.')
+    L = C.CDLL(LIB_PATH)
+    L.petr_version.restype = C.c_int
+    L.petr_last_error.restype = C.c_char_p
+    L.petr_device_caps.argtypes = [C.POINTER(C.c_int), C.c_char_p, C.c_int]
+    L.petr_coords3d_fwd.argtypes = [C.POINTER(Coords3dArgs), C.c_void_p]
+    L.petr_sine3d_fwd.argtypes = [C.POINTER(Sine3dArgs), C.c_void_p]
+    L.petr_posemb3d_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.petr_posemb3d_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.petr_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+    L.petr_colsum_workspace_bytes.argtypes = [C.c_int]
+    L.petr_colsum_workspace_bytes.restype = C.c_size_t
+    L.petr_colsum.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.petr_layernorm_fwd.argtypes = [C.POINTER(LayerNormArgs), C.c_void_p]
+    L.petr_layernorm_bwd_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    L.petr_layernorm_bwd_workspace_bytes.restype = C.c_size_t
+    L.petr_layernorm_bwd.argtypes = [C.POINTER(LayerNormBwdArgs), C.c_void_p]
+    L.petr_mha_fwd_workspace_bytes.argtypes = [C.c_int] * 5
+    L.petr_mha_fwd_workspace_bytes.restype = C.c_size_t
+    L.petr_mha_choose_split.argtypes = [C.c_int] * 4
+    L.petr_mha_fwd.argtypes = [C.POINTER(MhaFwdArgs), C.c_void_p]
+    L.petr_mha_bwd_workspace_bytes.argtypes = [C.c_int] * 4
+    L.petr_mha_bwd_workspace_bytes.restype = C.c_size_t
+    L.petr_mha_bwd.argtypes = [C.POINTER(MhaBwdArgs), C.c_void_p]
+    L.petr_bbox_epilogue_fwd.argtypes = [C.POINTER(BboxArgs), C.c_void_p]
+    L.petr_bbox_epilogue_bwd.argtypes = [C.POINTER(BboxArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.petr_add_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]
+    L.petr_fill.argtypes = [C.c_void_p, C.c_float, C.c_long, C.c_void_p]
+    L.petr_axpy.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_long, C.c_void_p]
+    L.petr_reduce_partials.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
+                                       C.c_int, C.c_void_p]
+    L.petr_reduce_batch.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    missing = [n for n in EXPORTS if not hasattr(L, n)]
+    if missing:
+        raise PetrHipError(f'{LIB_PATH} is stale: missing exports {missing}; rebuild it')
+    L.petr_head_layout.argtypes = [C.POINTER(HeadConfig), C.POINTER(HeadLayout)]
+    L.petr_head_workspace_bytes.argtypes = [C.POINTER(HeadConfig)]
+    L.petr_head_workspace_bytes.restype = C.c_size_t
+    L.petr_head_fwd.argtypes = [C.POINTER(HeadConfig), C.POINTER(HeadIO), C.c_void_p]
+    L.petr_head_bwd_num_stages.argtypes = [C.POINTER(HeadConfig)]
+    L.petr_head_bwd_stage_range.argtypes = [C.POINTER(HeadConfig), C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    L.petr_head_bwd.argtypes = [C.POINTER(HeadConfig), C.POINTER(HeadIO), C.POINTER(HeadGrads), C.c_int, C.c_int,
+                                C.c_void_p]
+    L.petr_head_ws_view.argtypes = [C.POINTER(HeadConfig), C.c_char_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    'petr_version', 'petr_last_error', 'petr_device_caps', 'petr_coords3d_fwd', 'petr_sine3d_fwd',
+    'petr_posemb3d_fwd', 'petr_posemb3d_bwd', 'petr_gemm', 'petr_colsum_workspace_bytes', 'petr_colsum',
+    'petr_layernorm_fwd', 'petr_layernorm_bwd_workspace_bytes', 'petr_layernorm_bwd',
+    'petr_mha_fwd_workspace_bytes', 'petr_mha_choose_split', 'petr_mha_fwd', 'petr_mha_bwd_workspace_bytes',
+    'petr_mha_bwd', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows',
+    'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
+    'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
+]
+
+
+def check(status, what='libpetr_hip'):
+    if status != 0:
+        msg = lib().petr_last_error()
+        raise PetrHipError(f'{what} failed ({status}): {msg.decode() if msg else "?"}')

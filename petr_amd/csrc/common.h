@@ -1,0 +1,61 @@
+// Shared helpers for the libpetr_hip kernels (gfx950 / CDNA4 only: wave64, MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/petr_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void petr_set_error(const char* fmt, ...);
+
+#define PETR_CHECK(cond, code, ...)     \
+  do {                                  \
+    if (!(cond)) {                      \
+      petr_set_error(__VA_ARGS__);      \
+      return (code);                    \
+    }                                   \
+  } while (0)
+
+#define PETR_LAUNCH_CHECK(what)                                              \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      petr_set_error("%s: launch failed: %s", what, hipGetErrorString(e__)); \
+      return PETR_ERR_LAUNCH;                                                \
+    }                                                                        \
+  } while (0)
+
+static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Row index held by accumulator register r of a 32x32 MFMA result in lane-half h
+// (C/D map of v_mfma_f32_32x32x*: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+__device__ __forceinline__ int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// value of the partner lane (lane ^ 32) combined by max / sum: one v_permlane32_swap, no LDS.
+__device__ __forceinline__ float xhalf_max(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware remap of a linear workgroup id (cdna guide T1, bijective form): consecutive
+// remapped ids run on the same XCD (round-robin dispatch: id % 8 labels the XCD group).
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n >> 3, r = n & 7, x = id & 7, s = id >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}

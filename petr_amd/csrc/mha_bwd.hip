@@ -1,0 +1,287 @@
+// Multi-head attention backward (head_dim 32, fp32): dQ, dK, dV from Q, K, V, O, dO and the
+// forward's log-sum-exp; P is recomputed, the [Q x L] score matrix is never stored.
+// Gradient of the attention core reached from reference petr_transformer.py:357-362 (the reference
+// gets it from autograd through bmm/softmax/bmm and, because of cp.checkpoint :201-212, re-runs the
+// whole layer forward first).
+//
+// Structure (cdna guide, Appendix B "Attention backward", adapted to fp32 MFMA 32x32x2):
+//   workgroup = 4 waves = 128 keys of one (batch, head) x a slice of the query tiles;
+//   each wave owns 32 keys: its K and V rows live in registers for the whole sweep and its
+//   dK^T / dV^T accumulators (32x32 each) stay in registers, so dK/dV need no cross-wave sum.
+//   Per 32-query tile, with the KEY ON THE LANE:
+//     S'  = Q K^T  (acc initialised to -LSE/scale + key bias)      -> p  = exp2(S' * scale*log2e)
+//     dP' = dO V^T (acc initialised to -delta)                     -> ds = p * dP'
+//     dV^T += dO^T p ,  dK^T += Q^T ds   : p / ds accumulators are used directly as B operands
+//     dQ   += ds K  : ds crosses LDS once (transpose key-on-lane -> query-on-lane); the four
+//                     waves' partial tiles are summed in LDS and added to global dQ with
+//                     128-byte-segment float atomics (two segments per wave instruction).
+//   LDS tiles of Q and dO use pitch 33 so that both the row-fragment read (lane = query) and the
+//   column-fragment read (lane = d) are conflict-free ds_read_b32.
+// Outputs are ACCUMULATED (+=): the caller zero-fills them (the executor clears its gradient
+// workspace once).  dQ uses float atomics, so its low-order bits depend on arrival order.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int P33 = 33;
+
+struct MhaBwdParams {
+  petr_mha_bwd_args a;
+  int nkb, q_splits, qtiles_per_split;
+  const float* delta;  // [B*H][Q]
+  int vec;             // q/do/k/v 16-byte loads legal
+};
+
+__global__ __launch_bounds__(256) void mha_delta_kernel(const petr_mha_bwd_args a, float* delta) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long rows = (long)a.B * a.H * a.Q;
+  if (idx >= rows * 8) return;
+  const long row = idx >> 3;
+  const int d4 = (int)(idx & 7);
+  const int q = (int)(row % a.Q);
+  const int bh = (int)(row / a.Q);
+  const int b = bh / a.H, hd = bh - b * a.H;
+  const float* op = a.o + (long)b * a.o_bs + (long)hd * a.o_hs + (long)q * a.o_rs + 4 * d4;
+  const float* gp = a.d_o + (long)b * a.do_bs + (long)hd * a.do_hs + (long)q * a.do_rs + 4 * d4;
+  float s = op[0] * gp[0] + op[1] * gp[1] + op[2] * gp[2] + op[3] * gp[3];
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (d4 == 0) delta[row] = s;
+}
+
+template <bool HAS_MASK>
+__global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
+  __shared__ __attribute__((aligned(16))) float Qs[32 * P33];
+  __shared__ __attribute__((aligned(16))) float dOs[32 * P33];
+  __shared__ __attribute__((aligned(16))) float dSs[4][32 * P33];
+  __shared__ __attribute__((aligned(16))) float Ks[128 * 32];
+  __shared__ __attribute__((aligned(16))) float red[4][32 * P33];
+  __shared__ float lse_s[32], dl_s[32];
+
+  const petr_mha_bwd_args& a = p.a;
+  const int total = p.nkb * a.B * a.H * p.q_splits;
+  const int w = xcd_remap(blockIdx.x, total);
+  const int qs = w % p.q_splits;
+  const int rest = w / p.q_splits;
+  const int kb = rest % p.nkb;
+  const int bh = rest / p.nkb;
+  const int b = bh / a.H, hd = bh - b * a.H;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  const int key0 = kb * 128 + wave * 32;
+  const int key = key0 + c;
+  const bool key_ok = key < a.L;
+  const int key_ld = key_ok ? key : a.L - 1;
+
+  const float* qp = a.q + (long)b * a.q_bs + (long)hd * a.q_hs;
+  const float* gp = a.d_o + (long)b * a.do_bs + (long)hd * a.do_hs;
+  const float* kp = a.k + (long)b * a.k_bs + (long)hd * a.k_hs;
+  const float* vp = a.v + (long)b * a.v_bs + (long)hd * a.v_hs;
+
+  // ---- this wave's K / V rows: lane (c,h) holds row key, columns 16h..16h+15 ----
+  float kf[16], vf[16];
+  {
+    const float* ks = kp + (long)key_ld * a.k_rs + 16 * h;
+    const float* vs = vp + (long)key_ld * a.v_rs + 16 * h;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      kf[i] = key_ok ? ks[i] : 0.f;
+      vf[i] = key_ok ? vs[i] : 0.f;
+    }
+  }
+  // K also in LDS, natural [key][d], as the B operand of the dQ product (lane = d)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + 256 * i;
+    const int kr = idx >> 3, c4 = idx & 7;
+    const int kg = kb * 128 + kr;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kg < a.L) {
+      const float* s = kp + (long)kg * a.k_rs + 4 * c4;
+      v = make_float4(s[0], s[1], s[2], s[3]);
+    }
+    *reinterpret_cast<float4*>(Ks + kr * 32 + 4 * c4) = v;
+  }
+  float key_bias = key_ok ? 0.f : -INFINITY;
+  if (HAS_MASK && key_ok && a.kpm[(long)b * a.L + key]) key_bias = -INFINITY;
+
+  f32x16 dKt, dVt;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dKt[r] = dVt[r] = 0.f;
+
+  const int qtiles = (a.Q + 31) / 32;
+  const int qt_begin = qs * p.qtiles_per_split;
+  const int qt_end = min(qtiles, qt_begin + p.qtiles_per_split);
+  const float inv_scale = 1.f / a.scale;
+  const float sc2 = a.scale * LOG2E;
+
+  // register prefetch of a query tile: thread -> (row = t>>3, 4 columns at 4*(t&7))
+  float4 qreg, greg;
+  float lreg = 0.f, dreg = 0.f;
+  auto gload = [&](int qt) {
+    const int row = qt * 32 + (t >> 3), c4 = t & 7;
+    qreg = greg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < a.Q) {
+      const float* s = qp + (long)row * a.q_rs + 4 * c4;
+      const float* g = gp + (long)row * a.do_rs + 4 * c4;
+      if (p.vec) {
+        qreg = *reinterpret_cast<const float4*>(s);
+        greg = *reinterpret_cast<const float4*>(g);
+      } else {
+        qreg = make_float4(s[0], s[1], s[2], s[3]);
+        greg = make_float4(g[0], g[1], g[2], g[3]);
+      }
+    }
+    if (t < 32) {
+      const int r = qt * 32 + t;
+      // rows beyond Q: -LSE/scale = -inf  =>  p = 0
+      lreg = r < a.Q ? -a.lse[(long)bh * a.Q + r] * inv_scale : -INFINITY;
+      dreg = r < a.Q ? -p.delta[(long)bh * a.Q + r] : 0.f;
+    }
+  };
+
+  if (qt_begin < qt_end) gload(qt_begin);
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
+    {
+      const int row = t >> 3, c4 = t & 7;
+      float* d = Qs + row * P33 + 4 * c4;
+      d[0] = qreg.x; d[1] = qreg.y; d[2] = qreg.z; d[3] = qreg.w;
+      float* e = dOs + row * P33 + 4 * c4;
+      e[0] = greg.x; e[1] = greg.y; e[2] = greg.z; e[3] = greg.w;
+      if (t < 32) { lse_s[t] = lreg; dl_s[t] = dreg; }
+    }
+    __syncthreads();
+    if (qt + 1 < qt_end) gload(qt + 1);
+
+    f32x16 S, dP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = mfma32_row(r, h);
+      S[r] = lse_s[qr] + key_bias;
+      dP[r] = dl_s[qr];
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[c * P33 + 16 * h + s], kf[s], S, 0, 0, 0);
+      dP = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[c * P33 + 16 * h + s], vf[s], dP, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S[r] = __builtin_amdgcn_exp2f(S[r] * sc2);   // p
+      dP[r] = S[r] * dP[r];                        // ds (without the softmax scale)
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int qr = mfma32_row(s, h);
+      dVt = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[qr * P33 + c], S[s], dVt, 0, 0, 0);
+      dKt = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qr * P33 + c], dP[s], dKt, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dSs[wave][mfma32_row(r, h) * P33 + c] = dP[r];
+    __syncthreads();
+
+    f32x16 dQp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dQp[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      dQp = __builtin_amdgcn_mfma_f32_32x32x2f32(dSs[wave][c * P33 + 16 * h + s], Ks[(wave * 32 + 16 * h + s) * 32 + c],
+                                                 dQp, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][mfma32_row(r, h) * 32 + c] = dQp[r];
+    __syncthreads();
+    {
+      float* dq = a.dq + (long)b * a.dq_bs + (long)hd * a.dq_hs;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = t + 256 * j;
+        const int qr = qt * 32 + (idx >> 5), d = idx & 31;
+        const float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+        if (qr < a.Q) atomicAdd(dq + (long)qr * a.dq_rs + d, v * a.scale);
+      }
+    }
+  }
+
+  // ---- dK / dV: transpose each wave's 32x32 accumulators through LDS, then row-major adds ----
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    red[wave][c * P33 + mfma32_row(r, h)] = dKt[r] * a.scale;
+    dSs[wave][c * P33 + mfma32_row(r, h)] = dVt[r];
+  }
+  __syncthreads();
+  {
+    float* dk = a.dk + (long)b * a.dk_bs + (long)hd * a.dk_hs;
+    float* dv = a.dv + (long)b * a.dv_bs + (long)hd * a.dv_hs;
+    const bool use_atomic = p.q_splits > 1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int idx = j * 64 + lane;
+      const int kr = idx >> 5, d = idx & 31;
+      const int kg = key0 + kr;
+      if (kg < a.L) {
+        const float gk = red[wave][kr * P33 + d], gv = dSs[wave][kr * P33 + d];
+        float* pk = dk + (long)kg * a.dk_rs + d;
+        float* pv = dv + (long)kg * a.dv_rs + d;
+        if (use_atomic) {
+          atomicAdd(pk, gk);
+          atomicAdd(pv, gv);
+        } else {
+          *pk += gk;
+          *pv += gv;
+        }
+      }
+    }
+  }
+}
+
+int choose_q_splits(int B, int H, int Q, int L) {
+  const long base = cdiv(L, 128) * (long)B * H;
+  const int qtiles = (int)cdiv(Q, 32);
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= qtiles && s <= 16; ++s) {
+    const int per = (int)cdiv(qtiles, s);
+    if ((long)(s - 1) * per >= qtiles) continue;
+    const double cost = (double)cdiv(base * s, 256) * per + 1.0 * s;
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+
+}  // namespace
+
+extern "C" size_t petr_mha_bwd_workspace_bytes(int B, int H, int Q, int L) {
+  (void)L;
+  return (size_t)B * H * Q * sizeof(float);
+}
+
+extern "C" int petr_mha_bwd(const petr_mha_bwd_args* ap, void* stream) {
+  PETR_CHECK(ap && ap->q && ap->k && ap->v && ap->o && ap->d_o && ap->lse && ap->dq && ap->dk && ap->dv, PETR_ERR_INVALID,
+             "mha_bwd: null pointer");
+  PETR_CHECK(ap->B > 0 && ap->H > 0 && ap->Q > 0 && ap->L > 0, PETR_ERR_INVALID, "mha_bwd: bad shape");
+  const size_t need = petr_mha_bwd_workspace_bytes(ap->B, ap->H, ap->Q, ap->L);
+  PETR_CHECK(ap->ws && ap->ws_bytes >= need, PETR_ERR_WORKSPACE, "mha_bwd: workspace %zu < %zu bytes", ap->ws_bytes, need);
+  MhaBwdParams p;
+  p.a = *ap;
+  const petr_mha_bwd_args& a = p.a;
+  p.nkb = (int)cdiv(a.L, 128);
+  p.q_splits = choose_q_splits(a.B, a.H, a.Q, a.L);
+  p.qtiles_per_split = (int)cdiv(cdiv(a.Q, 32), p.q_splits);
+  p.delta = (const float*)a.ws;
+  p.vec = aligned16(a.q) && aligned16(a.d_o) && !(a.q_bs & 3) && !(a.q_hs & 3) && !(a.q_rs & 3) && !(a.do_bs & 3) &&
+          !(a.do_hs & 3) && !(a.do_rs & 3);
+  hipStream_t s = (hipStream_t)stream;
+  const long nrow8 = (long)a.B * a.H * a.Q * 8;
+  hipLaunchKernelGGL(mha_delta_kernel, dim3((unsigned)cdiv(nrow8, 256)), dim3(256), 0, s, a, (float*)a.ws);
+  PETR_LAUNCH_CHECK("mha_delta");
+  const long total = (long)p.nkb * a.B * a.H * p.q_splits;
+  PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_bwd: grid too large");
+  if (a.kpm) hipLaunchKernelGGL(mha_bwd_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(mha_bwd_kernel<false>, dim3((unsigned)total), dim3(256), 0, s, p);
+  PETR_LAUNCH_CHECK("mha_bwd");
+  return PETR_OK;
+}

@@ -1,0 +1,293 @@
+// Multi-head attention forward for the PETR decoder (head_dim 32, fp32, flash-style).
+//
+// Replaces the bmm -> softmax -> bmm inside torch.nn.MultiheadAttention reached from
+// PETRMultiheadAttention.forward (reference models/utils/petr_transformer.py:357-362): 900 object
+// queries against L = N*H*W key/value tokens (4 224 ... 24 000), and the 900x900 self-attention.
+// Scores are never written to memory.
+//
+// Mapping (one wave = 32 queries, workgroup = 4 waves = 128 queries, KV tile = 64 keys in LDS):
+//   S^T[key][q] = K . Q^T   : A = K tile (row = key), B = Q^T  -> v_mfma_f32_32x32x2_f32 x16
+//     ("swapped" product: the query lands on the LANE, the keys on the 16 accumulator registers,
+//      so the softmax row reduction is 15 in-lane max/add + ONE v_permlane32_swap; no LDS, no shuffles)
+//   O^T[d][q]  += V^T . P^T : the P accumulator registers are used AS the B operand of the second
+//     product (k-order permuted identically on the V side: step s multiplies key mfma32_row(s,h)),
+//     so P never leaves the register file.
+// LDS images: K transposed [d][key] with pitch 65 (transposing ds_write_b32 of a float4 hit 32
+// distinct banks; fragment reads are 32 consecutive floats), V natural [key][32].
+// K/V tiles are register-prefetched one tile ahead (cdna guide T14).
+// B=1 gives only 8 heads x 8 query blocks = 64 workgroups, so L is split over workgroups
+// (flash-decoding): each split writes (O, m, l) partials and a second kernel merges them.
+// Workgroup ids are XCD-remapped so that the query blocks sharing one (head, L-split) K/V slice
+// run on the same XCD and share its L2.
+#include "common.h"
+
+namespace {
+
+constexpr int KV_TILE = 64;
+constexpr int KT_PITCH = 65;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct MhaFwdParams {
+  petr_mha_fwd_args a;
+  int nqb, n_split, tiles_per_split;
+  float* o_part;   // [n_split][B*H][Q][32]
+  float* ml_part;  // [n_split][B*H][Q][2]
+  int q_vec, kv_vec;
+};
+
+template <bool HAS_MASK>
+__global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
+  __shared__ __attribute__((aligned(16))) float Kt[32 * KT_PITCH];
+  __shared__ __attribute__((aligned(16))) float Vs[KV_TILE * 32];
+  __shared__ float bias_s[KV_TILE];
+
+  const petr_mha_fwd_args& a = p.a;
+  const int total = p.nqb * a.B * a.H * p.n_split;
+  const int w = xcd_remap(blockIdx.x, total);
+  const int qb = w % p.nqb;
+  const int rest = w / p.nqb;
+  const int split = rest % p.n_split;
+  const int bh = rest / p.n_split;
+  const int b = bh / a.H, hd = bh - b * a.H;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  const int q_row = qb * 128 + wave * 32 + c;
+  const int q_ld = min(q_row, a.Q - 1);
+
+  const int k_begin = split * p.tiles_per_split * KV_TILE;
+  const int k_end = min(a.L, k_begin + p.tiles_per_split * KV_TILE);
+
+  // ---- Q fragment: lane (c,h) holds Q[q][16h .. 16h+15], pre-scaled by scale*log2(e) ----
+  float qf[16];
+  {
+    const float* qp = a.q + (long)b * a.q_bs + (long)hd * a.q_hs + (long)q_ld * a.q_rs + 16 * h;
+    const float sc = a.scale * LOG2E;
+    if (p.q_vec) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = reinterpret_cast<const float4*>(qp)[i];
+        qf[4 * i] = v.x * sc; qf[4 * i + 1] = v.y * sc; qf[4 * i + 2] = v.z * sc; qf[4 * i + 3] = v.w * sc;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) qf[i] = qp[i] * sc;
+    }
+  }
+
+  const float* kp = a.k + (long)b * a.k_bs + (long)hd * a.k_hs;
+  const float* vp = a.v + (long)b * a.v_bs + (long)hd * a.v_hs;
+  const uint8_t* mp = HAS_MASK ? a.kpm + (long)b * a.L : nullptr;
+
+  float4 kreg[2], vreg[2];
+  float breg = 0.f;
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = t + 256 * i;
+      const int kg = k0 + (idx >> 3), c4 = idx & 7;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (kg < k_end) {
+        const float* ks = kp + (long)kg * a.k_rs + 4 * c4;
+        const float* vs = vp + (long)kg * a.v_rs + 4 * c4;
+        if (p.kv_vec) {
+          kv = *reinterpret_cast<const float4*>(ks);
+          vv = *reinterpret_cast<const float4*>(vs);
+        } else {
+          kv = make_float4(ks[0], ks[1], ks[2], ks[3]);
+          vv = make_float4(vs[0], vs[1], vs[2], vs[3]);
+        }
+      }
+      kreg[i] = kv;
+      vreg[i] = vv;
+    }
+    if (t < KV_TILE) {
+      const int kg = k0 + t;
+      bool dead = kg >= k_end;
+      if (HAS_MASK && !dead) dead = mp[kg] != 0;
+      breg = dead ? -INFINITY : 0.f;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = t + 256 * i;
+      const int key = idx >> 3, c4 = idx & 7;
+      float* d = Kt + (4 * c4) * KT_PITCH + key;
+      d[0] = kreg[i].x;
+      d[KT_PITCH] = kreg[i].y;
+      d[2 * KT_PITCH] = kreg[i].z;
+      d[3 * KT_PITCH] = kreg[i].w;
+      *reinterpret_cast<float4*>(Vs + key * 32 + 4 * c4) = vreg[i];
+    }
+    if (t < KV_TILE) bias_s[t] = breg;
+  };
+
+  f32x16 O;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) O[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  if (k_begin < k_end) gload(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += KV_TILE) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (k0 + KV_TILE < k_end) gload(k0 + KV_TILE);
+    const bool use_bias = HAS_MASK || (k0 + KV_TILE > k_end);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      if (k0 + sub * 32 >= k_end) break;   // uniform: whole sub-tile beyond the slice
+      f32x16 S;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[(16 * h + s) * KT_PITCH + sub * 32 + c], qf[s], S, 0, 0, 0);
+      if (use_bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] += bias_s[sub * 32 + mfma32_row(r, h)];
+      }
+      float mx = S[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+      mx = xhalf_max(mx);
+      const float m_new = fmaxf(m_run, mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        S[r] = __builtin_amdgcn_exp2f(S[r] - m_use);
+        rs += S[r];
+      }
+      rs = xhalf_sum(rs);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[r] *= alpha;
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        O = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(sub * 32 + mfma32_row(s, h)) * 32 + c], S[s], O, 0, 0, 0);
+    }
+  }
+
+  if (q_row >= a.Q) return;
+  if (p.n_split == 1) {
+    const float inv = 1.f / l_run;   // fully masked row: 0 * inf = NaN, as torch's softmax of all -inf
+    float* op = a.o + (long)b * a.o_bs + (long)hd * a.o_hs + (long)q_row * a.o_rs;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = 8 * g + 4 * h;
+      op[d0] = O[4 * g] * inv;
+      op[d0 + 1] = O[4 * g + 1] * inv;
+      op[d0 + 2] = O[4 * g + 2] * inv;
+      op[d0 + 3] = O[4 * g + 3] * inv;
+    }
+    if (a.lse && h == 0) a.lse[(long)bh * a.Q + q_row] = (m_run + log2f(l_run)) * LN2;
+  } else {
+    const long row = ((long)split * a.B * a.H + bh) * a.Q + q_row;
+    float* op = p.o_part + row * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(op + 8 * g + 4 * h) = make_float4(O[4 * g], O[4 * g + 1], O[4 * g + 2], O[4 * g + 3]);
+    if (h == 0) {
+      p.ml_part[row * 2] = m_run;
+      p.ml_part[row * 2 + 1] = l_run;
+    }
+  }
+}
+
+// merge the L-split partials: thread = (row, 4 consecutive d)
+__global__ __launch_bounds__(256) void mha_combine_kernel(const MhaFwdParams p) {
+  const petr_mha_fwd_args& a = p.a;
+  const long rows = (long)a.B * a.H * a.Q;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * 8) return;
+  const long row = idx >> 3;
+  const int d4 = (int)(idx & 7);
+  float M = -INFINITY;
+  for (int s = 0; s < p.n_split; ++s) M = fmaxf(M, p.ml_part[((long)s * rows + row) * 2]);
+  float L = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < p.n_split; ++s) {
+    const float ms = p.ml_part[((long)s * rows + row) * 2];
+    const float ls = p.ml_part[((long)s * rows + row) * 2 + 1];
+    // M == -inf (every key of the row masked): exp2(-inf - -inf) = NaN, propagating like the reference
+    const float wgt = __builtin_amdgcn_exp2f(ms - M);
+    const float4 o = *reinterpret_cast<const float4*>(p.o_part + ((long)s * rows + row) * 32 + 4 * d4);
+    L += ls * wgt;
+    acc.x += o.x * wgt; acc.y += o.y * wgt; acc.z += o.z * wgt; acc.w += o.w * wgt;
+  }
+  const float inv = 1.f / L;
+  const int q = (int)(row % a.Q);
+  const int bh = (int)(row / a.Q);
+  const int b = bh / a.H, hd = bh - b * a.H;
+  float* op = a.o + (long)b * a.o_bs + (long)hd * a.o_hs + (long)q * a.o_rs + 4 * d4;
+  op[0] = acc.x * inv; op[1] = acc.y * inv; op[2] = acc.z * inv; op[3] = acc.w * inv;
+  if (a.lse && d4 == 0) a.lse[row] = (M + log2f(L)) * LN2;
+}
+
+}  // namespace
+
+extern "C" int petr_mha_choose_split(int B, int H, int Q, int L) {
+  const long base = cdiv(Q, 128) * (long)B * H;
+  const int tiles = (int)cdiv(L, KV_TILE);
+  int best = 1;
+  double best_cost = 1e30;
+  for (int ns = 1; ns <= tiles && ns <= 64; ++ns) {
+    const int per = (int)cdiv(tiles, ns);
+    if ((long)(ns - 1) * per >= tiles) continue;   // would leave an empty split
+    const long wgs = base * ns;
+    double cost = (double)cdiv(wgs, 256) * per;
+    if (wgs < 512) cost *= 1.5;                    // < 2 workgroups per CU: softmax cannot hide under MFMA
+    if (ns > 1) cost += 0.25;                      // merge pass
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = ns; }
+  }
+  return best;
+}
+
+extern "C" size_t petr_mha_fwd_workspace_bytes(int B, int H, int Q, int L, int n_split) {
+  if (n_split <= 0) n_split = petr_mha_choose_split(B, H, Q, L);
+  if (n_split == 1) return 0;
+  return (size_t)n_split * B * H * Q * (32 + 2) * sizeof(float);
+}
+
+extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
+  PETR_CHECK(ap && ap->q && ap->k && ap->v && ap->o, PETR_ERR_INVALID, "mha_fwd: null pointer");
+  PETR_CHECK(ap->B > 0 && ap->H > 0 && ap->Q > 0 && ap->L > 0, PETR_ERR_INVALID, "mha_fwd: bad shape");
+  MhaFwdParams p;
+  p.a = *ap;
+  const petr_mha_fwd_args& a = p.a;
+  p.nqb = (int)cdiv(a.Q, 128);
+  int ns = a.n_split > 0 ? a.n_split : petr_mha_choose_split(a.B, a.H, a.Q, a.L);
+  const int tiles = (int)cdiv(a.L, KV_TILE);
+  if (ns > tiles) ns = tiles;
+  p.n_split = ns;
+  p.tiles_per_split = (int)cdiv(tiles, ns);
+  p.o_part = nullptr;
+  p.ml_part = nullptr;
+  if (ns > 1) {
+    const size_t need = petr_mha_fwd_workspace_bytes(a.B, a.H, a.Q, a.L, ns);
+    PETR_CHECK(a.ws && a.ws_bytes >= need && aligned16(a.ws), PETR_ERR_WORKSPACE,
+               "mha_fwd: workspace %zu < %zu bytes", a.ws_bytes, need);
+    p.o_part = (float*)a.ws;
+    p.ml_part = p.o_part + (size_t)ns * a.B * a.H * a.Q * 32;
+  }
+  p.q_vec = aligned16(a.q) && !(a.q_bs & 3) && !(a.q_hs & 3) && !(a.q_rs & 3);
+  p.kv_vec = aligned16(a.k) && aligned16(a.v) && !(a.k_bs & 3) && !(a.k_hs & 3) && !(a.k_rs & 3) && !(a.v_bs & 3) &&
+             !(a.v_hs & 3) && !(a.v_rs & 3);
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)p.nqb * a.B * a.H * ns;
+  PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_fwd: grid too large");
+  if (a.kpm) hipLaunchKernelGGL(mha_fwd_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(mha_fwd_kernel<false>, dim3((unsigned)total), dim3(256), 0, s, p);
+  PETR_LAUNCH_CHECK("mha_fwd");
+  if (ns > 1) {
+    const long n = (long)a.B * a.H * a.Q * 8;
+    hipLaunchKernelGGL(mha_combine_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, p);
+    PETR_LAUNCH_CHECK("mha_combine");
+  }
+  return PETR_OK;
+}

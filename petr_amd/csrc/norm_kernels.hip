@@ -1,0 +1,426 @@
+// Row-wise / elementwise kernels of the PETRHead path (all HBM- or latency-bound):
+// LayerNorm forward/backward with fused partial-sum + bias + residual prologue, column sums for
+// bias gradients, the box-decoding epilogue and its gradient, and small reducers.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXV = 4;  // float4 chunks per lane: C <= 1024
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm forward: one wave per row, row kept in registers (two-pass mean / variance).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nan_to_num_f(float v) {
+  if (v != v) return 0.f;
+  if (v == INFINITY) return 3.402823466e+38f;
+  if (v == -INFINITY) return -3.402823466e+38f;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(petr_layernorm_args a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.M) return;
+  const int nv = a.C >> 2;
+  float4 v[LN_MAXV];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int i4 = lane + 64 * j;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < nv) {
+      x = reinterpret_cast<const float4*>(a.x + (size_t)row * a.C)[i4];
+      for (int p = 1; p < a.n_partials; ++p) {
+        const float4 y = reinterpret_cast<const float4*>(a.x + (size_t)p * a.partial_stride + (size_t)row * a.C)[i4];
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+      }
+      if (a.bias) {
+        const float4 y = reinterpret_cast<const float4*>(a.bias)[i4];
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+      }
+      if (a.residual) {
+        const float4 y = reinterpret_cast<const float4*>(a.residual + (size_t)row * a.C)[i4];
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+      }
+      if (a.z_out) reinterpret_cast<float4*>(a.z_out + (size_t)row * a.C)[i4] = x;
+      sum += (x.x + x.y) + (x.z + x.w);
+    }
+    v[j] = x;
+  }
+  const float mean = wave_sum(sum) / (float)a.C;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    if (lane + 64 * j < nv) {
+      const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+      sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float var = wave_sum(sq) / (float)a.C;
+  const float rstd = 1.f / sqrtf(var + a.eps);
+  if (lane == 0) {
+    if (a.mean) a.mean[row] = mean;
+    if (a.rstd) a.rstd[row] = rstd;
+  }
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int i4 = lane + 64 * j;
+    if (i4 < nv) {
+      const float4 gm = reinterpret_cast<const float4*>(a.gamma)[i4];
+      const float4 bt = reinterpret_cast<const float4*>(a.beta)[i4];
+      float4 y;
+      y.x = (v[j].x - mean) * rstd * gm.x + bt.x;
+      y.y = (v[j].y - mean) * rstd * gm.y + bt.y;
+      y.z = (v[j].z - mean) * rstd * gm.z + bt.z;
+      y.w = (v[j].w - mean) * rstd * gm.w + bt.w;
+      if (a.flags & PETR_LN_RELU) {
+        y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+      }
+      if (a.flags & PETR_LN_NAN_TO_NUM) {
+        y.x = nan_to_num_f(y.x); y.y = nan_to_num_f(y.y); y.z = nan_to_num_f(y.z); y.w = nan_to_num_f(y.w);
+      }
+      reinterpret_cast<float4*>(a.y + (size_t)row * a.C)[i4] = y;
+      if (a.y2) {
+        const int r2 = a.add2_rows > 0 ? row % a.add2_rows : row;
+        const float4 e = reinterpret_cast<const float4*>(a.add2 + (size_t)r2 * a.C)[i4];
+        reinterpret_cast<float4*>(a.y2 + (size_t)row * a.C)[i4] = make_float4(y.x + e.x, y.y + e.y, y.z + e.z, y.w + e.w);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm backward.  Each block walks rows block-stride, every lane owns fixed columns, so
+// dgamma/dbeta accumulate in registers; per-block partials -> ws, reduced by a second kernel
+// (deterministic, no atomics).
+// ------------------------------------------------------------------------------------------
+constexpr int LNB_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(petr_layernorm_bwd_args a, int nblocks) {
+  __shared__ float red[2][4][LN_MAXV * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = a.C >> 2;
+  float4 dg[LN_MAXV], db[LN_MAXV];
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) dg[j] = db[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int row = blockIdx.x * 4 + wave; row < a.M; row += nblocks * 4) {
+    const float mean = a.mean[row], rstd = a.rstd[row];
+    float4 xh[LN_MAXV], g[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int i4 = lane + 64 * j;
+      xh[j] = g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i4 < nv) {
+        const float4 z = reinterpret_cast<const float4*>(a.z + (size_t)row * a.C)[i4];
+        float4 dy = reinterpret_cast<const float4*>(a.dy + (size_t)row * a.C)[i4];
+        if (a.flags & PETR_LN_RELU) {
+          const float4 y = reinterpret_cast<const float4*>(a.y + (size_t)row * a.C)[i4];
+          dy.x = y.x > 0.f ? dy.x : 0.f; dy.y = y.y > 0.f ? dy.y : 0.f;
+          dy.z = y.z > 0.f ? dy.z : 0.f; dy.w = y.w > 0.f ? dy.w : 0.f;
+        }
+        const float4 gm = reinterpret_cast<const float4*>(a.gamma)[i4];
+        xh[j] = make_float4((z.x - mean) * rstd, (z.y - mean) * rstd, (z.z - mean) * rstd, (z.w - mean) * rstd);
+        g[j] = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
+        s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+        s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+        dg[j].x += dy.x * xh[j].x; dg[j].y += dy.y * xh[j].y; dg[j].z += dy.z * xh[j].z; dg[j].w += dy.w * xh[j].w;
+        db[j].x += dy.x; db[j].y += dy.y; db[j].z += dy.z; db[j].w += dy.w;
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)a.C, m2 = wave_sum(s2) / (float)a.C;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int i4 = lane + 64 * j;
+      if (i4 < nv) {
+        float4 d;
+        d.x = rstd * (g[j].x - m1 - xh[j].x * m2);
+        d.y = rstd * (g[j].y - m1 - xh[j].y * m2);
+        d.z = rstd * (g[j].z - m1 - xh[j].z * m2);
+        d.w = rstd * (g[j].w - m1 - xh[j].w * m2);
+        float4* dst = reinterpret_cast<float4*>(a.dz + (size_t)row * a.C) + i4;
+        if (a.dz_accumulate) { const float4 o = *dst; d.x += o.x; d.y += o.y; d.z += o.z; d.w += o.w; }
+        *dst = d;
+      }
+    }
+  }
+  // cross-wave reduction of the column partials
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int i4 = lane + 64 * j;
+    reinterpret_cast<float4*>(red[0][wave])[i4] = dg[j];
+    reinterpret_cast<float4*>(red[1][wave])[i4] = db[j];
+  }
+  __syncthreads();
+  float* ws = reinterpret_cast<float*>(a.ws);
+  for (int cidx = threadIdx.x; cidx < a.C; cidx += 256) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { sg += red[0][w][cidx]; sb += red[1][w][cidx]; }
+    ws[(size_t)blockIdx.x * 2 * a.C + cidx] = sg;
+    ws[(size_t)blockIdx.x * 2 * a.C + a.C + cidx] = sb;
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* ws, int nblocks, int C, float* dgamma,
+                                                                    float* dbeta) {
+  const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cidx >= 2 * C) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += ws[(size_t)b * 2 * C + cidx];
+  if (cidx < C) { if (dgamma) dgamma[cidx] += s; }
+  else { if (dbeta) dbeta[cidx - C] += s; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Column sums (bias gradients): 32 row-chunks x 64-column stripes -> partials -> final add.
+// ------------------------------------------------------------------------------------------
+constexpr int CS_CHUNKS = 32;
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, int M, int N, float* ws) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  const int per = (M + CS_CHUNKS - 1) / CS_CHUNKS;
+  const int r0 = blockIdx.y * per, r1 = min(M, r0 + per);
+  float s = 0.f;
+  if (n < N)
+    for (int r = r0 + wave; r < r1; r += 4) s += x[(size_t)r * ld + n];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && n < N) ws[(size_t)blockIdx.y * N + n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* ws, int N, float* out, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int c = 0; c < CS_CHUNKS; ++c) s += ws[(size_t)c * N + n];
+  out[n] = accumulate ? out[n] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Box epilogue (petr_head.py:441-460)
+// ------------------------------------------------------------------------------------------
+struct BboxParams {
+  const float* reg; const float* ref; float* out;
+  int rows, Q, code;
+  float lo[3], span[3];
+  float time_div, eps;
+};
+
+__device__ __forceinline__ float inv_sigmoid_dev(float x, float eps) {
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  return logf(fmaxf(x, eps) / fmaxf(1.f - x, eps));
+}
+
+__global__ __launch_bounds__(256) void bbox_fwd_kernel(BboxParams p) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)p.rows * p.code) return;
+  const int row = (int)(idx / p.code), ch = (int)(idx - (long)row * p.code);
+  const int q = row % p.Q;
+  float t = p.reg[idx];
+  const int ax = ch == 0 ? 0 : (ch == 1 ? 1 : (ch == 4 ? 2 : -1));
+  if (ax >= 0) {
+    t += inv_sigmoid_dev(p.ref[q * 3 + ax], p.eps);
+    t = 1.f / (1.f + expf(-t));
+    t = t * p.span[ax] + p.lo[ax];
+  } else if (ch >= 8 && p.time_div != 0.f) {
+    t = t / p.time_div;
+  }
+  p.out[idx] = t;
+}
+
+// thread per (q, ch): loops over the rows/Q (level, batch) copies so that dref needs no atomics
+__global__ __launch_bounds__(256) void bbox_bwd_kernel(BboxParams p, const float* dout, float* dreg, float* dref) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.Q * p.code) return;
+  const int q = idx / p.code, ch = idx - q * p.code;
+  const int ax = ch == 0 ? 0 : (ch == 1 ? 1 : (ch == 4 ? 2 : -1));
+  const int copies = p.rows / p.Q;
+  float racc = 0.f;
+  for (int cpy = 0; cpy < copies; ++cpy) {
+    const long off = ((long)cpy * p.Q + q) * p.code + ch;
+    float g = dout[off];
+    if (ax >= 0) {
+      const float s = (p.out[off] - p.lo[ax]) / p.span[ax];
+      g = g * p.span[ax] * s * (1.f - s);
+      racc += g;
+    } else if (ch >= 8 && p.time_div != 0.f) {
+      g = g / p.time_div;
+    }
+    dreg[off] = g;
+  }
+  if (ax >= 0 && dref) {
+    const float r = p.ref[q * 3 + ax];
+    // d/dr log(clamp(r,eps)/clamp(1-r,eps)) on the un-clamped interior; 0 where a clamp is active
+    float d = 0.f;
+    if (r > 0.f && r < 1.f) {
+      if (r > p.eps) d += 1.f / r;
+      if (1.f - r > p.eps) d += 1.f / (1.f - r);
+    }
+    dref[q * 3 + ax] += racc * d;
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* p, float v, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, float alpha, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += alpha * x[i];
+}
+__global__ __launch_bounds__(256) void add_rows_kernel(const float4* x, const float4* e, float4* out, long n4, long e_n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 a = x[i], b = e[i % e_n4];
+  out[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* x, int np, long stride, const float* bias,
+                                                               const float* residual, float* out, long M, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * C) return;
+  float s = x[i];
+  for (int p = 1; p < np; ++p) s += x[(size_t)p * stride + i];
+  if (bias) s += bias[i % C];
+  if (residual) s += residual[i];
+  out[i] = s;
+}
+__global__ __launch_bounds__(256) void reduce_batch_kernel(const float* x, int B, long n, float* out, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += x[(size_t)b * n + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+}  // namespace
+
+extern "C" int petr_layernorm_fwd(const petr_layernorm_args* a, void* stream) {
+  PETR_CHECK(a && a->x && a->gamma && a->beta && a->y, PETR_ERR_INVALID, "layernorm: null pointer");
+  PETR_CHECK(a->M > 0 && a->C > 0 && (a->C & 3) == 0 && a->C <= 256 * LN_MAXV, PETR_ERR_UNSUPPORTED,
+             "layernorm: C=%d must be a multiple of 4 and <= 1024", a->C);
+  PETR_CHECK(aligned16(a->x) && aligned16(a->y) && aligned16(a->gamma) && aligned16(a->beta) &&
+                 (!a->bias || aligned16(a->bias)) && (!a->residual || aligned16(a->residual)) &&
+                 (!a->z_out || aligned16(a->z_out)) && (a->partial_stride & 3) == 0 &&
+                 (!a->y2 || (a->add2 && aligned16(a->y2) && aligned16(a->add2))),
+             PETR_ERR_INVALID, "layernorm: pointers must be 16-byte aligned");
+  petr_layernorm_args p = *a;
+  if (p.n_partials <= 0) p.n_partials = 1;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)cdiv(a->M, 4)), dim3(256), 0, (hipStream_t)stream, p);
+  PETR_LAUNCH_CHECK("layernorm_fwd");
+  return PETR_OK;
+}
+
+extern "C" size_t petr_layernorm_bwd_workspace_bytes(int M, int C) {
+  (void)M;
+  return (size_t)LNB_BLOCKS * 2 * C * sizeof(float);
+}
+
+extern "C" int petr_layernorm_bwd(const petr_layernorm_bwd_args* a, void* stream) {
+  PETR_CHECK(a && a->z && a->mean && a->rstd && a->gamma && a->dy && a->dz && a->ws, PETR_ERR_INVALID,
+             "layernorm_bwd: null pointer");
+  PETR_CHECK(a->M > 0 && a->C > 0 && (a->C & 3) == 0 && a->C <= 256 * LN_MAXV, PETR_ERR_UNSUPPORTED,
+             "layernorm_bwd: C=%d unsupported", a->C);
+  PETR_CHECK(!(a->flags & PETR_LN_RELU) || a->y, PETR_ERR_INVALID, "layernorm_bwd: ReLU flag needs y");
+  const int nblocks = (int)((cdiv(a->M, 4) < LNB_BLOCKS) ? cdiv(a->M, 4) : LNB_BLOCKS);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblocks), dim3(256), 0, s, *a, nblocks);
+  PETR_LAUNCH_CHECK("layernorm_bwd");
+  if (a->dgamma || a->dbeta) {
+    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * a->C, 256)), dim3(256), 0, s,
+                       (const float*)a->ws, nblocks, a->C, a->dgamma, a->dbeta);
+    PETR_LAUNCH_CHECK("layernorm_bwd_reduce");
+  }
+  return PETR_OK;
+}
+
+extern "C" size_t petr_colsum_workspace_bytes(int N) { return (size_t)CS_CHUNKS * N * sizeof(float); }
+
+extern "C" int petr_colsum(const float* x, long ld, int M, int N, float* out, int accumulate, void* ws, void* stream) {
+  PETR_CHECK(x && out && ws && M > 0 && N > 0, PETR_ERR_INVALID, "colsum: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(N, 64), CS_CHUNKS), dim3(256), 0, s, x, ld, M, N, (float*)ws);
+  PETR_LAUNCH_CHECK("colsum");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, (const float*)ws, N, out,
+                     accumulate);
+  PETR_LAUNCH_CHECK("colsum_final");
+  return PETR_OK;
+}
+
+static BboxParams make_bbox(const petr_bbox_args* a) {
+  BboxParams p;
+  p.reg = a->reg; p.ref = a->ref; p.out = a->out;
+  p.rows = a->rows; p.Q = a->Q; p.code = a->code;
+  for (int i = 0; i < 3; ++i) {
+    p.lo[i] = a->pc_range[i];
+    p.span[i] = (float)((double)a->pc_range[i + 3] - (double)a->pc_range[i]);
+  }
+  p.time_div = a->time_div;
+  p.eps = a->eps;
+  return p;
+}
+
+extern "C" int petr_bbox_epilogue_fwd(const petr_bbox_args* a, void* stream) {
+  PETR_CHECK(a && a->reg && a->ref && a->out, PETR_ERR_INVALID, "bbox: null pointer");
+  PETR_CHECK(a->rows > 0 && a->Q > 0 && a->rows % a->Q == 0 && a->code >= 5, PETR_ERR_INVALID, "bbox: bad shape");
+  BboxParams p = make_bbox(a);
+  hipLaunchKernelGGL(bbox_fwd_kernel, dim3((unsigned)cdiv((long)a->rows * a->code, 256)), dim3(256), 0,
+                     (hipStream_t)stream, p);
+  PETR_LAUNCH_CHECK("bbox_fwd");
+  return PETR_OK;
+}
+
+extern "C" int petr_bbox_epilogue_bwd(const petr_bbox_args* a, const float* dout, float* dreg, float* dref, void* stream) {
+  PETR_CHECK(a && a->out && a->ref && dout && dreg, PETR_ERR_INVALID, "bbox_bwd: null pointer");
+  PETR_CHECK(a->rows > 0 && a->Q > 0 && a->rows % a->Q == 0 && a->code >= 5, PETR_ERR_INVALID, "bbox_bwd: bad shape");
+  BboxParams p = make_bbox(a);
+  hipLaunchKernelGGL(bbox_bwd_kernel, dim3((unsigned)cdiv((long)a->Q * a->code, 256)), dim3(256), 0,
+                     (hipStream_t)stream, p, dout, dreg, dref);
+  PETR_LAUNCH_CHECK("bbox_bwd");
+  return PETR_OK;
+}
+
+extern "C" int petr_fill(float* p, float v, long n, void* stream) {
+  PETR_CHECK(p && n >= 0, PETR_ERR_INVALID, "fill: bad argument");
+  if (n == 0) return PETR_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+  PETR_LAUNCH_CHECK("fill");
+  return PETR_OK;
+}
+
+extern "C" int petr_axpy(float* y, const float* x, float alpha, long n, void* stream) {
+  PETR_CHECK(y && x && n >= 0, PETR_ERR_INVALID, "axpy: bad argument");
+  if (n == 0) return PETR_OK;
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, y, x, alpha, n);
+  PETR_LAUNCH_CHECK("axpy");
+  return PETR_OK;
+}
+
+extern "C" int petr_add_rows(const float* x, const float* e, float* out, long M, int e_rows, int C, void* stream) {
+  PETR_CHECK(x && e && out && M > 0 && C > 0 && (C & 3) == 0 && aligned16(x) && aligned16(e) && aligned16(out),
+             PETR_ERR_INVALID, "add_rows: bad argument");
+  const long n4 = M * C / 4, e_n4 = (long)(e_rows > 0 ? e_rows : M) * C / 4;
+  hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                     (const float4*)e, (float4*)out, n4, e_n4);
+  PETR_LAUNCH_CHECK("add_rows");
+  return PETR_OK;
+}
+
+extern "C" int petr_reduce_partials(const float* x, int n_partials, long stride, const float* bias,
+                                    const float* residual, float* out, long M, int C, void* stream) {
+  PETR_CHECK(x && out && M > 0 && C > 0 && n_partials > 0, PETR_ERR_INVALID, "reduce_partials: bad argument");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(M * C, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     n_partials, stride, bias, residual, out, M, C);
+  PETR_LAUNCH_CHECK("reduce_partials");
+  return PETR_OK;
+}
+
+extern "C" int petr_reduce_batch(const float* x, int B, long rows, int C, float* out, int accumulate, void* stream) {
+  PETR_CHECK(x && out && B > 0 && rows > 0 && C > 0, PETR_ERR_INVALID, "reduce_batch: bad argument");
+  hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, B,
+                     rows * C, out, accumulate);
+  PETR_LAUNCH_CHECK("reduce_batch");
+  return PETR_OK;
+}

@@ -1,0 +1,284 @@
+// Position-embedding producers of the PETRHead path (HBM-bound, integer index generation -> fp32):
+//   K1  camera-frustum -> LiDAR coordinate volume      (reference petr_head.py:290-331)
+//   K3a SinePositionalEncoding3D features              (reference positional_encoding.py:58-100)
+//   K3b pos2posemb3d for the object queries            (reference petr_head.py:31-43)
+// Output layouts are the reference's ([B*N, C, H, W]); the GEMM consumes them directly as an
+// "M-contiguous" A operand, so no permute copy exists anywhere on the path.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// K1.  One thread = one depth bin d of 4 consecutive pixels of one view; writes 3 float4
+// (x,y,z channels 3d..3d+2).  blockIdx.y = view so the 4x4 inverse projection is wave-uniform
+// and is held in SGPRs (scalar loads through the constant cache) instead of LDS.
+// Arithmetic follows the reference op for op in fp32.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float logit_clamped(float x, float eps) {
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  const float x1 = fmaxf(x, eps);
+  const float x2 = fmaxf(1.f - x, eps);
+  return logf(x1 / x2);
+}
+
+struct Coords3dParams {
+  const float* img2lidar;
+  const float* depth;
+  float* out;
+  uint8_t* cmask;
+  int N, H, W, D;
+  float pad_h, pad_w;
+  float lo[3], span[3];
+  float eps;
+};
+
+__device__ __forceinline__ void frustum_point(const float* __restrict__ m, float u, float v, float dv, float eps,
+                                              const float lo[3], const float span[3], float nrm[3]) {
+  const float s = fmaxf(dv, eps);
+  const float p0 = u * s, p1 = v * s, p2 = dv;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float x = m[4 * a + 0] * p0;
+    x = fmaf(m[4 * a + 1], p1, x);
+    x = fmaf(m[4 * a + 2], p2, x);
+    x = x + m[4 * a + 3];
+    nrm[a] = (x - lo[a]) / span[a];
+  }
+}
+
+__global__ __launch_bounds__(256) void coords3d_kernel(Coords3dParams p) {
+  const int HW = p.H * p.W;
+  const int quads = HW >> 2;
+  const int bn = blockIdx.y;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= quads * p.D) return;
+  const int d = idx / quads;
+  const int quad = idx - d * quads;
+  const float* __restrict__ m = p.img2lidar + (size_t)bn * 16;  // uniform -> s_load
+  const float dv = p.depth[d];
+  float o[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int hw = quad * 4 + j;
+    const int h = hw / p.W, w = hw - h * p.W;
+    const float u = ((float)w * p.pad_w) / (float)p.W;
+    const float v = ((float)h * p.pad_h) / (float)p.H;
+    float nrm[3];
+    frustum_point(m, u, v, dv, p.eps, p.lo, p.span, nrm);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o[a][j] = logit_clamped(nrm[a], p.eps);
+  }
+  float* base = p.out + ((size_t)bn * 3 * p.D + 3 * d) * HW + quad * 4;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    *reinterpret_cast<float4*>(base + (size_t)a * HW) = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
+}
+
+// scalar-tail variant for H*W not a multiple of 4 (never the case in the BASELINE shapes)
+__global__ __launch_bounds__(256) void coords3d_scalar_kernel(Coords3dParams p) {
+  const int HW = p.H * p.W;
+  const int bn = blockIdx.y;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= HW * p.D) return;
+  const int d = idx / HW;
+  const int hw = idx - d * HW;
+  const int h = hw / p.W, w = hw - h * p.W;
+  const float* __restrict__ m = p.img2lidar + (size_t)bn * 16;
+  float nrm[3];
+  frustum_point(m, ((float)w * p.pad_w) / (float)p.W, ((float)h * p.pad_h) / (float)p.H, p.depth[d], p.eps, p.lo,
+                p.span, nrm);
+  float* base = p.out + ((size_t)bn * 3 * p.D + 3 * d) * HW + hw;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) base[(size_t)a * HW] = logit_clamped(nrm[a], p.eps);
+}
+
+// coords_mask (petr_head.py:327-328): returned by position_embeding() but discarded by
+// PETRHead.forward (:397), so it is a separate, optional kernel off the hot path.
+__global__ __launch_bounds__(256) void coords3d_mask_kernel(Coords3dParams p) {
+  const int HW = p.H * p.W;
+  const int bn = blockIdx.y;
+  const int hw = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hw >= HW) return;
+  const int h = hw / p.W, w = hw - h * p.W;
+  const float* __restrict__ m = p.img2lidar + (size_t)bn * 16;
+  const float u = ((float)w * p.pad_w) / (float)p.W;
+  const float v = ((float)h * p.pad_h) / (float)p.H;
+  int cnt = 0;
+  for (int d = 0; d < p.D; ++d) {
+    float nrm[3];
+    frustum_point(m, u, v, p.depth[d], p.eps, p.lo, p.span, nrm);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) cnt += (nrm[a] > 1.0f) | (nrm[a] < 0.0f);
+  }
+  p.cmask[(size_t)bn * HW + hw] = ((float)cnt > (float)p.D * 0.5f) ? 1 : 0;
+}
+
+extern "C" int petr_coords3d_fwd(const petr_coords3d_args* a, void* stream) {
+  PETR_CHECK(a && a->img2lidar && a->depth && (a->out || a->cmask), PETR_ERR_INVALID, "coords3d: null pointer");
+  PETR_CHECK(a->B > 0 && a->N > 0 && a->H > 0 && a->W > 0 && a->D > 0, PETR_ERR_INVALID, "coords3d: bad shape");
+  Coords3dParams p;
+  p.img2lidar = a->img2lidar;
+  p.depth = a->depth;
+  p.out = a->out;
+  p.cmask = a->cmask;
+  p.N = a->N; p.H = a->H; p.W = a->W; p.D = a->D;
+  p.pad_h = a->pad_h; p.pad_w = a->pad_w;
+  for (int i = 0; i < 3; ++i) {
+    p.lo[i] = a->range[i];
+    p.span[i] = (float)((double)a->range[i + 3] - (double)a->range[i]);
+  }
+  p.eps = a->eps;
+  const int HW = a->H * a->W, BN = a->B * a->N;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->out) {
+    if ((HW & 3) == 0 && aligned16(a->out)) {
+      dim3 grid((unsigned)cdiv((long)(HW / 4) * a->D, 256), BN);
+      hipLaunchKernelGGL(coords3d_kernel, grid, dim3(256), 0, s, p);
+    } else {
+      dim3 grid((unsigned)cdiv((long)HW * a->D, 256), BN);
+      hipLaunchKernelGGL(coords3d_scalar_kernel, grid, dim3(256), 0, s, p);
+    }
+    PETR_LAUNCH_CHECK("coords3d");
+  }
+  if (a->cmask) {
+    dim3 grid((unsigned)cdiv(HW, 256), BN);
+    hipLaunchKernelGGL(coords3d_mask_kernel, grid, dim3(256), 0, s, p);
+    PETR_LAUNCH_CHECK("coords3d_mask");
+  }
+  return PETR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K3a.  Block = 64 consecutive pixels of one (b, n) view.  Phase 1: 64x3 threads compute the
+// normalised cumulative-count embeddings (integer cumsum of the non-masked positions along
+// N / H / W, exactly as the reference) into LDS.  Phase 2: every thread emits (sin, cos) pairs
+// for its pixel over a strided set of channel pairs; stores are coalesced along the pixel axis.
+// ------------------------------------------------------------------------------------------
+struct Sine3dParams {
+  const uint8_t* mask;
+  const float* dim_t;
+  float* out;
+  int B, N, H, W, F;
+  int normalize;
+  float scale, eps, offset;
+};
+
+__global__ __launch_bounds__(256) void sine3d_kernel(Sine3dParams p) {
+  __shared__ float emb[3][64];
+  const int HW = p.H * p.W;
+  const int bn = blockIdx.y;
+  const int b = bn / p.N, n = bn - b * p.N;
+  const int pix0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+  if (t < 192) {
+    const int axis = t >> 6;  // 0: n, 1: y, 2: x  (concat order positional_encoding.py:99)
+    const int hw = pix0 + (t & 63);
+    if (hw < HW) {
+      const int h = hw / p.W, w = hw - h * p.W;
+      int cum = 0, tot = 0;
+      if (p.mask == nullptr) {
+        if (axis == 0) { cum = n + 1; tot = p.N; }
+        else if (axis == 1) { cum = h + 1; tot = p.H; }
+        else { cum = w + 1; tot = p.W; }
+      } else {
+        const uint8_t* mb = p.mask + (size_t)b * p.N * HW;
+        if (axis == 0) {
+          for (int i = 0; i < p.N; ++i) { const int v = mb[(size_t)i * HW + hw] ? 0 : 1; tot += v; if (i <= n) cum += v; }
+        } else if (axis == 1) {
+          for (int i = 0; i < p.H; ++i) { const int v = mb[(size_t)n * HW + i * p.W + w] ? 0 : 1; tot += v; if (i <= h) cum += v; }
+        } else {
+          for (int i = 0; i < p.W; ++i) { const int v = mb[(size_t)n * HW + h * p.W + i] ? 0 : 1; tot += v; if (i <= w) cum += v; }
+        }
+      }
+      float e = (float)cum;
+      if (p.normalize) e = (e + p.offset) / ((float)tot + p.eps) * p.scale;
+      emb[axis][t & 63] = e;
+    }
+  }
+  __syncthreads();
+  const int pix = t & 63;
+  const int hw = pix0 + pix;
+  if (hw >= HW) return;
+  const int half = p.F >> 1;           // channel pairs per axis
+  const int pairs = 3 * half;
+  float* ob = p.out + (size_t)bn * 3 * p.F * HW + hw;
+  for (int pr = t >> 6; pr < pairs; pr += 4) {
+    const int axis = pr / half;
+    const int k = pr - axis * half;
+    const float e = emb[axis][pix];
+    // positional_encoding.py:90-98 stacks (sin(even), cos(odd)) on a NEW dim 4 of a 5-D tensor and
+    // flattens [2][F/2]: the F/2 sines come first, then the F/2 cosines (NOT interleaved, unlike
+    // pos2posemb3d which stacks on the last dim).
+    const float s = sinf(e / p.dim_t[2 * k]);
+    const float c = cosf(e / p.dim_t[2 * k + 1]);
+    ob[(size_t)(axis * p.F + k) * HW] = s;
+    ob[(size_t)(axis * p.F + half + k) * HW] = c;
+  }
+}
+
+extern "C" int petr_sine3d_fwd(const petr_sine3d_args* a, void* stream) {
+  PETR_CHECK(a && a->dim_t && a->out, PETR_ERR_INVALID, "sine3d: null pointer");
+  PETR_CHECK(a->F > 0 && (a->F & 1) == 0, PETR_ERR_INVALID, "sine3d: num_feats must be even");
+  Sine3dParams p{a->mask, a->dim_t, a->out, a->B, a->N, a->H, a->W, a->F, a->normalize, a->scale, a->eps, a->offset};
+  dim3 grid((unsigned)cdiv((long)a->H * a->W, 64), a->B * a->N);
+  hipLaunchKernelGGL(sine3d_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  PETR_LAUNCH_CHECK("sine3d");
+  return PETR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K3b.  pos2posemb3d: out[q, blk*F + 2k] = sin(pos[q,ax]*2pi / dim_t[2k]), +1 -> cos; block order
+// (y, x, z) = pos axis (1, 0, 2)  (petr_head.py:42).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void posemb3d_kernel(const float* __restrict__ pos, const float* __restrict__ dim_t,
+                                                        float* __restrict__ out, int n, int F) {
+  const int half = F >> 1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * 3 * half) return;
+  const int q = idx / (3 * half);
+  const int rem = idx - q * 3 * half;
+  const int blk = rem / half, k = rem - blk * half;
+  const int ax = blk == 0 ? 1 : (blk == 1 ? 0 : 2);
+  const float scale = 2.f * 3.14159265358979323846f;   // fp32(2*pi), as torch does for a python-float multiplier
+  const float v = pos[q * 3 + ax] * scale;
+  out[(size_t)q * 3 * F + blk * F + 2 * k] = sinf(v / dim_t[2 * k]);
+  out[(size_t)q * 3 * F + blk * F + 2 * k + 1] = cosf(v / dim_t[2 * k + 1]);
+}
+
+// dpos[q,ax] = sum_k 2pi/dim_t[2k] * ( cos(a)*dout[sin ch] - sin(a)*dout[cos ch] ); one wave per (q, blk)
+__global__ __launch_bounds__(256) void posemb3d_bwd_kernel(const float* __restrict__ pos, const float* __restrict__ dim_t,
+                                                            const float* __restrict__ dout, float* __restrict__ dpos,
+                                                            int n, int F) {
+  const int half = F >> 1;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= n * 3) return;
+  const int q = wave / 3, blk = wave - q * 3;
+  const int ax = blk == 0 ? 1 : (blk == 1 ? 0 : 2);
+  const float scale = 2.f * 3.14159265358979323846f;
+  const float v = pos[q * 3 + ax] * scale;
+  float acc = 0.f;
+  for (int k = lane; k < half; k += 64) {
+    const float t0 = dim_t[2 * k], t1 = dim_t[2 * k + 1];
+    const float g0 = dout[(size_t)q * 3 * F + blk * F + 2 * k];
+    const float g1 = dout[(size_t)q * 3 * F + blk * F + 2 * k + 1];
+    acc += g0 * cosf(v / t0) * (scale / t0) - g1 * sinf(v / t1) * (scale / t1);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) dpos[q * 3 + ax] += acc;
+}
+
+extern "C" int petr_posemb3d_fwd(const float* pos, const float* dim_t, float* out, int n, int F, void* stream) {
+  PETR_CHECK(pos && dim_t && out && n > 0 && F > 0 && (F & 1) == 0, PETR_ERR_INVALID, "posemb3d: bad argument");
+  hipLaunchKernelGGL(posemb3d_kernel, dim3((unsigned)cdiv((long)n * 3 * (F / 2), 256)), dim3(256), 0,
+                     (hipStream_t)stream, pos, dim_t, out, n, F);
+  PETR_LAUNCH_CHECK("posemb3d");
+  return PETR_OK;
+}
+
+extern "C" int petr_posemb3d_bwd(const float* pos, const float* dim_t, const float* dout, float* dpos, int n, int F,
+                                 void* stream) {
+  PETR_CHECK(pos && dim_t && dout && dpos && n > 0 && F > 0 && (F & 1) == 0, PETR_ERR_INVALID, "posemb3d_bwd: bad argument");
+  hipLaunchKernelGGL(posemb3d_bwd_kernel, dim3((unsigned)cdiv((long)n * 3 * 64, 256)), dim3(256), 0,
+                     (hipStream_t)stream, pos, dim_t, dout, dpos, n, F);
+  PETR_LAUNCH_CHECK("posemb3d_bwd");
+  return PETR_OK;
+}

@@ -1,0 +1,224 @@
+"""Per-operator Python entry points over the C ABI (torch tensors in, torch tensors out).
+
+Torch is plumbing here: device memory, the current HIP stream, nothing else.  Every function
+launches hand-written gfx950 kernels through libpetr_hip.so on ``torch.cuda.current_stream()``;
+there is no fallback path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _C
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f32(t):
+    assert t.is_cuda and t.dtype == torch.float32, 'expected a float32 CUDA tensor'
+    return t
+
+
+def coords3d(img2lidar, depth, B, N, H, W, pad_h, pad_w, position_range, eps=1e-5, want_volume=True, want_mask=False):
+    """K1: [B*N,3D,H,W] logit volume (+ optional coords_mask [B,N,H,W] bool)."""
+    L = _C.lib()
+    D = depth.numel()
+    dev = depth.device
+    out = torch.empty((B * N, 3 * D, H, W), dtype=torch.float32, device=dev) if want_volume else None
+    cmask = torch.empty((B, N, H, W), dtype=torch.uint8, device=dev) if want_mask else None
+    a = _C.Coords3dArgs(_ptr(_f32(img2lidar).contiguous()), _ptr(_f32(depth)), _ptr(out), _ptr(cmask), B, N, H, W, D,
+                        float(pad_h), float(pad_w), (C.c_float * 6)(*[float(v) for v in position_range]), float(eps))
+    _C.check(L.petr_coords3d_fwd(C.byref(a), _stream()), 'petr_coords3d_fwd')
+    return out, (cmask.bool() if cmask is not None else None)
+
+
+def sine3d(mask, dim_t, B, N, H, W, normalize=True, scale=6.283185307179586, eps=1e-6, offset=0.0):
+    """K3a: SinePositionalEncoding3D features [B,N,3F,H,W]; mask uint8/bool [B,N,H,W] or None (all valid)."""
+    L = _C.lib()
+    F = dim_t.numel()
+    if mask is not None:
+        mask = mask.to(torch.uint8).contiguous()
+    out = torch.empty((B, N, 3 * F, H, W), dtype=torch.float32, device=dim_t.device)
+    a = _C.Sine3dArgs(_ptr(mask), _ptr(_f32(dim_t)), _ptr(out), B, N, H, W, F, int(normalize), float(scale), float(eps),
+                      float(offset))
+    _C.check(L.petr_sine3d_fwd(C.byref(a), _stream()), 'petr_sine3d_fwd')
+    return out
+
+
+def posemb3d(pos, dim_t):
+    L = _C.lib()
+    n, F = pos.shape[0], dim_t.numel()
+    out = torch.empty((n, 3 * F), dtype=torch.float32, device=pos.device)
+    _C.check(L.petr_posemb3d_fwd(_ptr(_f32(pos).contiguous()), _ptr(_f32(dim_t)), _ptr(out), n, F, _stream()),
+             'petr_posemb3d_fwd')
+    return out
+
+
+def posemb3d_bwd(pos, dim_t, dout):
+    L = _C.lib()
+    n, F = pos.shape[0], dim_t.numel()
+    dpos = torch.zeros_like(pos)
+    _C.check(L.petr_posemb3d_bwd(_ptr(_f32(pos).contiguous()), _ptr(dim_t), _ptr(_f32(dout).contiguous()), _ptr(dpos), n,
+                                 F, _stream()), 'petr_posemb3d_bwd')
+    return dpos
+
+
+def gemm_raw(**kw):
+    """Direct access to petr_gemm; keyword names are the struct fields (tensors for pointers)."""
+    L = _C.lib()
+    g = _C.GemmArgs()
+    keep = []
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            keep.append(v)
+            v = v.data_ptr()
+        setattr(g, k, v)
+    _C.check(L.petr_gemm(C.byref(g), _stream()), 'petr_gemm')
+
+
+def linear(x, w, bias=None, relu=False, residual=None, a2=None, a2_rows=0, a2_ncols=0, out=None, accumulate=False,
+           split_k=1):
+    """y = act((x [+ a2]) @ w.T + bias [+ residual]);  x [M,K] row-major, w [N,K] (nn.Linear layout)."""
+    M, K = x.shape
+    N = w.shape[0]
+    if split_k > 1:
+        out = torch.empty((split_k, M, N), dtype=torch.float32, device=x.device)
+    elif out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    flags = (_C.GEMM_RELU if relu else 0) | (_C.GEMM_ACCUMULATE if accumulate else 0)
+    kw = dict(a=_f32(x), lda=x.stride(0), a_kcontig=1, b=_f32(w), ldb=w.stride(0), b_kcontig=1, c=out, ldc=N, M=M, N=N, K=K,
+              flags=flags, alpha=1.0, split_k=split_k, c_split_stride=M * N)
+    if bias is not None:
+        kw['bias'] = bias
+    if residual is not None:
+        kw.update(r=residual, ldr=residual.stride(0))
+    if a2 is not None:
+        kw.update(a2=a2, a2_rows=a2_rows, a2_ncols=a2_ncols)
+    gemm_raw(**kw)
+    return out
+
+
+def conv1x1(x, w, bias=None, relu=False, out=None, accumulate=False):
+    """x [V, C_in, HW] (NCHW views) -> token-major [V*HW, C_out]; w [C_out, C_in]."""
+    V, Cin, HW = x.shape
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.empty((V * HW, Cout), dtype=torch.float32, device=x.device)
+    flags = (_C.GEMM_RELU if relu else 0) | (_C.GEMM_ACCUMULATE if accumulate else 0)
+    kw = dict(a=_f32(x), lda=HW, a_kcontig=0, a_bs0=Cin * HW, b=_f32(w), ldb=w.stride(0), b_kcontig=1, c=out, ldc=Cout,
+              c_bs0=HW * Cout, M=HW, N=Cout, K=Cin, nb0=V, flags=flags, alpha=1.0)
+    if bias is not None:
+        kw['bias'] = bias
+    gemm_raw(**kw)
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    L = _C.lib()
+    M, N = x.shape
+    if out is None:
+        out = torch.zeros(N, dtype=torch.float32, device=x.device)
+    ws = torch.empty(L.petr_colsum_workspace_bytes(N) // 4, dtype=torch.float32, device=x.device)
+    _C.check(L.petr_colsum(_ptr(_f32(x)), x.stride(0), M, N, _ptr(out), int(accumulate), _ptr(ws), _stream()), 'petr_colsum')
+    return out
+
+
+def layernorm(x, gamma, beta, bias=None, residual=None, relu=False, nan_to_num=False, eps=1e-5, save_stats=False):
+    """y = LN(sum_p x[p] + bias + residual); x [M,C] or [P,M,C] (split-K partial slabs)."""
+    L = _C.lib()
+    if x.dim() == 3:
+        P, M, Cc = x.shape
+    else:
+        P, (M, Cc) = 1, x.shape
+    y = torch.empty((M, Cc), dtype=torch.float32, device=x.device)
+    z = mean = rstd = None
+    if save_stats:
+        z = torch.empty_like(y)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+    flags = (_C.LN_RELU if relu else 0) | (_C.LN_NAN_TO_NUM if nan_to_num else 0)
+    a = _C.LayerNormArgs(_ptr(_f32(x)), P, M * Cc, _ptr(bias), _ptr(residual), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(z),
+                         _ptr(mean), _ptr(rstd), M, Cc, float(eps), flags)
+    _C.check(L.petr_layernorm_fwd(C.byref(a), _stream()), 'petr_layernorm_fwd')
+    return (y, z, mean, rstd) if save_stats else y
+
+
+def layernorm_bwd(z, mean, rstd, gamma, dy, y=None, relu=False):
+    L = _C.lib()
+    M, Cc = z.shape
+    dz = torch.empty_like(z)
+    dgamma = torch.zeros_like(gamma)
+    dbeta = torch.zeros_like(gamma)
+    ws = torch.empty(L.petr_layernorm_bwd_workspace_bytes(M, Cc) // 4, dtype=torch.float32, device=z.device)
+    a = _C.LayerNormBwdArgs(_ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(_f32(dy).contiguous()), _ptr(y), _ptr(dz),
+                            _ptr(dgamma), _ptr(dbeta), _ptr(ws), M, Cc, _C.LN_RELU if relu else 0, 0)
+    _C.check(L.petr_layernorm_bwd(C.byref(a), _stream()), 'petr_layernorm_bwd')
+    return dz, dgamma, dbeta
+
+
+def _bhsd(t):
+    assert t.dim() == 4 and t.stride(3) == 1 and t.shape[3] == 32, 'expected a [B,H,S,32] view with contiguous head dim'
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True):
+    """softmax(scale q k^T + mask) v for [B,H,S,32] (strided) views.  Returns (o [B,H,Q,32], lse [B,H,Q])."""
+    L = _C.lib()
+    B, H, Q, _ = q.shape
+    Lk = k.shape[2]
+    scale = float(scale if scale is not None else 32 ** -0.5)
+    o = torch.empty((B, H, Q, 32), dtype=torch.float32, device=q.device)
+    lse = torch.empty((B, H, Q), dtype=torch.float32, device=q.device) if need_lse else None
+    ns = n_split if n_split > 0 else L.petr_mha_choose_split(B, H, Q, Lk)
+    nbytes = L.petr_mha_fwd_workspace_bytes(B, H, Q, Lk, ns)
+    ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=q.device)
+    kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
+    a = _C.MhaFwdArgs(_ptr(_f32(q)), *_bhsd(q), _ptr(_f32(k)), *_bhsd(k), _ptr(_f32(v)), *_bhsd(v), _ptr(o), *_bhsd(o),
+                      _ptr(lse), _ptr(kpm), B, H, Q, Lk, scale, ns, _ptr(ws), nbytes)
+    _C.check(L.petr_mha_fwd(C.byref(a), _stream()), 'petr_mha_fwd')
+    return o, lse
+
+
+def mha_bwd(q, k, v, o, do, lse, key_padding_mask=None, scale=None):
+    L = _C.lib()
+    B, H, Q, _ = q.shape
+    Lk = k.shape[2]
+    scale = float(scale if scale is not None else 32 ** -0.5)
+    dq = torch.zeros((B, H, Q, 32), dtype=torch.float32, device=q.device)
+    dk = torch.zeros((B, H, Lk, 32), dtype=torch.float32, device=q.device)
+    dv = torch.zeros_like(dk)
+    nbytes = L.petr_mha_bwd_workspace_bytes(B, H, Q, Lk)
+    ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=q.device)
+    kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
+    a = _C.MhaBwdArgs(_ptr(_f32(q)), *_bhsd(q), _ptr(_f32(k)), *_bhsd(k), _ptr(_f32(v)), *_bhsd(v), _ptr(_f32(o)), *_bhsd(o),
+                      _ptr(_f32(do)), *_bhsd(do), _ptr(lse), _ptr(kpm), _ptr(dq), *_bhsd(dq), _ptr(dk), *_bhsd(dk),
+                      _ptr(dv), *_bhsd(dv), B, H, Q, Lk, scale, _ptr(ws), nbytes)
+    _C.check(L.petr_mha_bwd(C.byref(a), _stream()), 'petr_mha_bwd')
+    return dq, dk, dv
+
+
+def bbox_epilogue(reg, ref, Q, pc_range, time_div=0.0, eps=1e-5):
+    L = _C.lib()
+    rows, code = reg.shape
+    out = torch.empty_like(reg)
+    a = _C.BboxArgs(_ptr(_f32(reg).contiguous()), _ptr(_f32(ref).contiguous()), _ptr(out), rows, Q, code,
+                    (C.c_float * 6)(*[float(v) for v in pc_range]), float(time_div), float(eps))
+    _C.check(L.petr_bbox_epilogue_fwd(C.byref(a), _stream()), 'petr_bbox_epilogue_fwd')
+    return out
+
+
+def bbox_epilogue_bwd(out, ref, dout, Q, pc_range, time_div=0.0, eps=1e-5):
+    L = _C.lib()
+    rows, code = out.shape
+    dreg = torch.empty_like(out)
+    dref = torch.zeros_like(ref)
+    a = _C.BboxArgs(None, _ptr(_f32(ref).contiguous()), _ptr(_f32(out).contiguous()), rows, Q, code,
+                    (C.c_float * 6)(*[float(v) for v in pc_range]), float(time_div), float(eps))
+    _C.check(L.petr_bbox_epilogue_bwd(C.byref(a), _ptr(_f32(dout).contiguous()), _ptr(dreg), _ptr(dref), _stream()),
+             'petr_bbox_epilogue_bwd')
+    return dreg, dref

@@ -1,0 +1,247 @@
+"""GPU parity of every C-ABI operator against the CPU oracle / plain fp32 torch on the CPU."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import petr_oracle as O  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from petr_amd import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def relerr(got, want):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    return ((got - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
+
+
+# ------------------------------------------------------------------ K1 coords3d
+@pytest.mark.parametrize('name', ['coords3d_toy', 'coords3d_toy_masked'])
+def test_coords3d_golden(ops, golden_dir, name):
+    fx = np.load(os.path.join(golden_dir, name + '.npz'))
+    N, H, W = [int(v) for v in fx['shape']]
+    pad_h, pad_w = [int(v) for v in fx['pad_hw']]
+    metas = [{'lidar2img': list(fx['lidar2img']), 'pad_shape': [(pad_h, pad_w, 3)] * N}]
+    i2l = O.img2lidar_matrices(metas).reshape(-1, 16)
+    depth = O.depth_bins(64, 1, [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], True)
+    vol, cmask = ops.coords3d(dev(i2l), dev(depth), 1, N, H, W, pad_h, pad_w, [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+                              want_mask=True)
+    want = torch.from_numpy(fx['volume'])
+    assert vol.shape == want.shape                       # layout [B*N, 3D, H, W], channel = 3d+axis
+    # index space exact: compare in the normalised (pre-logit) space where the tolerance is meaningful
+    got_n = torch.sigmoid(vol.cpu().double())
+    want_n = torch.sigmoid(want.double())
+    assert (got_n - want_n).abs().max().item() < 1e-5
+    # logit values: tight away from the clamps
+    inner = (want.abs() < 8)
+    assert (vol.cpu()[inner] - want[inner]).abs().max().item() < 2e-3
+    geo = torch.from_numpy(fx['coords_mask']) & ~torch.from_numpy(fx['masks']) | torch.from_numpy(fx['coords_mask'])
+    got_mask = cmask.cpu() | torch.from_numpy(fx['masks'])
+    # the count threshold can flip only where a coordinate sits within 1e-6 of 0 or 1
+    assert (got_mask != torch.from_numpy(fx['coords_mask'])).sum().item() <= 1
+    del geo
+
+
+def test_coords3d_c5_full(ops):
+    metas = O.synthetic_img_metas(1, 6, (512, 1408), seed=0)
+    want, wmask, wnorm = O.coords3d_volume(1, 6, 16, 44, metas)
+    i2l = O.img2lidar_matrices(metas).reshape(-1, 16)
+    depth = O.depth_bins(64, 1, [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], True)
+    vol, cmask = ops.coords3d(dev(i2l), dev(depth), 1, 6, 16, 44, 512, 1408, [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+                              want_mask=True)
+    assert (torch.sigmoid(vol.cpu().double()) - torch.sigmoid(want.double())).abs().max().item() < 1e-5
+    assert (cmask.cpu() != wmask).sum().item() <= 2
+    # determinism: same input twice -> bit-identical
+    vol2, _ = ops.coords3d(dev(i2l), dev(depth), 1, 6, 16, 44, 512, 1408, [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0])
+    assert torch.equal(vol, vol2)
+
+
+# ------------------------------------------------------------------ K3 sine / posemb
+def test_sine3d(ops, golden_dir):
+    fx = np.load(os.path.join(golden_dir, 'sine3d.npz'))
+    mask = torch.from_numpy(fx['mask'])
+    dim_t = O.sine_dim_t(128)
+    got = ops.sine3d(dev(mask), dev(dim_t), *mask.shape)
+    assert (got.cpu() - torch.from_numpy(fx['pos'])).abs().max().item() < 2e-6
+    got0 = ops.sine3d(None, dev(dim_t), 1, 6, 16, 44)
+    want0 = O.sine_positional_encoding_3d(torch.zeros(1, 6, 16, 44, dtype=torch.bool), 128, normalize=True)
+    assert (got0.cpu() - want0).abs().max().item() < 2e-6
+
+
+def test_posemb3d_fwd_bwd(ops, golden_dir):
+    fx = np.load(os.path.join(golden_dir, 'pos2posemb3d.npz'))
+    pos = torch.from_numpy(fx['pos'])
+    dim_t = O.sine_dim_t(128)
+    got = ops.posemb3d(dev(pos), dev(dim_t))
+    assert (got.cpu() - torch.from_numpy(fx['emb'])).abs().max().item() < 2e-6
+    p = pos.clone().double().requires_grad_(True)
+    g = torch.randn(64, 384, generator=torch.Generator().manual_seed(0))
+    O.pos2posemb3d(p).backward(g.double())
+    dpos = ops.posemb3d_bwd(dev(pos), dev(dim_t), dev(g))
+    assert relerr(dpos, p.grad) < 1e-4
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('M,N,K', [(900, 256, 256), (4224, 1024, 192), (5400, 10, 256), (37, 70, 44), (900, 256, 2048)])
+def test_linear(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    want = torch.relu(x.double() @ w.double().T + b.double() + res.double())
+    got = ops.linear(dev(x), dev(w), dev(b), relu=True, residual=dev(res))
+    assert relerr(got, want) < 2e-6
+
+
+def test_linear_addend_splitk_accumulate(ops):
+    g = torch.Generator().manual_seed(7)
+    x, e = torch.randn(2 * 90, 256, generator=g), torch.randn(90, 256, generator=g)
+    w, b = torch.randn(768, 256, generator=g) / 16, torch.randn(768, generator=g)
+    xe = x + e.repeat(2, 1)
+    want = torch.cat([xe.double() @ w[:512].double().T, x.double() @ w[512:].double().T], 1) + b.double()
+    got = ops.linear(dev(x), dev(w), dev(b), a2=dev(e), a2_rows=90, a2_ncols=512)
+    assert relerr(got, want) < 2e-6
+    # split-K partial slabs reduced by LayerNorm's prologue
+    x2, w2 = torch.randn(900, 2048, generator=g), torch.randn(256, 2048, generator=g) / 45
+    parts = ops.linear(dev(x2), dev(w2), split_k=4)
+    assert relerr(parts.sum(0), x2.double() @ w2.double().T) < 2e-6
+    acc = dev(torch.ones(900, 256))
+    ops.linear(dev(x2), dev(w2), out=acc, accumulate=True)
+    assert relerr(acc, x2.double() @ w2.double().T + 1) < 2e-6
+
+
+def test_conv1x1_and_transposed_layouts(ops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(6, 256, 704, generator=g)             # [views, C_in, HW]
+    w, b = torch.randn(256, 256, generator=g) / 16, torch.randn(256, generator=g)
+    want = torch.einsum('vch,oc->vho', x.double(), w.double()).reshape(-1, 256) + b.double()
+    got = ops.conv1x1(dev(x), dev(w), dev(b))
+    assert relerr(got, want) < 2e-6
+    # backward forms: dA = dC @ W (B not K-contiguous), dW = dC^T @ A (neither K-contiguous)
+    dC, A, W = torch.randn(900, 256, generator=g), torch.randn(900, 192, generator=g), torch.randn(256, 192, generator=g)
+    dA = torch.empty(900, 192).cuda()
+    ops.gemm_raw(a=dev(dC), lda=256, a_kcontig=1, b=dev(W), ldb=192, b_kcontig=0, c=dA, ldc=192, M=900, N=192, K=256, alpha=1.0)
+    assert relerr(dA, dC.double() @ W.double()) < 2e-6
+    dW = torch.empty(256, 192).cuda()
+    ops.gemm_raw(a=dev(dC), lda=256, a_kcontig=0, b=dev(A), ldb=192, b_kcontig=0, c=dW, ldc=192, M=256, N=192, K=900, alpha=1.0)
+    assert relerr(dW, dC.double().T @ A.double()) < 2e-6
+
+
+def test_colsum(ops):
+    x = torch.randn(5400, 300, generator=torch.Generator().manual_seed(1))
+    assert relerr(ops.colsum(dev(x)), x.double().sum(0)) < 1e-6
+
+
+# ------------------------------------------------------------------ LayerNorm
+def test_layernorm_fwd_bwd(ops):
+    g = torch.Generator().manual_seed(5)
+    x, res, bias = torch.randn(900, 256, generator=g) * 3, torch.randn(900, 256, generator=g), torch.randn(256, generator=g)
+    gamma, beta = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    zt = (x + bias + res).double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    bd = beta.double().requires_grad_(True)
+    want = torch.relu(torch.nn.functional.layer_norm(zt, (256,), gd, bd, 1e-5))
+    y, z, mean, rstd = ops.layernorm(dev(x), dev(gamma), dev(beta), bias=dev(bias), residual=dev(res), relu=True,
+                                     save_stats=True)
+    assert relerr(y, want) < 2e-6 and relerr(z, zt) < 1e-6
+    dy = torch.randn(900, 256, generator=g)
+    want.backward(dy.double())
+    dz, dgm, dbt = ops.layernorm_bwd(z, mean, rstd, dev(gamma), dev(dy), y=y, relu=True)
+    assert relerr(dz, zt.grad) < 1e-5 and relerr(dgm, gd.grad) < 1e-5 and relerr(dbt, bd.grad) < 1e-5
+    # nan_to_num epilogue (petr_head.py:435)
+    xn = x.clone()
+    xn[3, :] = float('nan')
+    yn = ops.layernorm(dev(xn), dev(gamma), dev(beta), nan_to_num=True)
+    assert torch.isfinite(yn).all() and (yn[3] == 0).all()
+
+
+# ------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, kpm, scale):
+    s = torch.einsum('bhqd,bhkd->bhqk', q.double(), k.double()) * scale
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :], float('-inf'))
+    p = torch.softmax(s, -1)
+    return torch.einsum('bhqk,bhkd->bhqd', p, v.double()), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize('B,H,Q,L,split,masked', [(1, 8, 900, 4224, 0, False), (2, 8, 900, 900, 0, False),
+                                                   (1, 2, 70, 333, 3, True), (1, 8, 900, 1000, 1, True),
+                                                   (1, 1, 16, 40, 0, True)])
+def test_mha_fwd(ops, B, H, Q, L, split, masked):
+    g = torch.Generator().manual_seed(Q + L)
+    q, k, v = (torch.randn(B, H, n, 32, generator=g) for n in (Q, L, L))
+    kpm = None
+    if masked:
+        kpm = torch.zeros(B, L, dtype=torch.bool)
+        kpm[:, L - L // 4:] = True
+        kpm[0, 3] = True
+    want, wlse = _attn_ref(q, k, v, kpm, 32 ** -0.5)
+    o, lse = ops.mha_fwd(dev(q), dev(k), dev(v), dev(kpm) if masked else None, n_split=split)
+    assert relerr(o, want) < 2e-6
+    assert (lse.cpu().double() - wlse).abs().max().item() < 1e-5
+
+
+def test_mha_fwd_strided_views_and_all_masked(ops):
+    """q from a [B,Q,768] projection buffer, k/v head-split: the layouts the executor uses."""
+    g = torch.Generator().manual_seed(11)
+    B, H, Q, L = 2, 8, 100, 200
+    qkv = torch.randn(B, Q, 768, generator=g)
+    kk, vv = torch.randn(B, H, L, 32, generator=g), torch.randn(B, H, L, 32, generator=g)
+    qd = dev(qkv)
+    qv = qd.view(B, Q, 24, 32)[:, :, :8].permute(0, 2, 1, 3)
+    kpm = torch.zeros(B, L, dtype=torch.bool)
+    kpm[1, :] = True                                   # every key of sample 1 masked -> NaN like torch
+    want, _ = _attn_ref(qkv.view(B, Q, 24, 32)[:, :, :8].permute(0, 2, 1, 3), kk, vv, kpm, 32 ** -0.5)
+    o, _ = ops.mha_fwd(qv, dev(kk), dev(vv), dev(kpm))
+    assert relerr(o[0], want[0]) < 2e-6
+    assert torch.isnan(o[1]).all() and torch.isnan(want[1]).all()
+
+
+@pytest.mark.parametrize('B,H,Q,L,masked', [(1, 8, 900, 4224, False), (1, 2, 70, 333, True), (2, 8, 900, 900, False)])
+def test_mha_bwd(ops, B, H, Q, L, masked):
+    g = torch.Generator().manual_seed(Q * 3 + L)
+    q, k, v = (torch.randn(B, H, n, 32, generator=g).double().requires_grad_(True) for n in (Q, L, L))
+    do = torch.randn(B, H, Q, 32, generator=g)
+    kpm = None
+    if masked:
+        kpm = torch.zeros(B, L, dtype=torch.bool)
+        kpm[:, L - L // 4:] = True
+    want, _ = _attn_ref(q, k, v, kpm, 32 ** -0.5)
+    want.backward(do.double())
+    qf, kf, vf = (dev(t.detach().float()) for t in (q, k, v))
+    o, lse = ops.mha_fwd(qf, kf, vf, dev(kpm) if masked else None)
+    dq, dk, dv = ops.mha_bwd(qf, kf, vf, o, dev(do), lse, dev(kpm) if masked else None)
+    assert relerr(dq, q.grad) < 1e-5 and relerr(dk, k.grad) < 1e-5 and relerr(dv, v.grad) < 1e-5
+
+
+# ------------------------------------------------------------------ box epilogue
+def test_bbox_epilogue(ops):
+    g = torch.Generator().manual_seed(9)
+    Q, rows = 50, 6 * 2 * 50
+    reg = torch.randn(rows, 10, generator=g).double().requires_grad_(True)
+    ref = torch.rand(Q, 3, generator=g).double().requires_grad_(True)
+    pc = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    t = reg.clone().view(12, Q, 10)
+    r = O.inverse_sigmoid(ref)
+    xy = torch.sigmoid(t[..., 0:2] + r[..., 0:2])
+    z = torch.sigmoid(t[..., 4:5] + r[..., 2:3])
+    want = torch.cat([xy[..., 0:1] * (pc[3] - pc[0]) + pc[0], xy[..., 1:2] * (pc[4] - pc[1]) + pc[1], t[..., 2:4],
+                      z * (pc[5] - pc[2]) + pc[2], t[..., 5:]], -1).view(rows, 10)
+    got = ops.bbox_epilogue(dev(reg.detach().float()), dev(ref.detach().float()), Q, pc)
+    assert relerr(got, want) < 2e-6
+    dout = torch.randn(rows, 10, generator=g)
+    want.backward(dout.double())
+    dreg, dref = ops.bbox_epilogue_bwd(got, dev(ref.detach().float()), dev(dout), Q, pc)
+    assert relerr(dreg, reg.grad) < 1e-5 and relerr(dref, ref.grad) < 1e-4

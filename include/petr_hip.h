@@ -106,9 +106,14 @@ int petr_posemb3d_bwd(const float* pos, const float* dim_t, const float* dout, f
  *         result by (relu_mask[m,n] > 0); relu_mask indexed like R) , PETR_GEMM_SIGMOID_MUL
  *         (C = mul[m,n] * sigmoid(value); mul indexed like R; PETRv2 SELayer petrv2_head.py:48-60).
  *     split_k > 1: slice z2 of K writes its partial to c + z2*c_split_stride (bias/residual are NOT
- *         applied; reduce with petr_layernorm_fwd or petr_reduce_partials).
+ *         applied; reduce with petr_layernorm_fwd or petr_reduce_partials).  With PETR_GEMM_ATOMIC
+ *         every slice instead ADDS into c with float atomics (weight gradients, c += ; low-order
+ *         bits depend on arrival order).
+ *     a_colsum: optional [M] vector receiving (atomically, +=) sum_k A(m,k): the bias gradient that
+ *         belongs to a weight-gradient contraction dW = dC^T X (A = dC^T), at no extra launch.
  * ------------------------------------------------------------------------------------------ */
-enum { PETR_GEMM_RELU = 1, PETR_GEMM_ACCUMULATE = 2, PETR_GEMM_RELU_MASK = 4, PETR_GEMM_SIGMOID_MUL = 8 };
+enum { PETR_GEMM_RELU = 1, PETR_GEMM_ACCUMULATE = 2, PETR_GEMM_RELU_MASK = 4, PETR_GEMM_SIGMOID_MUL = 8,
+       PETR_GEMM_ATOMIC = 16 };
 typedef struct {
   const float* a; long lda; int a_kcontig; long a_bs0, a_bs1;
   const float* a2; int a2_rows; int a2_ncols;
@@ -119,6 +124,7 @@ typedef struct {
   int M, N, K, nb0, nb1;
   int split_k; long c_split_stride;
   int k_seg; long a_seg_stride, b_seg_stride;
+  float* a_colsum; long cs_bs0, cs_bs1;
   int flags;
   float alpha;
 } petr_gemm_args;
@@ -151,7 +157,8 @@ typedef struct {
 int petr_layernorm_fwd(const petr_layernorm_args* a, void* stream);
 /* dz = LN backward given z (pre-norm input), mean, rstd, gamma, dy (and y if PETR_LN_RELU was used:
  * dy is masked by y>0). dgamma/dbeta [C] accumulated (+=) via per-block partials in `ws`
- * (petr_layernorm_bwd_workspace_bytes). dz may alias dy. dz_accumulate: dz += result.      */
+ * (petr_layernorm_bwd_workspace_bytes); ws == NULL: float atomics instead (one launch).
+ * dz may alias dy. dz_accumulate: dz += result.                                            */
 typedef struct {
   const float* z; const float* mean; const float* rstd; const float* gamma;
   const float* dy; const float* y;
@@ -228,6 +235,13 @@ typedef struct {
 int petr_bbox_epilogue_fwd(const petr_bbox_args* a, void* stream);
 /* out = forward OUTPUT (post-scale); dout -> dreg; dref += */
 int petr_bbox_epilogue_bwd(const petr_bbox_args* a, const float* dout, float* dreg, float* dref, void* stream);
+
+/* Opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline leg; off by
+ * default).  petr_prof_begin(capacity) arms it; tagged launches (tag & 15: 1 attention forward,
+ * 2 attention backward, 4 coords3d; tag & 16: cross-attention, i.e. L > Q) record begin/end events;
+ * petr_prof_end synchronises them and returns elapsed milliseconds per record.                 */
+int petr_prof_begin(int capacity);
+int petr_prof_end(float* ms, int* tags, int cap, int* n_out);
 
 /* small helpers used by the host executor */
 /* out[m,:] = x[m,:] + e[m % e_rows,:]   (key + key_pos, petr_transformer.py:343-344) */

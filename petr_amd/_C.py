@@ -43,10 +43,11 @@ class GemmArgs(C.Structure):
         ('r', C.c_void_p), ('ldr', C.c_long), ('r_bs0', C.c_long), ('r_bs1', C.c_long),
         ('M', C.c_int), ('N', C.c_int), ('K', C.c_int), ('nb0', C.c_int), ('nb1', C.c_int),
         ('split_k', C.c_int), ('c_split_stride', C.c_long), ('k_seg', C.c_int), ('a_seg_stride', C.c_long),
-        ('b_seg_stride', C.c_long), ('flags', C.c_int), ('alpha', C.c_float))
+        ('b_seg_stride', C.c_long), ('a_colsum', C.c_void_p), ('cs_bs0', C.c_long), ('cs_bs1', C.c_long),
+        ('flags', C.c_int), ('alpha', C.c_float))
 
 
-GEMM_RELU, GEMM_ACCUMULATE, GEMM_RELU_MASK, GEMM_SIGMOID_MUL = 1, 2, 4, 8
+GEMM_RELU, GEMM_ACCUMULATE, GEMM_RELU_MASK, GEMM_SIGMOID_MUL, GEMM_ATOMIC = 1, 2, 4, 8, 16
 LN_RELU, LN_NAN_TO_NUM = 1, 2
 
 
@@ -165,6 +166,8 @@ def lib():
     L.petr_mha_bwd.argtypes = [C.POINTER(MhaBwdArgs), C.c_void_p]
     L.petr_bbox_epilogue_fwd.argtypes = [C.POINTER(BboxArgs), C.c_void_p]
     L.petr_bbox_epilogue_bwd.argtypes = [C.POINTER(BboxArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.petr_prof_begin.argtypes = [C.c_int]
+    L.petr_prof_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
     L.petr_add_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]
     L.petr_fill.argtypes = [C.c_void_p, C.c_float, C.c_long, C.c_void_p]
     L.petr_axpy.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_long, C.c_void_p]
@@ -192,7 +195,7 @@ EXPORTS = [
     'petr_posemb3d_fwd', 'petr_posemb3d_bwd', 'petr_gemm', 'petr_colsum_workspace_bytes', 'petr_colsum',
     'petr_layernorm_fwd', 'petr_layernorm_bwd_workspace_bytes', 'petr_layernorm_bwd',
     'petr_mha_fwd_workspace_bytes', 'petr_mha_choose_split', 'petr_mha_fwd', 'petr_mha_bwd_workspace_bytes',
-    'petr_mha_bwd', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows',
+    'petr_mha_bwd', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows', 'petr_prof_begin', 'petr_prof_end',
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
 ]

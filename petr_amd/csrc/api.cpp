@@ -24,3 +24,64 @@ extern "C" int petr_device_caps(int* num_cu, char* arch, int arch_len) {
   if (arch && arch_len > 0) snprintf(arch, (size_t)arch_len, "%s", prop.gcnArchName);
   return PETR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Opt-in kernel timing with HIP events on the launch stream (bench.py's roofline leg).  Disabled by
+// default: the hot path then records nothing.  Events are created in petr_prof_begin (outside any
+// launch path), recorded around tagged launches, resolved in petr_prof_end after a synchronise.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Prof {
+  bool on = false;
+  int cap = 0, n = 0;
+  hipEvent_t* ev = nullptr;   // 2 per record
+  int* tag = nullptr;
+} g_prof;
+}  // namespace
+
+int petr_prof_open_record(int tag, void* stream) {
+  if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
+  const int i = g_prof.n++;
+  g_prof.tag[i] = tag;
+  hipEventRecord(g_prof.ev[2 * i], (hipStream_t)stream);
+  return i;
+}
+
+void petr_prof_close_record(int i, void* stream) {
+  if (i >= 0) hipEventRecord(g_prof.ev[2 * i + 1], (hipStream_t)stream);
+}
+
+extern "C" int petr_prof_begin(int capacity) {
+  PETR_CHECK(capacity > 0 && capacity <= (1 << 20), PETR_ERR_INVALID, "prof_begin: bad capacity");
+  if (g_prof.cap < capacity) {
+    for (int i = 0; i < 2 * g_prof.cap; ++i) hipEventDestroy(g_prof.ev[i]);
+    delete[] g_prof.ev;
+    delete[] g_prof.tag;
+    g_prof.ev = new hipEvent_t[2 * capacity];
+    g_prof.tag = new int[capacity];
+    for (int i = 0; i < 2 * capacity; ++i) {
+      hipError_t e = hipEventCreate(&g_prof.ev[i]);
+      PETR_CHECK(e == hipSuccess, PETR_ERR_LAUNCH, "prof_begin: hipEventCreate: %s", hipGetErrorString(e));
+    }
+    g_prof.cap = capacity;
+  }
+  g_prof.n = 0;
+  g_prof.on = true;
+  return PETR_OK;
+}
+
+extern "C" int petr_prof_end(float* ms, int* tags, int cap, int* n_out) {
+  g_prof.on = false;
+  PETR_CHECK(ms && tags && n_out, PETR_ERR_INVALID, "prof_end: null pointer");
+  const int n = g_prof.n < cap ? g_prof.n : cap;
+  for (int i = 0; i < n; ++i) {
+    hipError_t e = hipEventSynchronize(g_prof.ev[2 * i + 1]);
+    PETR_CHECK(e == hipSuccess, PETR_ERR_LAUNCH, "prof_end: %s", hipGetErrorString(e));
+    float t = 0.f;
+    hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+    ms[i] = t;
+    tags[i] = g_prof.tag[i];
+  }
+  *n_out = n;
+  return PETR_OK;
+}

@@ -13,6 +13,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void petr_set_error(const char* fmt, ...);
 
+// opt-in event timing of tagged launches (api.cpp); no-ops unless petr_prof_begin() was called
+enum { PETR_PROF_MHA_FWD = 1, PETR_PROF_MHA_BWD = 2, PETR_PROF_GEMM = 3, PETR_PROF_COORDS3D = 4 };
+int petr_prof_open_record(int tag, void* stream);
+void petr_prof_close_record(int rec, void* stream);
+
 #define PETR_CHECK(cond, code, ...)     \
   do {                                  \
     if (!(cond)) {                      \

@@ -156,6 +156,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // bias gradient for free: column sums of the A operand (= dC^T in a weight-gradient
+  // contraction) taken from the LDS image by the workgroups of the first N-tile
+  const bool do_colsum = g.a_colsum != nullptr && tn_i == 0;
+  float colacc = 0.f;
+
   SA sa;
   SB sb;
   auto stage_load = [&](int kt) {
@@ -170,6 +175,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
     sb.store(Bs);
     __syncthreads();
     if (kt + 1 < kt_end) stage_load(kt + 1);
+    if (do_colsum && threadIdx.x < BM) {
+      float cs = 0.f;
+#pragma unroll
+      for (int k = 0; k < BK; ++k) cs += As[k * SA::LD + threadIdx.x];
+      colacc += cs;
+    }
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
       float af[TM], bf[TN];
@@ -184,9 +195,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
     }
   }
 
+  if (do_colsum && threadIdx.x < BM && m0 + (int)threadIdx.x < g.M)
+    atomicAdd(g.a_colsum + z0 * g.cs_bs0 + z1 * g.cs_bs1 + m0 + threadIdx.x, colacc);
+
   // ---- epilogue ----
-  float* C = g.c + z0 * g.c_bs0 + z1 * g.c_bs1 + (long)ks * g.c_split_stride;
-  const bool plain = g.split_k > 1;   // K-slices store raw partial sums
+  const bool atomic = (g.flags & PETR_GEMM_ATOMIC) != 0;
+  float* C = g.c + z0 * g.c_bs0 + z1 * g.c_bs1 + (atomic ? 0 : (long)ks * g.c_split_stride);
+  const bool plain = g.split_k > 1 && !atomic;   // K-slices store raw partial sums
   const float* bias = (!plain && g.bias) ? g.bias + z0 * g.bias_bs0 + z1 * g.bias_bs1 : nullptr;
   const float* R = (!plain && g.r) ? g.r + z0 * g.r_bs0 + z1 * g.r_bs1 : nullptr;
   const int flags = plain ? 0 : g.flags;
@@ -212,8 +227,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
         }
         if (flags & PETR_GEMM_RELU) v = fmaxf(v, 0.f);
         float* dst = C + (long)m * g.ldc + ccol;
-        if (flags & PETR_GEMM_ACCUMULATE) v += *dst;
-        *dst = v;
+        if (atomic) {
+          atomicAdd(dst, v);
+        } else {
+          if (flags & PETR_GEMM_ACCUMULATE) v += *dst;
+          *dst = v;
+        }
       }
     }
   }
@@ -254,7 +273,10 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
   PETR_CHECK(!(g.a2 && !g.a_kcontig), PETR_ERR_UNSUPPORTED, "gemm: a2 addend needs a K-contiguous A");
   PETR_CHECK(!((g.flags & (PETR_GEMM_RELU_MASK | PETR_GEMM_SIGMOID_MUL)) && !g.r), PETR_ERR_INVALID,
              "gemm: mask/mul flag without r operand");
-  PETR_CHECK(!(g.split_k > 1 && g.c_split_stride <= 0), PETR_ERR_INVALID, "gemm: split_k needs c_split_stride");
+  PETR_CHECK(!(g.split_k > 1 && g.c_split_stride <= 0 && !(g.flags & PETR_GEMM_ATOMIC)), PETR_ERR_INVALID,
+             "gemm: split_k needs c_split_stride (or PETR_GEMM_ATOMIC)");
+  PETR_CHECK(!((g.flags & PETR_GEMM_ATOMIC) && (g.bias || g.r || (g.flags & ~PETR_GEMM_ATOMIC))), PETR_ERR_UNSUPPORTED,
+             "gemm: PETR_GEMM_ATOMIC excludes bias/residual/other flags");
   PETR_CHECK((long)g.nb0 * g.nb1 * g.split_k <= 65535, PETR_ERR_UNSUPPORTED, "gemm: too many batches");
   PETR_CHECK(g.k_seg <= 0 || g.K % g.k_seg == 0, PETR_ERR_INVALID, "gemm: K=%d is not a multiple of k_seg=%d", g.K, g.k_seg);
   const int kseg = g.k_seg > 0 ? g.k_seg : g.K;

@@ -1,9 +1,912 @@
-// placeholder until the executor lands
+// Whole-path executor: PETRHead.forward (reference models/dense_heads/petr_head.py:366-468, with
+// PETRTransformer.forward petr_transformer.py:69-109 and the decoder loop :423-447 inlined) and its
+// gradient, each as ONE host call that enqueues every kernel on the caller's stream.
+//
+// MI355X-first design notes
+//  * one flat fp32 parameter buffer (and one flat gradient buffer with the same layout): the host
+//    aliases its nn.Parameters onto it, the data-parallel gradient exchange is a handful of large
+//    contiguous RCCL all-reduces instead of 222 small ones.  The layout is ordered by backward
+//    completion time (branches, decoder layer 5..0, then everything that only becomes final at the
+//    end), so stage s of the backward finalises one contiguous range = one all-reduce bucket.
+//  * token-major activations [B*L, 256]: the NCHW inputs are read by the GEMM directly as an
+//    M-contiguous operand, so the two permute copies of petr_transformer.py:90-91 do not exist.
+//  * the key/value projections of all 6 decoder layers are ONE batched contraction each (memory and
+//    positional embedding are layer-invariant; petr_transformer.py:343-344,357-362).
+//  * every elementwise op of the reference (bias, residual, ReLU, key+pos, query+pos, nan_to_num,
+//    sigmoid/box scaling) is an epilogue/prologue of the producing kernel.
+#include <string.h>
+
 #include "common.h"
-extern "C" int petr_head_layout(const petr_head_config*, petr_head_layout_t*) { petr_set_error("not built"); return PETR_ERR_UNSUPPORTED; }
-extern "C" size_t petr_head_workspace_bytes(const petr_head_config*) { return 0; }
-extern "C" int petr_head_fwd(const petr_head_config*, const petr_head_io*, void*) { petr_set_error("not built"); return PETR_ERR_UNSUPPORTED; }
-extern "C" int petr_head_bwd_num_stages(const petr_head_config*) { return 0; }
-extern "C" int petr_head_bwd_stage_range(const petr_head_config*, int, long*, long*) { return PETR_ERR_UNSUPPORTED; }
-extern "C" int petr_head_bwd(const petr_head_config*, const petr_head_io*, const petr_head_grads*, int, int, void*) { return PETR_ERR_UNSUPPORTED; }
-extern "C" int petr_head_ws_view(const petr_head_config*, const char*, long*, long*) { return PETR_ERR_UNSUPPORTED; }
+
+namespace {
+
+struct Dims {
+  int B, N, Cin, H, W, HW, Q, NL, NH, C, F, D, ncls, code;
+  long L, BL, BQ, R;
+};
+
+static Dims make_dims(const petr_head_config* c) {
+  Dims d;
+  d.B = c->B; d.N = c->N; d.Cin = c->C_in; d.H = c->H; d.W = c->W; d.HW = c->H * c->W;
+  d.Q = c->num_query; d.NL = c->num_layers; d.NH = c->num_heads; d.C = c->embed_dims; d.F = c->ffn_dims;
+  d.D = c->depth_num; d.ncls = c->num_classes; d.code = c->code_size;
+  d.L = (long)d.N * d.HW; d.BL = d.B * d.L; d.BQ = (long)d.B * d.Q; d.R = d.NL * d.BQ;
+  return d;
+}
+
+static int check_config(const petr_head_config* c) {
+  PETR_CHECK(c, PETR_ERR_INVALID, "head: null config");
+  PETR_CHECK(c->B > 0 && c->N > 0 && c->C_in > 0 && c->H > 0 && c->W > 0 && c->num_query > 0, PETR_ERR_INVALID,
+             "head: bad shape");
+  PETR_CHECK(c->embed_dims == 256 && c->num_heads == 8, PETR_ERR_UNSUPPORTED,
+             "head: embed_dims must be 256 (petr_head.py:175) with 8 heads of 32");
+  PETR_CHECK(c->num_layers >= 1 && c->num_layers <= 8, PETR_ERR_UNSUPPORTED, "head: 1..8 decoder layers");
+  PETR_CHECK(c->ffn_dims % 32 == 0 && c->ffn_dims > 0, PETR_ERR_UNSUPPORTED, "head: ffn_dims must be a multiple of 32");
+  PETR_CHECK((c->H * c->W) % 4 == 0, PETR_ERR_UNSUPPORTED, "head: H*W must be a multiple of 4");
+  PETR_CHECK(!c->v2, PETR_ERR_UNSUPPORTED, "head: PETRv2 switches are not implemented in the fused executor yet");
+  PETR_CHECK(c->code_size >= 5 && c->num_classes >= 1, PETR_ERR_INVALID, "head: bad code_size/num_classes");
+  return PETR_OK;
+}
+
+static long align4(long v) { return (v + 3) & ~3L; }
+
+// ---------------------------------------------------------------------------------------------
+// parameter layout
+// ---------------------------------------------------------------------------------------------
+struct LayerP {
+  long sa_in_w, sa_in_b, sa_out_w, sa_out_b, ca_out_w, ca_out_b, f1_w, f1_b, f2_w, f2_b, n_g[3], n_b[3];
+  long ca_in_w, ca_in_b;   // live in the final block (K/V rows are only final after the K/V-projection backward)
+};
+struct POff {
+  long cls_w[3], cls_b[3], cls_g[2], cls_be[2], reg_w[3], reg_b[3];
+  long post_g, post_b;
+  LayerP lay[8];
+  long ca_in_stride;
+  long qe_w1, qe_b1, qe_w2, qe_b2, ref, pe_w1, pe_b1, pe_w2, pe_b2, ad_w1, ad_b1, ad_w2, ad_b2, in_w, in_b, code_w;
+  long total;
+  int n_stages;
+  long stage_begin[16], stage_end[16];
+};
+
+struct LayoutBuilder {
+  petr_head_layout_t* out;   // may be null
+  long cur = 0;
+  int count = 0;
+  long add(const char* name, int ndim, int s0, int s1 = 1, int s2 = 1, int s3 = 1, int alias_of = -1) {
+    const long n = (long)s0 * s1 * s2 * s3;
+    long off = cur;
+    if (alias_of >= 0 && out) off = out->offset[alias_of];
+    if (out && count < PETR_MAX_PARAMS) {
+      snprintf(out->name[count], sizeof(out->name[count]), "%s", name);
+      out->offset[count] = off;
+      out->ndim[count] = ndim;
+      out->shape[count][0] = s0; out->shape[count][1] = s1; out->shape[count][2] = s2; out->shape[count][3] = s3;
+      out->alias_of[count] = alias_of;
+    }
+    ++count;
+    if (alias_of < 0) cur = align4(cur + n);
+    return off;
+  }
+};
+
+static void build_layout(const petr_head_config* c, POff* P, petr_head_layout_t* out) {
+  const Dims d = make_dims(c);
+  LayoutBuilder lb;
+  lb.out = out;
+  char nm[128];
+  int stage = 0;
+  // ---- stage 0: branches + post_norm ----
+  P->stage_begin[stage] = lb.cur;
+  const int cls_idx[3] = {0, 3, 6}, ln_idx[2] = {1, 4}, reg_idx[3] = {0, 2, 4};
+  int first_cls[3][2], first_ln[2][2], first_reg[3][2];
+  for (int lvl = 0; lvl < d.NL; ++lvl) {
+    const bool alias = lvl > 0;   // PETRHead: one module in all slots (petr_head.py:244-247)
+    for (int i = 0; i < 3; ++i) {
+      const int nout = i == 2 ? d.ncls : d.C;
+      snprintf(nm, sizeof nm, "cls_branches.%d.%d.weight", lvl, cls_idx[i]);
+      if (!alias) first_cls[i][0] = lb.count;
+      long o = lb.add(nm, 2, nout, d.C, 1, 1, alias ? first_cls[i][0] : -1);
+      if (!alias) P->cls_w[i] = o;
+      snprintf(nm, sizeof nm, "cls_branches.%d.%d.bias", lvl, cls_idx[i]);
+      if (!alias) first_cls[i][1] = lb.count;
+      o = lb.add(nm, 1, nout, 1, 1, 1, alias ? first_cls[i][1] : -1);
+      if (!alias) P->cls_b[i] = o;
+      if (i < 2) {
+        snprintf(nm, sizeof nm, "cls_branches.%d.%d.weight", lvl, ln_idx[i]);
+        if (!alias) first_ln[i][0] = lb.count;
+        o = lb.add(nm, 1, d.C, 1, 1, 1, alias ? first_ln[i][0] : -1);
+        if (!alias) P->cls_g[i] = o;
+        snprintf(nm, sizeof nm, "cls_branches.%d.%d.bias", lvl, ln_idx[i]);
+        if (!alias) first_ln[i][1] = lb.count;
+        o = lb.add(nm, 1, d.C, 1, 1, 1, alias ? first_ln[i][1] : -1);
+        if (!alias) P->cls_be[i] = o;
+      }
+    }
+    for (int i = 0; i < 3; ++i) {
+      const int nout = i == 2 ? d.code : d.C;
+      snprintf(nm, sizeof nm, "reg_branches.%d.%d.weight", lvl, reg_idx[i]);
+      if (!alias) first_reg[i][0] = lb.count;
+      long o = lb.add(nm, 2, nout, d.C, 1, 1, alias ? first_reg[i][0] : -1);
+      if (!alias) P->reg_w[i] = o;
+      snprintf(nm, sizeof nm, "reg_branches.%d.%d.bias", lvl, reg_idx[i]);
+      if (!alias) first_reg[i][1] = lb.count;
+      o = lb.add(nm, 1, nout, 1, 1, 1, alias ? first_reg[i][1] : -1);
+      if (!alias) P->reg_b[i] = o;
+    }
+  }
+  P->post_g = lb.add("transformer.decoder.post_norm.weight", 1, d.C);
+  P->post_b = lb.add("transformer.decoder.post_norm.bias", 1, d.C);
+  P->stage_end[stage++] = lb.cur;
+  // ---- stages 1..NL: decoder layers, last layer first ----
+  for (int l = d.NL - 1; l >= 0; --l) {
+    P->stage_begin[stage] = lb.cur;
+    LayerP& lp = P->lay[l];
+    const char* pre = "transformer.decoder.layers";
+    snprintf(nm, sizeof nm, "%s.%d.attentions.0.attn.in_proj_weight", pre, l); lp.sa_in_w = lb.add(nm, 2, 3 * d.C, d.C);
+    snprintf(nm, sizeof nm, "%s.%d.attentions.0.attn.in_proj_bias", pre, l); lp.sa_in_b = lb.add(nm, 1, 3 * d.C);
+    snprintf(nm, sizeof nm, "%s.%d.attentions.0.attn.out_proj.weight", pre, l); lp.sa_out_w = lb.add(nm, 2, d.C, d.C);
+    snprintf(nm, sizeof nm, "%s.%d.attentions.0.attn.out_proj.bias", pre, l); lp.sa_out_b = lb.add(nm, 1, d.C);
+    snprintf(nm, sizeof nm, "%s.%d.attentions.1.attn.out_proj.weight", pre, l); lp.ca_out_w = lb.add(nm, 2, d.C, d.C);
+    snprintf(nm, sizeof nm, "%s.%d.attentions.1.attn.out_proj.bias", pre, l); lp.ca_out_b = lb.add(nm, 1, d.C);
+    snprintf(nm, sizeof nm, "%s.%d.ffns.0.layers.0.0.weight", pre, l); lp.f1_w = lb.add(nm, 2, d.F, d.C);
+    snprintf(nm, sizeof nm, "%s.%d.ffns.0.layers.0.0.bias", pre, l); lp.f1_b = lb.add(nm, 1, d.F);
+    snprintf(nm, sizeof nm, "%s.%d.ffns.0.layers.1.weight", pre, l); lp.f2_w = lb.add(nm, 2, d.C, d.F);
+    snprintf(nm, sizeof nm, "%s.%d.ffns.0.layers.1.bias", pre, l); lp.f2_b = lb.add(nm, 1, d.C);
+    for (int i = 0; i < 3; ++i) {
+      snprintf(nm, sizeof nm, "%s.%d.norms.%d.weight", pre, l, i); lp.n_g[i] = lb.add(nm, 1, d.C);
+      snprintf(nm, sizeof nm, "%s.%d.norms.%d.bias", pre, l, i); lp.n_b[i] = lb.add(nm, 1, d.C);
+    }
+    P->stage_end[stage++] = lb.cur;
+  }
+  // ---- final stage ----
+  P->stage_begin[stage] = lb.cur;
+  for (int l = 0; l < d.NL; ++l) {
+    snprintf(nm, sizeof nm, "transformer.decoder.layers.%d.attentions.1.attn.in_proj_weight", l);
+    P->lay[l].ca_in_w = lb.add(nm, 2, 3 * d.C, d.C);
+    snprintf(nm, sizeof nm, "transformer.decoder.layers.%d.attentions.1.attn.in_proj_bias", l);
+    P->lay[l].ca_in_b = lb.add(nm, 1, 3 * d.C);
+  }
+  P->ca_in_stride = d.NL > 1 ? P->lay[1].ca_in_w - P->lay[0].ca_in_w : 0;
+  P->qe_w1 = lb.add("query_embedding.0.weight", 2, d.C, d.C * 3 / 2);
+  P->qe_b1 = lb.add("query_embedding.0.bias", 1, d.C);
+  P->qe_w2 = lb.add("query_embedding.2.weight", 2, d.C, d.C);
+  P->qe_b2 = lb.add("query_embedding.2.bias", 1, d.C);
+  P->ref = lb.add("reference_points.weight", 2, d.Q, 3);
+  P->pe_w1 = lb.add("position_encoder.0.weight", 4, 4 * d.C, 3 * d.D, 1, 1);
+  P->pe_b1 = lb.add("position_encoder.0.bias", 1, 4 * d.C);
+  P->pe_w2 = lb.add("position_encoder.2.weight", 4, d.C, 4 * d.C, 1, 1);
+  P->pe_b2 = lb.add("position_encoder.2.bias", 1, d.C);
+  P->ad_w1 = lb.add("adapt_pos3d.0.weight", 4, 4 * d.C, d.C * 3 / 2, 1, 1);
+  P->ad_b1 = lb.add("adapt_pos3d.0.bias", 1, 4 * d.C);
+  P->ad_w2 = lb.add("adapt_pos3d.2.weight", 4, d.C, 4 * d.C, 1, 1);
+  P->ad_b2 = lb.add("adapt_pos3d.2.bias", 1, d.C);
+  P->in_w = lb.add("input_proj.weight", 4, d.C, d.Cin, 1, 1);
+  P->in_b = lb.add("input_proj.bias", 1, d.C);
+  P->stage_end[stage++] = lb.cur;
+  P->n_stages = stage;
+  P->code_w = lb.add("code_weights", 1, d.code);   // no gradient (petr_head.py:211-212)
+  P->total = lb.cur;
+  if (out) {
+    out->count = lb.count;
+    out->total = lb.cur;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace layout (activations kept for backward + scratch), offsets in floats
+// ---------------------------------------------------------------------------------------------
+struct LayerW {
+  long qkv, ao_s, lse_s, z0, mean0, rstd0, x1, xe1, qc, ao_c, lse_c, z1, mean1, rstd1, x2, hff, z2, mean2, rstd2, xe_in;
+};
+struct WOff {
+  long posemb, qe_h, qe, vol, sine, mem, h1, h2, pos, mempos, k_all, v_all, x0;
+  LayerW lay[8];
+  long xs, mean_p, rstd_p, outs;
+  long c1, c1_mean, c1_rstd, c1n, c2, c2_mean, c2_rstd, c2n, r1, r2, reg_raw;
+  long ffn_part; int ffn_split;
+  long mha_ws; size_t mha_ws_bytes;
+  // ---- backward scratch ----
+  long zero_begin, zero_end;     // cleared once per backward (atomic / += targets)
+  long d_qc, d_qkv, dk_all, dv_all, d_ref_tmp;
+  long d_outs, d_xs, ga, gb, gc, gd, d_mempos, d_mem, d_hpe, d_e_slab, d_e, d_qe_h, d_posemb;
+  long total;
+};
+
+struct WsBuilder {
+  long cur = 0;
+  struct Entry { const char* name; long off, n; } table[256];
+  int count = 0;
+  long add(const char* name, long n) {
+    const long off = cur;
+    if (count < 256) table[count++] = {name, off, n};
+    cur = align4(cur + n);
+    return off;
+  }
+};
+
+static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
+  const Dims d = make_dims(c);
+  WsBuilder wb;
+  WOff& W = *Wf;
+  const long C = d.C;
+  W.posemb = wb.add("posemb", (long)d.Q * C * 3 / 2);
+  W.qe_h = wb.add("query_embed_hidden", (long)d.Q * C);
+  W.qe = wb.add("query_embed", (long)d.Q * C);
+  W.vol = wb.add("coords3d", (long)d.B * d.N * 3 * d.D * d.HW);
+  W.sine = wb.add("sine", (long)d.B * d.N * (C * 3 / 2) * d.HW);
+  W.mem = wb.add("memory", d.BL * C);
+  W.h1 = wb.add("pe_hidden", d.BL * 4 * C);
+  W.h2 = wb.add("sine_hidden", d.BL * 4 * C);
+  W.pos = wb.add("pos_embed", d.BL * C);
+  W.mempos = wb.add("mempos", d.BL * C);
+  W.k_all = wb.add("k_all", (long)d.B * d.NL * d.L * C);
+  W.v_all = wb.add("v_all", (long)d.B * d.NL * d.L * C);
+  W.x0 = wb.add("x0", d.BQ * C);
+  for (int l = 0; l < d.NL; ++l) {
+    LayerW& lw = W.lay[l];
+    lw.xe_in = wb.add("xe_in", d.BQ * C);
+    lw.qkv = wb.add("qkv_self", d.BQ * 3 * C);
+    lw.ao_s = wb.add("attn_self", d.BQ * C);
+    lw.lse_s = wb.add("lse_self", (long)d.B * d.NH * d.Q);
+    lw.z0 = wb.add("z0", d.BQ * C);
+    lw.mean0 = wb.add("mean0", d.BQ);
+    lw.rstd0 = wb.add("rstd0", d.BQ);
+    lw.x1 = wb.add("x1", d.BQ * C);
+    lw.xe1 = wb.add("xe1", d.BQ * C);
+    lw.qc = wb.add("q_cross", d.BQ * C);
+    lw.ao_c = wb.add("attn_cross", d.BQ * C);
+    lw.lse_c = wb.add("lse_cross", (long)d.B * d.NH * d.Q);
+    lw.z1 = wb.add("z1", d.BQ * C);
+    lw.mean1 = wb.add("mean1", d.BQ);
+    lw.rstd1 = wb.add("rstd1", d.BQ);
+    lw.x2 = wb.add("x2", d.BQ * C);
+    lw.hff = wb.add("ffn_hidden", d.BQ * d.F);
+    lw.z2 = wb.add("z2", d.BQ * C);
+    lw.mean2 = wb.add("mean2", d.BQ);
+    lw.rstd2 = wb.add("rstd2", d.BQ);
+  }
+  W.xs = wb.add("xs", d.R * C);
+  W.mean_p = wb.add("mean_post", d.R);
+  W.rstd_p = wb.add("rstd_post", d.R);
+  W.outs = wb.add("outs_dec", d.R * C);
+  W.c1 = wb.add("c1", d.R * C);
+  W.c1_mean = wb.add("c1_mean", d.R);
+  W.c1_rstd = wb.add("c1_rstd", d.R);
+  W.c1n = wb.add("c1n", d.R * C);
+  W.c2 = wb.add("c2", d.R * C);
+  W.c2_mean = wb.add("c2_mean", d.R);
+  W.c2_rstd = wb.add("c2_rstd", d.R);
+  W.c2n = wb.add("c2n", d.R * C);
+  W.r1 = wb.add("r1", d.R * C);
+  W.r2 = wb.add("r2", d.R * C);
+  W.reg_raw = wb.add("reg_raw", d.R * d.code);
+  // split-K of the second FFN contraction (K = F, only 4x15 output tiles otherwise)
+  W.ffn_split = d.BQ <= 2048 ? 4 : 1;
+  if (d.F / 32 < W.ffn_split) W.ffn_split = 1;
+  W.ffn_part = wb.add("ffn_partials", (long)W.ffn_split * d.BQ * C);
+  {
+    size_t a = petr_mha_fwd_workspace_bytes(d.B, d.NH, d.Q, (int)d.L, 0);
+    size_t b = petr_mha_fwd_workspace_bytes(d.B, d.NH, d.Q, d.Q, 0);
+    size_t e = petr_mha_bwd_workspace_bytes(d.B, d.NH, d.Q, (int)d.L);
+    size_t m = a > b ? a : b;
+    if (e > m) m = e;
+    W.mha_ws_bytes = m + 16;
+    W.mha_ws = wb.add("mha_ws", (long)(W.mha_ws_bytes / 4) + 4);
+  }
+  // ---- backward ----
+  W.zero_begin = wb.cur;
+  W.d_qc = wb.add("d_qc", (long)d.NL * d.BQ * C);
+  W.d_qkv = wb.add("d_qkv", (long)d.NL * d.BQ * 3 * C);
+  W.dk_all = wb.add("dk_all", (long)d.B * d.NL * d.L * C);
+  W.dv_all = wb.add("dv_all", (long)d.B * d.NL * d.L * C);
+  W.d_ref_tmp = wb.add("d_ref_tmp", (long)d.Q * 3);
+  W.zero_end = wb.cur;
+  W.d_outs = wb.add("d_outs", d.R * C);
+  W.d_xs = wb.add("d_xs", d.R * C);
+  const long wide = d.BQ * (d.F > 3 * C ? d.F : 3 * C);
+  W.ga = wb.add("ga", d.R * C > wide ? d.R * C : wide);
+  W.gb = wb.add("gb", d.R * C > wide ? d.R * C : wide);
+  W.gc = wb.add("gc", d.R * C);
+  W.gd = wb.add("gd", d.R * C);
+  W.d_mempos = wb.add("d_mempos", d.BL * C);
+  W.d_mem = wb.add("d_mem", d.BL * C);
+  W.d_hpe = wb.add("d_hpe", d.BL * 4 * C);
+  W.d_e_slab = wb.add("d_e_slab", (long)d.NL * d.BQ * C);
+  W.d_e = wb.add("d_e", (long)d.Q * C);
+  W.d_qe_h = wb.add("d_qe_h", (long)d.Q * C);
+  W.d_posemb = wb.add("d_posemb", (long)d.Q * C * 3 / 2);
+  W.total = wb.cur;
+  if (wb_out) *wb_out = wb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small call builders
+// ---------------------------------------------------------------------------------------------
+static petr_gemm_args gemm0() {
+  petr_gemm_args g;
+  memset(&g, 0, sizeof g);
+  g.nb0 = g.nb1 = g.split_k = 1;
+  g.alpha = 1.f;
+  return g;
+}
+// y[M,N] = x[M,K] @ w[N,K]^T (+bias)
+static petr_gemm_args lin_fwd(const float* x, const float* w, const float* bias, float* y, long M, int N, int K) {
+  petr_gemm_args g = gemm0();
+  g.a = x; g.lda = K; g.a_kcontig = 1;
+  g.b = w; g.ldb = K; g.b_kcontig = 1;
+  g.c = y; g.ldc = N; g.bias = bias;
+  g.M = (int)M; g.N = N; g.K = K;
+  return g;
+}
+// dx[M,K] = dy[M,N] @ w[N,K]
+static petr_gemm_args lin_dgrad(const float* dy, const float* w, float* dx, long M, int N, int K) {
+  petr_gemm_args g = gemm0();
+  g.a = dy; g.lda = N; g.a_kcontig = 1;
+  g.b = w; g.ldb = K; g.b_kcontig = 0;
+  g.c = dx; g.ldc = K;
+  g.M = (int)M; g.N = K; g.K = N;
+  return g;
+}
+// dw[N,K] += dy[M,N]^T @ x[M,K] ; db[N] += colsum(dy)   (float atomics, split over the M rows)
+static petr_gemm_args lin_wgrad(const float* dy, long ldy, const float* x, long ldx, float* dw, float* db, long M, int N,
+                                int K) {
+  petr_gemm_args g = gemm0();
+  g.a = dy; g.lda = ldy; g.a_kcontig = 0;
+  g.b = x; g.ldb = ldx; g.b_kcontig = 0;
+  g.c = dw; g.ldc = K;
+  g.M = N; g.N = K; g.K = (int)M;
+  g.flags = PETR_GEMM_ATOMIC;
+  g.a_colsum = db;
+  const long tiles = cdiv(N, 64) * cdiv(K, 64);
+  long sk = 512 / (tiles > 0 ? tiles : 1);
+  const long ktiles = cdiv(M, 32);
+  if (sk > ktiles / 2) sk = ktiles / 2;
+  if (sk < 1) sk = 1;
+  if (sk > 64) sk = 64;
+  g.split_k = (int)sk;
+  return g;
+}
+
+#define RUN(expr)                 \
+  do {                            \
+    const int rc__ = (expr);      \
+    if (rc__ != PETR_OK) return rc__; \
+  } while (0)
+
+static int ln_fwd(const float* x, int np, long pstride, const float* bias, const float* res, const float* g,
+                  const float* b, float* y, float* z_out, float* mean, float* rstd, long M, int C, int flags, float* y2,
+                  const float* add2, int add2_rows, void* s) {
+  petr_layernorm_args a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.n_partials = np; a.partial_stride = pstride; a.bias = bias; a.residual = res; a.gamma = g; a.beta = b;
+  a.y = y; a.z_out = z_out; a.mean = mean; a.rstd = rstd; a.M = (int)M; a.C = C; a.eps = 1e-5f; a.flags = flags;
+  a.y2 = y2; a.add2 = add2; a.add2_rows = add2_rows;
+  return petr_layernorm_fwd(&a, s);
+}
+
+static int ln_bwd(const float* z, const float* mean, const float* rstd, const float* g, const float* dy, const float* y,
+                  float* dz, float* dg, float* db, long M, int C, int flags, int accumulate, void* s) {
+  petr_layernorm_bwd_args a;
+  memset(&a, 0, sizeof a);
+  a.z = z; a.mean = mean; a.rstd = rstd; a.gamma = g; a.dy = dy; a.y = y; a.dz = dz; a.dgamma = dg; a.dbeta = db;
+  a.ws = nullptr; a.M = (int)M; a.C = C; a.flags = flags; a.dz_accumulate = accumulate;
+  return petr_layernorm_bwd(&a, s);
+}
+
+static int mha_f(const float* q, long q_bs, long q_rs, const float* k, long k_bs, long k_rs, const float* v, float* o,
+                 float* lse, const uint8_t* kpm, const Dims& d, int L, float* ws, size_t ws_bytes, void* s) {
+  petr_mha_fwd_args a;
+  memset(&a, 0, sizeof a);
+  a.q = q; a.q_bs = q_bs; a.q_hs = 32; a.q_rs = q_rs;
+  a.k = k; a.k_bs = k_bs; a.k_hs = 32; a.k_rs = k_rs;
+  a.v = v; a.v_bs = k_bs; a.v_hs = 32; a.v_rs = k_rs;
+  a.o = o; a.o_bs = (long)d.Q * d.C; a.o_hs = 32; a.o_rs = d.C;
+  a.lse = lse; a.kpm = kpm; a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
+  a.scale = 1.0f / sqrtf(32.f);
+  a.n_split = 0; a.ws = ws; a.ws_bytes = ws_bytes;
+  return petr_mha_fwd(&a, s);
+}
+
+static int mha_b(const float* q, long q_bs, long q_rs, const float* k, long k_bs, long k_rs, const float* v,
+                 const float* o, const float* d_o, const float* lse, const uint8_t* kpm, float* dq, float* dk, float* dv,
+                 const Dims& d, int L, float* ws, size_t ws_bytes, void* s) {
+  petr_mha_bwd_args a;
+  memset(&a, 0, sizeof a);
+  a.q = q; a.q_bs = q_bs; a.q_hs = 32; a.q_rs = q_rs;
+  a.k = k; a.k_bs = k_bs; a.k_hs = 32; a.k_rs = k_rs;
+  a.v = v; a.v_bs = k_bs; a.v_hs = 32; a.v_rs = k_rs;
+  a.o = o; a.o_bs = (long)d.Q * d.C; a.o_hs = 32; a.o_rs = d.C;
+  a.d_o = d_o; a.do_bs = (long)d.Q * d.C; a.do_hs = 32; a.do_rs = d.C;
+  a.lse = lse; a.kpm = kpm;
+  a.dq = dq; a.dq_bs = q_bs; a.dq_hs = 32; a.dq_rs = q_rs;
+  a.dk = dk; a.dk_bs = k_bs; a.dk_hs = 32; a.dk_rs = k_rs;
+  a.dv = dv; a.dv_bs = k_bs; a.dv_hs = 32; a.dv_rs = k_rs;
+  a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
+  a.scale = 1.0f / sqrtf(32.f);
+  a.ws = ws; a.ws_bytes = ws_bytes;
+  return petr_mha_bwd(&a, s);
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" int petr_head_layout(const petr_head_config* cfg, petr_head_layout_t* out) {
+  RUN(check_config(cfg));
+  PETR_CHECK(out, PETR_ERR_INVALID, "head_layout: null output");
+  POff P;
+  build_layout(cfg, &P, out);
+  PETR_CHECK(out->count <= PETR_MAX_PARAMS, PETR_ERR_UNSUPPORTED, "head_layout: too many tensors");
+  return PETR_OK;
+}
+
+extern "C" size_t petr_head_workspace_bytes(const petr_head_config* cfg) {
+  if (check_config(cfg) != PETR_OK) return 0;
+  WOff W;
+  build_ws(cfg, &W, nullptr);
+  return (size_t)W.total * sizeof(float);
+}
+
+extern "C" int petr_head_ws_view(const petr_head_config* cfg, const char* name, long* offset_floats, long* numel) {
+  RUN(check_config(cfg));
+  PETR_CHECK(name && offset_floats && numel, PETR_ERR_INVALID, "head_ws_view: null argument");
+  WOff W;
+  WsBuilder wb;
+  build_ws(cfg, &W, &wb);
+  // "<name>" (first occurrence) or "<name>.<layer>" (occurrence index) for per-layer buffers
+  char base[64];
+  int want = 0;
+  snprintf(base, sizeof base, "%s", name);
+  char* dot = strrchr(base, '.');
+  if (dot && dot[1] >= '0' && dot[1] <= '9') {
+    want = atoi(dot + 1);
+    *dot = 0;
+  }
+  int seen = 0;
+  for (int i = 0; i < wb.count; ++i) {
+    if (strcmp(wb.table[i].name, base) == 0) {
+      if (seen == want) {
+        *offset_floats = wb.table[i].off;
+        *numel = wb.table[i].n;
+        return PETR_OK;
+      }
+      ++seen;
+    }
+  }
+  petr_set_error("head_ws_view: no buffer named '%s'", name);
+  return PETR_ERR_INVALID;
+}
+
+extern "C" int petr_head_bwd_num_stages(const petr_head_config* cfg) {
+  if (check_config(cfg) != PETR_OK) return -1;
+  POff P;
+  build_layout(cfg, &P, nullptr);
+  return P.n_stages;
+}
+
+extern "C" int petr_head_bwd_stage_range(const petr_head_config* cfg, int stage, long* begin, long* end) {
+  RUN(check_config(cfg));
+  POff P;
+  build_layout(cfg, &P, nullptr);
+  PETR_CHECK(stage >= 0 && stage < P.n_stages && begin && end, PETR_ERR_INVALID, "head_bwd_stage_range: bad stage");
+  *begin = P.stage_begin[stage];
+  *end = P.stage_end[stage];
+  return PETR_OK;
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io, void* s) {
+  RUN(check_config(cfg));
+  PETR_CHECK(io && io->params && io->feats && io->img2lidar && io->depth && io->dim_t && io->all_cls_scores &&
+                 io->all_bbox_preds && io->ws,
+             PETR_ERR_INVALID, "head_fwd: null pointer");
+  PETR_CHECK(!cfg->has_mask || io->mask, PETR_ERR_INVALID, "head_fwd: has_mask without a mask");
+  const Dims d = make_dims(cfg);
+  POff P;
+  build_layout(cfg, &P, nullptr);
+  WOff W;
+  build_ws(cfg, &W, nullptr);
+  PETR_CHECK(io->ws_bytes >= (size_t)W.total * sizeof(float), PETR_ERR_WORKSPACE, "head_fwd: workspace %zu < %zu bytes",
+             io->ws_bytes, (size_t)W.total * sizeof(float));
+  PETR_CHECK(aligned16(io->params) && aligned16(io->ws) && aligned16(io->feats), PETR_ERR_INVALID,
+             "head_fwd: params / ws / feats must be 16-byte aligned");
+  const float* Pm = io->params;
+  float* Wm = (float*)io->ws;
+  const int C = d.C;
+  const uint8_t* kpm = cfg->has_mask ? io->mask : nullptr;
+
+  // ---- query embedding: pos2posemb3d + MLP (petr_head.py:422-423) ----
+  RUN(petr_posemb3d_fwd(Pm + P.ref, io->dim_t, Wm + W.posemb, d.Q, C / 2, s));
+  {
+    petr_gemm_args g = lin_fwd(Wm + W.posemb, Pm + P.qe_w1, Pm + P.qe_b1, Wm + W.qe_h, d.Q, C, C * 3 / 2);
+    g.flags = PETR_GEMM_RELU;
+    RUN(petr_gemm(&g, s));
+    g = lin_fwd(Wm + W.qe_h, Pm + P.qe_w2, Pm + P.qe_b2, Wm + W.qe, d.Q, C, C);
+    RUN(petr_gemm(&g, s));
+  }
+  const float* E = Wm + W.qe;
+
+  // ---- 3D position embedding (petr_head.py:286-334) + sine 3D (positional_encoding.py:58-100) ----
+  {
+    petr_coords3d_args a;
+    memset(&a, 0, sizeof a);
+    a.img2lidar = io->img2lidar; a.depth = io->depth; a.out = Wm + W.vol; a.cmask = nullptr;
+    a.B = d.B; a.N = d.N; a.H = d.H; a.W = d.W; a.D = d.D; a.pad_h = cfg->pad_h; a.pad_w = cfg->pad_w;
+    for (int i = 0; i < 6; ++i) a.range[i] = cfg->position_range[i];
+    a.eps = 1e-5f;
+    RUN(petr_coords3d_fwd(&a, s));
+    petr_sine3d_args b;
+    memset(&b, 0, sizeof b);
+    b.mask = kpm; b.dim_t = io->dim_t; b.out = Wm + W.sine; b.B = d.B; b.N = d.N; b.H = d.H; b.W = d.W; b.F = C / 2;
+    b.normalize = 1; b.scale = 6.283185307179586f; b.eps = 1e-6f; b.offset = 0.f;
+    RUN(petr_sine3d_fwd(&b, s));
+  }
+  const int V = d.B * d.N;
+  {
+    // input_proj (petr_head.py:390): NCHW view [C_in][HW] read as an M-contiguous operand -> token-major memory
+    petr_gemm_args g = gemm0();
+    g.a = io->feats; g.lda = d.HW; g.a_kcontig = 0; g.a_bs0 = (long)d.Cin * d.HW;
+    g.b = Pm + P.in_w; g.ldb = d.Cin; g.b_kcontig = 1;
+    g.c = Wm + W.mem; g.ldc = C; g.c_bs0 = (long)d.HW * C; g.bias = Pm + P.in_b;
+    g.M = d.HW; g.N = C; g.K = d.Cin; g.nb0 = V;
+    RUN(petr_gemm(&g, s));
+    // position_encoder: conv1x1 3D->4C, ReLU, conv1x1 4C->C (petr_head.py:263-267,332)
+    g = gemm0();
+    g.a = Wm + W.vol; g.lda = d.HW; g.a_kcontig = 0; g.a_bs0 = (long)3 * d.D * d.HW;
+    g.b = Pm + P.pe_w1; g.ldb = 3 * d.D; g.b_kcontig = 1;
+    g.c = Wm + W.h1; g.ldc = 4 * C; g.c_bs0 = (long)d.HW * 4 * C; g.bias = Pm + P.pe_b1;
+    g.M = d.HW; g.N = 4 * C; g.K = 3 * d.D; g.nb0 = V; g.flags = PETR_GEMM_RELU;
+    RUN(petr_gemm(&g, s));
+    g = lin_fwd(Wm + W.h1, Pm + P.pe_w2, Pm + P.pe_b2, Wm + W.pos, d.BL, C, 4 * C);
+    RUN(petr_gemm(&g, s));
+    // adapt_pos3d on the sine features, summed into pos (petr_head.py:400-402)
+    g = gemm0();
+    g.a = Wm + W.sine; g.lda = d.HW; g.a_kcontig = 0; g.a_bs0 = (long)(C * 3 / 2) * d.HW;
+    g.b = Pm + P.ad_w1; g.ldb = C * 3 / 2; g.b_kcontig = 1;
+    g.c = Wm + W.h2; g.ldc = 4 * C; g.c_bs0 = (long)d.HW * 4 * C; g.bias = Pm + P.ad_b1;
+    g.M = d.HW; g.N = 4 * C; g.K = C * 3 / 2; g.nb0 = V; g.flags = PETR_GEMM_RELU;
+    RUN(petr_gemm(&g, s));
+    g = lin_fwd(Wm + W.h2, Pm + P.ad_w2, Pm + P.ad_b2, Wm + W.pos, d.BL, C, 4 * C);
+    g.flags = PETR_GEMM_ACCUMULATE;
+    RUN(petr_gemm(&g, s));
+    // key = memory + key_pos (petr_transformer.py:343-344), once for all layers
+    RUN(petr_add_rows(Wm + W.mem, Wm + W.pos, Wm + W.mempos, d.BL, 0, C, s));
+    // K_l = (mem+pos) Wk_l^T + bk_l ; V_l = mem Wv_l^T + bv_l for ALL layers: [B][NL][L][C]
+    for (int kv = 0; kv < 2; ++kv) {
+      g = gemm0();
+      g.a = kv == 0 ? Wm + W.mempos : Wm + W.mem; g.lda = C; g.a_kcontig = 1; g.a_bs0 = d.L * C;
+      g.b = Pm + P.lay[0].ca_in_w + (long)(kv + 1) * C * C; g.ldb = C; g.b_kcontig = 1; g.b_bs1 = P.ca_in_stride;
+      g.bias = Pm + P.lay[0].ca_in_b + (kv + 1) * C; g.bias_bs1 = P.ca_in_stride;
+      g.c = Wm + (kv == 0 ? W.k_all : W.v_all); g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
+      g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
+      RUN(petr_gemm(&g, s));
+    }
+  }
+
+  // ---- decoder (petr_transformer.py:95-107,440-446; layer op order A.3) ----
+  RUN(petr_fill(Wm + W.x0, 0.f, d.BQ * C, s));                       // target = zeros (:95)
+  RUN(petr_add_rows(Wm + W.x0, E, Wm + W.lay[0].xe_in, d.BQ, d.Q, C, s));
+  const float* x_in = Wm + W.x0;
+  float* mws = Wm + W.mha_ws;
+  for (int l = 0; l < d.NL; ++l) {
+    const LayerP& lp = P.lay[l];
+    const LayerW& lw = W.lay[l];
+    // self-attention: q = k = x + query_pos, v = x  (multi_atten_decoder_layer.py:223-237)
+    petr_gemm_args g = lin_fwd(x_in, Pm + lp.sa_in_w, Pm + lp.sa_in_b, Wm + lw.qkv, d.BQ, 3 * C, C);
+    g.a2 = E; g.a2_rows = d.Q; g.a2_ncols = 2 * C;
+    RUN(petr_gemm(&g, s));
+    RUN(mha_f(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
+              Wm + lw.ao_s, Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, s));
+    g = lin_fwd(Wm + lw.ao_s, Pm + lp.sa_out_w, Pm + lp.sa_out_b, Wm + lw.z0, d.BQ, C, C);
+    g.r = x_in; g.ldr = C;                                             // identity + out (petr_transformer.py:367)
+    RUN(petr_gemm(&g, s));
+    RUN(ln_fwd(Wm + lw.z0, 1, 0, nullptr, nullptr, Pm + lp.n_g[0], Pm + lp.n_b[0], Wm + lw.x1, nullptr, Wm + lw.mean0,
+               Wm + lw.rstd0, d.BQ, C, 0, Wm + lw.xe1, E, d.Q, s));
+    // cross-attention: q = x1 + query_pos, k = mem + pos, v = mem (petr_transformer.py:341-362)
+    g = lin_fwd(Wm + lw.xe1, Pm + lp.ca_in_w, Pm + lp.ca_in_b, Wm + lw.qc, d.BQ, C, C);
+    RUN(petr_gemm(&g, s));
+    RUN(mha_f(Wm + lw.qc, (long)d.Q * C, C, Wm + W.k_all + (long)l * d.L * C, (long)d.NL * d.L * C, C,
+              Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, s));
+    g = lin_fwd(Wm + lw.ao_c, Pm + lp.ca_out_w, Pm + lp.ca_out_b, Wm + lw.z1, d.BQ, C, C);
+    g.r = Wm + lw.x1; g.ldr = C;
+    RUN(petr_gemm(&g, s));
+    RUN(ln_fwd(Wm + lw.z1, 1, 0, nullptr, nullptr, Pm + lp.n_g[1], Pm + lp.n_b[1], Wm + lw.x2, nullptr, Wm + lw.mean1,
+               Wm + lw.rstd1, d.BQ, C, 0, nullptr, nullptr, 0, s));
+    // FFN (mmcv FFN): x + W2 relu(W1 x + b1) + b2 ; second contraction split over K
+    g = lin_fwd(Wm + lw.x2, Pm + lp.f1_w, Pm + lp.f1_b, Wm + lw.hff, d.BQ, d.F, C);
+    g.flags = PETR_GEMM_RELU;
+    RUN(petr_gemm(&g, s));
+    g = lin_fwd(Wm + lw.hff, Pm + lp.f2_w, nullptr, Wm + W.ffn_part, d.BQ, C, d.F);
+    g.split_k = W.ffn_split; g.c_split_stride = d.BQ * C;
+    float* xs_l = Wm + W.xs + (long)l * d.BQ * C;
+    if (W.ffn_split == 1) { g.bias = Pm + lp.f2_b; g.r = Wm + lw.x2; g.ldr = C; g.c = Wm + lw.z2; }
+    RUN(petr_gemm(&g, s));
+    float* xe_next = l + 1 < d.NL ? Wm + W.lay[l + 1].xe_in : nullptr;
+    if (W.ffn_split == 1) {
+      RUN(ln_fwd(Wm + lw.z2, 1, 0, nullptr, nullptr, Pm + lp.n_g[2], Pm + lp.n_b[2], xs_l, nullptr, Wm + lw.mean2,
+                 Wm + lw.rstd2, d.BQ, C, 0, xe_next, E, d.Q, s));
+    } else {
+      RUN(ln_fwd(Wm + W.ffn_part, W.ffn_split, d.BQ * C, Pm + lp.f2_b, Wm + lw.x2, Pm + lp.n_g[2], Pm + lp.n_b[2], xs_l,
+                 Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, d.BQ, C, 0, xe_next, E, d.Q, s));
+    }
+    x_in = xs_l;
+  }
+  // post_norm of every intermediate (petr_transformer.py:444, one shared LN) + nan_to_num (petr_head.py:435)
+  RUN(ln_fwd(Wm + W.xs, 1, 0, nullptr, nullptr, Pm + P.post_g, Pm + P.post_b, Wm + W.outs, nullptr, Wm + W.mean_p,
+             Wm + W.rstd_p, d.R, C, PETR_LN_NAN_TO_NUM, nullptr, nullptr, 0, s));
+
+  // ---- branches (petr_head.py:226-247,440-460): one shared cls / reg module for all levels ----
+  {
+    petr_gemm_args g = lin_fwd(Wm + W.outs, Pm + P.cls_w[0], Pm + P.cls_b[0], Wm + W.c1, d.R, C, C);
+    RUN(petr_gemm(&g, s));
+    RUN(ln_fwd(Wm + W.c1, 1, 0, nullptr, nullptr, Pm + P.cls_g[0], Pm + P.cls_be[0], Wm + W.c1n, nullptr, Wm + W.c1_mean,
+               Wm + W.c1_rstd, d.R, C, PETR_LN_RELU, nullptr, nullptr, 0, s));
+    g = lin_fwd(Wm + W.c1n, Pm + P.cls_w[1], Pm + P.cls_b[1], Wm + W.c2, d.R, C, C);
+    RUN(petr_gemm(&g, s));
+    RUN(ln_fwd(Wm + W.c2, 1, 0, nullptr, nullptr, Pm + P.cls_g[1], Pm + P.cls_be[1], Wm + W.c2n, nullptr, Wm + W.c2_mean,
+               Wm + W.c2_rstd, d.R, C, PETR_LN_RELU, nullptr, nullptr, 0, s));
+    g = lin_fwd(Wm + W.c2n, Pm + P.cls_w[2], Pm + P.cls_b[2], io->all_cls_scores, d.R, d.ncls, C);
+    RUN(petr_gemm(&g, s));
+    g = lin_fwd(Wm + W.outs, Pm + P.reg_w[0], Pm + P.reg_b[0], Wm + W.r1, d.R, C, C);
+    g.flags = PETR_GEMM_RELU;
+    RUN(petr_gemm(&g, s));
+    g = lin_fwd(Wm + W.r1, Pm + P.reg_w[1], Pm + P.reg_b[1], Wm + W.r2, d.R, C, C);
+    g.flags = PETR_GEMM_RELU;
+    RUN(petr_gemm(&g, s));
+    g = lin_fwd(Wm + W.r2, Pm + P.reg_w[2], Pm + P.reg_b[2], Wm + W.reg_raw, d.R, d.code, C);
+    RUN(petr_gemm(&g, s));
+    petr_bbox_args a;
+    memset(&a, 0, sizeof a);
+    a.reg = Wm + W.reg_raw; a.ref = Pm + P.ref; a.out = io->all_bbox_preds; a.rows = (int)d.R; a.Q = d.Q; a.code = d.code;
+    for (int i = 0; i < 6; ++i) a.pc_range[i] = cfg->pc_range[i];
+    a.time_div = 0.f; a.eps = 1e-5f;
+    RUN(petr_bbox_epilogue_fwd(&a, s));
+  }
+  return PETR_OK;
+}
+
+// =============================================================================================
+// backward
+// =============================================================================================
+extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io, const petr_head_grads* gr,
+                             int stage_begin, int stage_end, void* s) {
+  RUN(check_config(cfg));
+  PETR_CHECK(io && io->params && io->feats && io->ws && io->all_bbox_preds && gr && gr->d_cls && gr->d_bbox && gr->d_params,
+             PETR_ERR_INVALID, "head_bwd: null pointer");
+  const Dims d = make_dims(cfg);
+  POff P;
+  build_layout(cfg, &P, nullptr);
+  WOff W;
+  build_ws(cfg, &W, nullptr);
+  PETR_CHECK(io->ws_bytes >= (size_t)W.total * sizeof(float), PETR_ERR_WORKSPACE, "head_bwd: workspace too small");
+  PETR_CHECK(stage_begin >= 0 && stage_end <= P.n_stages && stage_begin < stage_end, PETR_ERR_INVALID,
+             "head_bwd: bad stage range [%d,%d)", stage_begin, stage_end);
+  const float* Pm = io->params;
+  float* Gp = gr->d_params;
+  float* Wm = (float*)io->ws;
+  const int C = d.C;
+  const uint8_t* kpm = cfg->has_mask ? io->mask : nullptr;
+  const float* E = Wm + W.qe;
+  float* mws = Wm + W.mha_ws;
+  hipStream_t hs = (hipStream_t)s;
+
+  for (int stage = stage_begin; stage < stage_end; ++stage) {
+    if (stage == 0) {
+      // clear every += / atomic target of this backward pass
+      hipError_t e = hipMemsetAsync(Wm + W.zero_begin, 0, (size_t)(W.zero_end - W.zero_begin) * sizeof(float), hs);
+      PETR_CHECK(e == hipSuccess, PETR_ERR_LAUNCH, "head_bwd: memset failed: %s", hipGetErrorString(e));
+      // ---- box epilogue + reg branch ----
+      petr_bbox_args a;
+      memset(&a, 0, sizeof a);
+      a.ref = Pm + P.ref; a.out = io->all_bbox_preds; a.rows = (int)d.R; a.Q = d.Q; a.code = d.code;
+      for (int i = 0; i < 6; ++i) a.pc_range[i] = cfg->pc_range[i];
+      a.time_div = 0.f; a.eps = 1e-5f;
+      float* d_raw = Wm + W.ga;   // [R, code]
+      RUN(petr_bbox_epilogue_bwd(&a, gr->d_bbox, d_raw, Wm + W.d_ref_tmp, s));
+      petr_gemm_args g = lin_wgrad(d_raw, d.code, Wm + W.r2, C, Gp + P.reg_w[2], Gp + P.reg_b[2], d.R, d.code, C);
+      RUN(petr_gemm(&g, s));
+      float* d_r2 = Wm + W.gb;
+      g = lin_dgrad(d_raw, Pm + P.reg_w[2], d_r2, d.R, d.code, C);
+      g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.r2; g.ldr = C;
+      RUN(petr_gemm(&g, s));
+      g = lin_wgrad(d_r2, C, Wm + W.r1, C, Gp + P.reg_w[1], Gp + P.reg_b[1], d.R, C, C);
+      RUN(petr_gemm(&g, s));
+      float* d_r1 = Wm + W.gc;
+      g = lin_dgrad(d_r2, Pm + P.reg_w[1], d_r1, d.R, C, C);
+      g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.r1; g.ldr = C;
+      RUN(petr_gemm(&g, s));
+      g = lin_wgrad(d_r1, C, Wm + W.outs, C, Gp + P.reg_w[0], Gp + P.reg_b[0], d.R, C, C);
+      RUN(petr_gemm(&g, s));
+      g = lin_dgrad(d_r1, Pm + P.reg_w[0], Wm + W.d_outs, d.R, C, C);
+      RUN(petr_gemm(&g, s));
+      // ---- cls branch ----
+      g = lin_wgrad(gr->d_cls, d.ncls, Wm + W.c2n, C, Gp + P.cls_w[2], Gp + P.cls_b[2], d.R, d.ncls, C);
+      RUN(petr_gemm(&g, s));
+      float* d_c2n = Wm + W.ga;
+      g = lin_dgrad(gr->d_cls, Pm + P.cls_w[2], d_c2n, d.R, d.ncls, C);
+      RUN(petr_gemm(&g, s));
+      float* d_c2 = Wm + W.gb;
+      RUN(ln_bwd(Wm + W.c2, Wm + W.c2_mean, Wm + W.c2_rstd, Pm + P.cls_g[1], d_c2n, Wm + W.c2n, d_c2, Gp + P.cls_g[1],
+                 Gp + P.cls_be[1], d.R, C, PETR_LN_RELU, 0, s));
+      g = lin_wgrad(d_c2, C, Wm + W.c1n, C, Gp + P.cls_w[1], Gp + P.cls_b[1], d.R, C, C);
+      RUN(petr_gemm(&g, s));
+      float* d_c1n = Wm + W.ga;
+      g = lin_dgrad(d_c2, Pm + P.cls_w[1], d_c1n, d.R, C, C);
+      RUN(petr_gemm(&g, s));
+      float* d_c1 = Wm + W.gb;
+      RUN(ln_bwd(Wm + W.c1, Wm + W.c1_mean, Wm + W.c1_rstd, Pm + P.cls_g[0], d_c1n, Wm + W.c1n, d_c1, Gp + P.cls_g[0],
+                 Gp + P.cls_be[0], d.R, C, PETR_LN_RELU, 0, s));
+      g = lin_wgrad(d_c1, C, Wm + W.outs, C, Gp + P.cls_w[0], Gp + P.cls_b[0], d.R, C, C);
+      RUN(petr_gemm(&g, s));
+      g = lin_dgrad(d_c1, Pm + P.cls_w[0], Wm + W.d_outs, d.R, C, C);
+      g.flags = PETR_GEMM_ACCUMULATE;
+      RUN(petr_gemm(&g, s));
+      // ---- post_norm over all levels -> d_xs[l] ----
+      RUN(ln_bwd(Wm + W.xs, Wm + W.mean_p, Wm + W.rstd_p, Pm + P.post_g, Wm + W.d_outs, nullptr, Wm + W.d_xs, Gp + P.post_g,
+                 Gp + P.post_b, d.R, C, 0, 0, s));
+    } else if (stage <= d.NL) {
+      const int l = d.NL - stage;
+      const LayerP& lp = P.lay[l];
+      const LayerW& lw = W.lay[l];
+      const float* x_in = l == 0 ? Wm + W.x0 : Wm + W.xs + (long)(l - 1) * d.BQ * C;
+      const float* G = Wm + W.d_xs + (long)l * d.BQ * C;     // d(x3_l): post-norm path (+ layer l+1's input grad)
+      // LN2 / FFN
+      float* d_z2 = Wm + W.ga;
+      RUN(ln_bwd(Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, Pm + lp.n_g[2], G, nullptr, d_z2, Gp + lp.n_g[2], Gp + lp.n_b[2],
+                 d.BQ, C, 0, 0, s));
+      petr_gemm_args g = lin_wgrad(d_z2, C, Wm + lw.hff, d.F, Gp + lp.f2_w, Gp + lp.f2_b, d.BQ, C, d.F);
+      RUN(petr_gemm(&g, s));
+      float* d_h = Wm + W.gb;                                   // [BQ, F]
+      g = lin_dgrad(d_z2, Pm + lp.f2_w, d_h, d.BQ, C, d.F);
+      g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + lw.hff; g.ldr = d.F;
+      RUN(petr_gemm(&g, s));
+      g = lin_wgrad(d_h, d.F, Wm + lw.x2, C, Gp + lp.f1_w, Gp + lp.f1_b, d.BQ, d.F, C);
+      RUN(petr_gemm(&g, s));
+      float* d_x2 = Wm + W.gc;
+      g = lin_dgrad(d_h, Pm + lp.f1_w, d_x2, d.BQ, d.F, C);
+      g.r = d_z2; g.ldr = C;                                    // + identity path
+      RUN(petr_gemm(&g, s));
+      // LN1 / cross-attention
+      float* d_z1 = Wm + W.ga;
+      RUN(ln_bwd(Wm + lw.z1, Wm + lw.mean1, Wm + lw.rstd1, Pm + lp.n_g[1], d_x2, nullptr, d_z1, Gp + lp.n_g[1],
+                 Gp + lp.n_b[1], d.BQ, C, 0, 0, s));
+      g = lin_wgrad(d_z1, C, Wm + lw.ao_c, C, Gp + lp.ca_out_w, Gp + lp.ca_out_b, d.BQ, C, C);
+      RUN(petr_gemm(&g, s));
+      float* d_ao = Wm + W.gb;
+      g = lin_dgrad(d_z1, Pm + lp.ca_out_w, d_ao, d.BQ, C, C);
+      RUN(petr_gemm(&g, s));
+      float* d_qc = Wm + W.d_qc + (long)l * d.BQ * C;
+      RUN(mha_b(Wm + lw.qc, (long)d.Q * C, C, Wm + W.k_all + (long)l * d.L * C, (long)d.NL * d.L * C, C,
+                Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, d_ao, Wm + lw.lse_c, kpm, d_qc,
+                Wm + W.dk_all + (long)l * d.L * C, Wm + W.dv_all + (long)l * d.L * C, d, (int)d.L, mws, W.mha_ws_bytes, s));
+      // q projection of the cross-attention (rows 0..C of in_proj): weight grads live in the final block
+      g = lin_wgrad(d_qc, C, Wm + lw.xe1, C, Gp + lp.ca_in_w, Gp + lp.ca_in_b, d.BQ, C, C);
+      RUN(petr_gemm(&g, s));
+      float* d_x1 = Wm + W.gc;
+      g = lin_dgrad(d_qc, Pm + lp.ca_in_w, d_x1, d.BQ, C, C);
+      g.r = d_z1; g.ldr = C;
+      RUN(petr_gemm(&g, s));
+      // LN0 / self-attention
+      float* d_z0 = Wm + W.ga;
+      RUN(ln_bwd(Wm + lw.z0, Wm + lw.mean0, Wm + lw.rstd0, Pm + lp.n_g[0], d_x1, nullptr, d_z0, Gp + lp.n_g[0],
+                 Gp + lp.n_b[0], d.BQ, C, 0, 0, s));
+      g = lin_wgrad(d_z0, C, Wm + lw.ao_s, C, Gp + lp.sa_out_w, Gp + lp.sa_out_b, d.BQ, C, C);
+      RUN(petr_gemm(&g, s));
+      float* d_ao_s = Wm + W.gb;
+      g = lin_dgrad(d_z0, Pm + lp.sa_out_w, d_ao_s, d.BQ, C, C);
+      RUN(petr_gemm(&g, s));
+      float* d_qkv = Wm + W.d_qkv + (long)l * d.BQ * 3 * C;
+      RUN(mha_b(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
+                Wm + lw.ao_s, d_ao_s, Wm + lw.lse_s, nullptr, d_qkv, d_qkv + C, d_qkv + 2 * C, d, d.Q, mws, W.mha_ws_bytes, s));
+      // in_proj: q,k rows see x + query_pos, v rows see x
+      g = lin_wgrad(d_qkv, 3 * C, Wm + lw.xe_in, C, Gp + lp.sa_in_w, Gp + lp.sa_in_b, d.BQ, 2 * C, C);
+      RUN(petr_gemm(&g, s));
+      g = lin_wgrad(d_qkv + 2 * C, 3 * C, x_in, C, Gp + lp.sa_in_w + (long)2 * C * C, Gp + lp.sa_in_b + 2 * C, d.BQ, C, C);
+      RUN(petr_gemm(&g, s));
+      if (l > 0) {
+        // d(x_in) = d_z0 (identity) + d_qkv @ W_in, added to the post-norm gradient of level l-1
+        float* dst = Wm + W.d_xs + (long)(l - 1) * d.BQ * C;
+        RUN(petr_axpy(dst, d_z0, 1.f, d.BQ * C, s));
+        g = lin_dgrad(d_qkv, Pm + lp.sa_in_w, dst, d.BQ, 3 * C, C);
+        g.flags = PETR_GEMM_ACCUMULATE;
+        RUN(petr_gemm(&g, s));
+      }
+    } else {
+      // ================= final stage =================
+      // query_pos gradient: sum over layers and batch of d(q-proj inputs) (deferred from the layers)
+      petr_gemm_args g = gemm0();
+      g.a = Wm + W.d_qc; g.lda = C; g.a_kcontig = 1; g.a_bs0 = d.BQ * C;
+      g.b = Pm + P.lay[0].ca_in_w; g.ldb = C; g.b_kcontig = 0; g.b_bs0 = P.ca_in_stride;
+      g.c = Wm + W.d_e_slab; g.ldc = C; g.c_bs0 = d.BQ * C;
+      g.M = (int)d.BQ; g.N = C; g.K = C; g.nb0 = d.NL;
+      RUN(petr_gemm(&g, s));
+      for (int l = 0; l < d.NL; ++l) {   // self-attention q,k rows (layer blocks are not uniformly strided by design)
+        g = lin_dgrad(Wm + W.d_qkv + (long)l * d.BQ * 3 * C, Pm + P.lay[l].sa_in_w, Wm + W.d_e_slab + (long)l * d.BQ * C,
+                      d.BQ, 2 * C, C);
+        g.lda = 3 * C;
+        g.flags = PETR_GEMM_ACCUMULATE;
+        RUN(petr_gemm(&g, s));
+      }
+      RUN(petr_reduce_batch(Wm + W.d_e_slab, d.NL * d.B, d.Q, C, Wm + W.d_e, 0, s));
+      // query_embedding MLP + pos2posemb3d (petr_head.py:422-423)
+      g = lin_wgrad(Wm + W.d_e, C, Wm + W.qe_h, C, Gp + P.qe_w2, Gp + P.qe_b2, d.Q, C, C);
+      RUN(petr_gemm(&g, s));
+      g = lin_dgrad(Wm + W.d_e, Pm + P.qe_w2, Wm + W.d_qe_h, d.Q, C, C);
+      g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.qe_h; g.ldr = C;
+      RUN(petr_gemm(&g, s));
+      g = lin_wgrad(Wm + W.d_qe_h, C, Wm + W.posemb, C * 3 / 2, Gp + P.qe_w1, Gp + P.qe_b1, d.Q, C, C * 3 / 2);
+      RUN(petr_gemm(&g, s));
+      g = lin_dgrad(Wm + W.d_qe_h, Pm + P.qe_w1, Wm + W.d_posemb, d.Q, C, C * 3 / 2);
+      RUN(petr_gemm(&g, s));
+      RUN(petr_posemb3d_bwd(Pm + P.ref, io->dim_t, Wm + W.d_posemb, Wm + W.d_ref_tmp, d.Q, C / 2, s));
+      RUN(petr_axpy(Gp + P.ref, Wm + W.d_ref_tmp, 1.f, (long)d.Q * 3, s));
+
+      // K/V projections of all layers: k index = (batch, token) for the weights, (layer, channel) for the inputs
+      for (int kv = 0; kv < 2; ++kv) {
+        const float* dkv = Wm + (kv == 0 ? W.dk_all : W.dv_all);
+        const float* src = kv == 0 ? Wm + W.mempos : Wm + W.mem;
+        g = gemm0();      // dW_l[C,C] += sum_{b,t} dKV[b][l][t][o] * src[b][t][c]
+        g.a = dkv; g.lda = C; g.a_kcontig = 0; g.a_bs0 = d.L * C;
+        g.b = src; g.ldb = C; g.b_kcontig = 0;
+        g.c = Gp + P.lay[0].ca_in_w + (long)(kv + 1) * C * C; g.ldc = C; g.c_bs0 = P.ca_in_stride;
+        g.a_colsum = Gp + P.lay[0].ca_in_b + (kv + 1) * C; g.cs_bs0 = P.ca_in_stride;
+        g.M = C; g.N = C; g.K = (int)d.BL; g.nb0 = d.NL;
+        g.k_seg = (int)d.L; g.a_seg_stride = (long)d.NL * d.L * C; g.b_seg_stride = d.L * C;
+        g.flags = PETR_GEMM_ATOMIC;
+        g.split_k = 8;
+        RUN(petr_gemm(&g, s));
+        g = gemm0();      // d_src[b][t][c] = sum_{l,o} dKV[b][l][t][o] * W_l[o][c]
+        g.a = dkv; g.lda = C; g.a_kcontig = 1; g.a_bs0 = (long)d.NL * d.L * C;
+        g.b = Pm + P.lay[0].ca_in_w + (long)(kv + 1) * C * C; g.ldb = C; g.b_kcontig = 0;
+        g.c = Wm + (kv == 0 ? W.d_mempos : W.d_mem); g.ldc = C; g.c_bs0 = d.L * C;
+        g.M = (int)d.L; g.N = C; g.K = d.NL * C; g.nb0 = d.B;
+        g.k_seg = C; g.a_seg_stride = d.L * C; g.b_seg_stride = P.ca_in_stride;
+        RUN(petr_gemm(&g, s));
+      }
+      // d_mem = dV-path + d(mem+pos) ; d_pos = d(mem+pos)
+      RUN(petr_axpy(Wm + W.d_mem, Wm + W.d_mempos, 1.f, d.BL * C, s));
+      const float* d_pos = Wm + W.d_mempos;
+      const int V = d.B * d.N;
+      // position_encoder and adapt_pos3d (inputs carry no gradient)
+      for (int which = 0; which < 2; ++which) {
+        const long w1 = which == 0 ? P.pe_w1 : P.ad_w1, b1 = which == 0 ? P.pe_b1 : P.ad_b1;
+        const long w2 = which == 0 ? P.pe_w2 : P.ad_w2, b2 = which == 0 ? P.pe_b2 : P.ad_b2;
+        const float* hid = Wm + (which == 0 ? W.h1 : W.h2);
+        const float* feat = Wm + (which == 0 ? W.vol : W.sine);
+        const int Kin = which == 0 ? 3 * d.D : C * 3 / 2;
+        g = lin_wgrad(d_pos, C, hid, 4 * C, Gp + w2, Gp + b2, d.BL, C, 4 * C);
+        RUN(petr_gemm(&g, s));
+        g = lin_dgrad(d_pos, Pm + w2, Wm + W.d_hpe, d.BL, C, 4 * C);
+        g.flags = PETR_GEMM_RELU_MASK; g.r = hid; g.ldr = 4 * C;
+        RUN(petr_gemm(&g, s));
+        g = gemm0();      // dW1[4C, Kin] += sum_{view, hw} d_h[view*HW+hw][f] * feat[view][c][hw]
+        g.a = Wm + W.d_hpe; g.lda = 4 * C; g.a_kcontig = 0;
+        g.b = feat; g.ldb = d.HW; g.b_kcontig = 1;
+        g.c = Gp + w1; g.ldc = Kin; g.a_colsum = Gp + b1;
+        g.M = 4 * C; g.N = Kin; g.K = V * d.HW;
+        g.k_seg = d.HW; g.a_seg_stride = (long)d.HW * 4 * C; g.b_seg_stride = (long)Kin * d.HW;
+        g.flags = PETR_GEMM_ATOMIC; g.split_k = 8;
+        RUN(petr_gemm(&g, s));
+      }
+      // input_proj
+      g = gemm0();        // dW[C, Cin] += sum_{view,hw} d_mem[view*HW+hw][o] * x[view][ci][hw]
+      g.a = Wm + W.d_mem; g.lda = C; g.a_kcontig = 0;
+      g.b = io->feats; g.ldb = d.HW; g.b_kcontig = 1;
+      g.c = Gp + P.in_w; g.ldc = d.Cin; g.a_colsum = Gp + P.in_b;
+      g.M = C; g.N = d.Cin; g.K = V * d.HW;
+      g.k_seg = d.HW; g.a_seg_stride = (long)d.HW * C; g.b_seg_stride = (long)d.Cin * d.HW;
+      g.flags = PETR_GEMM_ATOMIC; g.split_k = 16;
+      RUN(petr_gemm(&g, s));
+      if (gr->d_feats) {
+        g = gemm0();      // d_x[view][ci][hw] = sum_o W[o][ci] * d_mem[view*HW+hw][o]
+        g.a = Pm + P.in_w; g.lda = d.Cin; g.a_kcontig = 0;
+        g.b = Wm + W.d_mem; g.ldb = C; g.b_kcontig = 1; g.b_bs0 = (long)d.HW * C;
+        g.c = gr->d_feats; g.ldc = d.HW; g.c_bs0 = (long)d.Cin * d.HW;
+        g.M = d.Cin; g.N = d.HW; g.K = C; g.nb0 = V;
+        RUN(petr_gemm(&g, s));
+      }
+    }
+  }
+  return PETR_OK;
+}

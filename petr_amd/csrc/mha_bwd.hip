@@ -280,8 +280,10 @@ extern "C" int petr_mha_bwd(const petr_mha_bwd_args* ap, void* stream) {
   PETR_LAUNCH_CHECK("mha_delta");
   const long total = (long)p.nkb * a.B * a.H * p.q_splits;
   PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_bwd: grid too large");
+  const int rec = petr_prof_open_record(PETR_PROF_MHA_BWD + 16 * (a.L > a.Q ? 1 : 0), stream);
   if (a.kpm) hipLaunchKernelGGL(mha_bwd_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(mha_bwd_kernel<false>, dim3((unsigned)total), dim3(256), 0, s, p);
+  petr_prof_close_record(rec, stream);
   PETR_LAUNCH_CHECK("mha_bwd");
   return PETR_OK;
 }

@@ -281,8 +281,10 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)p.nqb * a.B * a.H * ns;
   PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_fwd: grid too large");
+  const int rec = petr_prof_open_record(PETR_PROF_MHA_FWD + 16 * (a.L > a.Q ? 1 : 0), stream);
   if (a.kpm) hipLaunchKernelGGL(mha_fwd_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(mha_fwd_kernel<false>, dim3((unsigned)total), dim3(256), 0, s, p);
+  petr_prof_close_record(rec, stream);
   PETR_LAUNCH_CHECK("mha_fwd");
   if (ns > 1) {
     const long n = (long)a.B * a.H * a.Q * 8;

@@ -157,8 +157,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(petr_layernorm_bwd_a
     float sg = 0.f, sb = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) { sg += red[0][w][cidx]; sb += red[1][w][cidx]; }
-    ws[(size_t)blockIdx.x * 2 * a.C + cidx] = sg;
-    ws[(size_t)blockIdx.x * 2 * a.C + a.C + cidx] = sb;
+    if (ws) {
+      ws[(size_t)blockIdx.x * 2 * a.C + cidx] = sg;
+      ws[(size_t)blockIdx.x * 2 * a.C + a.C + cidx] = sb;
+    } else {
+      if (a.dgamma) atomicAdd(a.dgamma + cidx, sg);
+      if (a.dbeta) atomicAdd(a.dbeta + cidx, sb);
+    }
   }
 }
 
@@ -319,16 +324,17 @@ extern "C" size_t petr_layernorm_bwd_workspace_bytes(int M, int C) {
 }
 
 extern "C" int petr_layernorm_bwd(const petr_layernorm_bwd_args* a, void* stream) {
-  PETR_CHECK(a && a->z && a->mean && a->rstd && a->gamma && a->dy && a->dz && a->ws, PETR_ERR_INVALID,
+  PETR_CHECK(a && a->z && a->mean && a->rstd && a->gamma && a->dy && a->dz, PETR_ERR_INVALID,
              "layernorm_bwd: null pointer");
   PETR_CHECK(a->M > 0 && a->C > 0 && (a->C & 3) == 0 && a->C <= 256 * LN_MAXV, PETR_ERR_UNSUPPORTED,
              "layernorm_bwd: C=%d unsupported", a->C);
   PETR_CHECK(!(a->flags & PETR_LN_RELU) || a->y, PETR_ERR_INVALID, "layernorm_bwd: ReLU flag needs y");
-  const int nblocks = (int)((cdiv(a->M, 4) < LNB_BLOCKS) ? cdiv(a->M, 4) : LNB_BLOCKS);
+  int nblocks = (int)((cdiv(a->M, 4) < LNB_BLOCKS) ? cdiv(a->M, 4) : LNB_BLOCKS);
+  if (!a->ws && nblocks > 64) nblocks = 64;   // atomics form: fewer, longer blocks -> fewer atomic adds
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblocks), dim3(256), 0, s, *a, nblocks);
   PETR_LAUNCH_CHECK("layernorm_bwd");
-  if (a->dgamma || a->dbeta) {
+  if (a->ws && (a->dgamma || a->dbeta)) {
     hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * a->C, 256)), dim3(256), 0, s,
                        (const float*)a->ws, nblocks, a->C, a->dgamma, a->dbeta);
     PETR_LAUNCH_CHECK("layernorm_bwd_reduce");

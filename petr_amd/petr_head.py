@@ -1,0 +1,418 @@
+"""PETRHead — host mirror of reference models/dense_heads/petr_head.py:47-468 (forward path).
+
+Same constructor arguments, sub-module / parameter names (state_dict keys load reference ``.pth``
+heads, including the legacy-key remap of ``_load_from_state_dict`` :336-364) and the same
+``forward(mlvl_feats, img_metas) -> dict`` contract.  The arithmetic is ONE call into libpetr_hip.so
+(``petr_head_fwd``; ``petr_head_bwd`` for the gradient) — there is no torch-operator fallback.
+
+Host-side work kept in Python because the reference does it on the host too:
+  * ``np.linalg.inv(lidar2img)`` in float64 per view (petr_head.py:308-315), uploaded as fp32;
+  * the padding mask, in closed form instead of ``ones -> zero-fill -> F.interpolate`` (:383-394):
+    nearest-neighbour source index = floor(dst * in/out), so
+    ``mask[i,j] = (floor(i*pad_h/H) >= img_h) or (floor(j*pad_w/W) >= img_w)``.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _C, ops
+from .positional_encoding import sine_dim_t
+from .registry import build_positional_encoding, build_transformer, register
+
+
+def pos2posemb3d(pos, num_pos_feats=128, temperature=10000):
+    """reference petr_head.py:31-43 through the ``petr_posemb3d_fwd`` kernel ([n,3] -> [n,384])."""
+    dim_t = sine_dim_t(num_pos_feats, temperature).to(pos.device)
+    shp = pos.shape[:-1]
+    return ops.posemb3d(pos.reshape(-1, 3).contiguous(), dim_t).view(*shp, 3 * num_pos_feats)
+
+
+def padding_mask_closed_form(img_metas, num_cams, feat_hw):
+    """uint8 [B,N,H,W] equal to the reference's interpolated mask (petr_head.py:383-394)."""
+    H, W = feat_hw
+    pad_h, pad_w, _ = img_metas[0]['pad_shape'][0]
+    # torch nearest: src = min(int(floorf(dst * scale)), in - 1), scale = float(in) / out  (float32)
+    sh, sw = np.float32(pad_h) / np.float32(H), np.float32(pad_w) / np.float32(W)
+    src_h = np.minimum(np.floor(np.arange(H, dtype=np.float32) * sh).astype(np.int64), pad_h - 1)
+    src_w = np.minimum(np.floor(np.arange(W, dtype=np.float32) * sw).astype(np.int64), pad_w - 1)
+    B = len(img_metas)
+    mask = np.zeros((B, num_cams, H, W), dtype=np.uint8)
+    for b in range(B):
+        for n in range(num_cams):
+            img_h, img_w, _ = img_metas[b]['img_shape'][n]
+            mask[b, n] = (src_h[:, None] >= img_h) | (src_w[None, :] >= img_w)
+    return mask
+
+
+def depth_bins(depth_num, depth_start, position_range, LID):
+    """reference petr_head.py:293-301 with the same torch ops (host, once)."""
+    index = torch.arange(start=0, end=depth_num, step=1).float()
+    if LID:
+        index_1 = index + 1
+        bin_size = (position_range[3] - depth_start) / (depth_num * (1 + depth_num))
+        return depth_start + bin_size * index * index_1
+    bin_size = (position_range[3] - depth_start) / depth_num
+    return depth_start + bin_size * index
+
+
+class _HeadFn(torch.autograd.Function):
+    """autograd node around petr_head_fwd / petr_head_bwd.  Parameter gradients are written by the
+    kernels straight into the head's flat gradient buffer (each ``p.grad`` is a view of it), the
+    return value only carries d(feats)."""
+
+    @staticmethod
+    def forward(ctx, head, feats, anchor, run):
+        ctx.head, ctx.run = head, run
+        ctx.feats_requires_grad = feats.requires_grad
+        cls, bbox = head._launch_forward(run, feats)
+        return cls, bbox
+
+    @staticmethod
+    def backward(ctx, d_cls, d_bbox):
+        head, run = ctx.head, ctx.run
+        d_feats = head._launch_backward(run, d_cls.contiguous(), d_bbox.contiguous(), ctx.feats_requires_grad)
+        return None, d_feats, None, None
+
+
+class _Run:
+    """Everything one forward needs to keep alive until its backward: workspace, outputs, host inputs."""
+    __slots__ = ('cfg', 'io', 'ws', 'feats', 'img2lidar', 'mask', 'cls', 'bbox', 'key', 'time_div')
+
+
+@register('HEADS')
+class PETRHead(nn.Module):
+    _version = 2
+
+    def __init__(self, num_classes, in_channels, num_query=100, num_reg_fcs=2, transformer=None,
+                 sync_cls_avg_factor=False,
+                 positional_encoding=dict(type='SinePositionalEncoding', num_feats=128, normalize=True),
+                 code_weights=None, bbox_coder=None, loss_cls=None, loss_bbox=None, loss_iou=None, train_cfg=None,
+                 test_cfg=dict(max_per_img=100), with_position=True, with_multiview=False, depth_step=0.8, depth_num=64,
+                 LID=False, depth_start=1, position_range=[-65, -65, -8.0, 65, 65, 8.0], init_cfg=None,
+                 normedlinear=False, **kwargs):
+        super().__init__()
+        self.code_size = kwargs.get('code_size', 10)
+        cw = code_weights if code_weights is not None else [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2]
+        cw = list(cw)[:self.code_size]
+        self.sync_cls_avg_factor = sync_cls_avg_factor
+        self.num_query, self.num_classes, self.in_channels = num_query, num_classes, in_channels
+        self.num_reg_fcs = num_reg_fcs
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.loss_cfg = dict(loss_cls=loss_cls, loss_bbox=loss_bbox, loss_iou=loss_iou)
+        self.fp16_enabled = False
+        self.embed_dims = 256                       # petr_head.py:175
+        self.depth_step, self.depth_num = depth_step, depth_num
+        self.position_dim = 3 * depth_num
+        self.position_range = list(position_range)
+        self.LID, self.depth_start = LID, depth_start
+        self.position_level = 0
+        self.with_position, self.with_multiview = with_position, with_multiview
+        assert 'num_feats' in positional_encoding
+        num_feats = positional_encoding['num_feats']
+        assert num_feats * 2 == self.embed_dims, \
+            f'embed_dims should be exactly 2 times of num_feats. Found {self.embed_dims} and {num_feats}.'
+        assert num_reg_fcs == 2, 'the fused branches kernel chain is built for num_reg_fcs=2 (every reference config)'
+        assert not normedlinear, 'normedlinear=True is not used by any reference config'
+        assert with_position and with_multiview, \
+            'the fused executor implements the with_position=with_multiview=True path of the BASELINE configs'
+        self.num_pred = 6                           # petr_head.py:192
+        self.normedlinear = normedlinear
+        use_sigmoid = True if loss_cls is None else loss_cls.get('use_sigmoid', False)
+        self.cls_out_channels = num_classes if use_sigmoid else num_classes + 1
+        self._use_sigmoid = use_sigmoid
+        # construction order follows the reference (:208-215) so that a seeded init draws the same numbers
+        self.positional_encoding = build_positional_encoding(positional_encoding)
+        self.transformer = build_transformer(transformer)
+        self.code_weights = nn.Parameter(torch.tensor(cw, requires_grad=False), requires_grad=False)
+        self.pc_range = list(bbox_coder['pc_range']) if bbox_coder is not None else [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+        self.bbox_coder_cfg = bbox_coder
+        self._init_layers()
+        dec = self.transformer.decoder
+        self._nl = dec.num_layers
+        self._ffn = dec.layers[0].ffns[0].feedforward_channels
+        self._heads = dec.layers[0].attentions[0].num_heads
+        self.register_buffer('_depth', depth_bins(depth_num, depth_start, self.position_range, LID), persistent=False)
+        self.register_buffer('_dim_t', sine_dim_t(num_feats, positional_encoding.get('temperature', 10000)),
+                             persistent=False)
+        self._flat = None
+        self._flat_grad = None
+        self._layout = None
+        self._runs = {}
+        self._free_ws = {}
+        self._anchor = None
+        self._stream_events = None
+
+    # ------------------------------------------------------------------ construction
+    def _init_layers(self):
+        """reference petr_head.py:217-274."""
+        E = self.embed_dims
+        self.input_proj = nn.Conv2d(self.in_channels, E, kernel_size=1)
+        cls_branch = []
+        for _ in range(self.num_reg_fcs):
+            cls_branch += [nn.Linear(E, E), nn.LayerNorm(E), nn.ReLU(inplace=True)]
+        cls_branch.append(nn.Linear(E, self.cls_out_channels))
+        fc_cls = nn.Sequential(*cls_branch)
+        reg_branch = []
+        for _ in range(self.num_reg_fcs):
+            reg_branch += [nn.Linear(E, E), nn.ReLU()]
+        reg_branch.append(nn.Linear(E, self.code_size))
+        reg_branch = nn.Sequential(*reg_branch)
+        # the SAME module in all num_pred slots (petr_head.py:244-247): shared weights, aliased keys
+        self.cls_branches = nn.ModuleList([fc_cls for _ in range(self.num_pred)])
+        self.reg_branches = nn.ModuleList([reg_branch for _ in range(self.num_pred)])
+        self.adapt_pos3d = nn.Sequential(nn.Conv2d(E * 3 // 2, E * 4, 1), nn.ReLU(), nn.Conv2d(E * 4, E, 1))
+        self.position_encoder = nn.Sequential(nn.Conv2d(self.position_dim, E * 4, 1), nn.ReLU(), nn.Conv2d(E * 4, E, 1))
+        self.reference_points = nn.Embedding(self.num_query, 3)
+        self.query_embedding = nn.Sequential(nn.Linear(E * 3 // 2, E), nn.ReLU(), nn.Linear(E, E))
+
+    def init_weights(self):
+        """reference petr_head.py:276-284."""
+        self.transformer.init_weights()
+        nn.init.uniform_(self.reference_points.weight.data, 0, 1)
+        if self._use_sigmoid:
+            bias_init = float(-np.log((1 - 0.01) / 0.01))   # mmcv bias_init_with_prob(0.01)
+            for m in self.cls_branches:
+                nn.init.constant_(m[-1].bias, bias_init)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        """legacy DETR key names -> current ones (reference petr_head.py:345-359)."""
+        version = local_metadata.get('version', None)
+        if (version is None or version < 2) and self.__class__ is PETRHead:
+            convert_dict = {'.self_attn.': '.attentions.0.', '.multihead_attn.': '.attentions.1.',
+                            '.decoder.norm.': '.decoder.post_norm.'}
+            for k in list(state_dict.keys()):
+                for ori_key, convert_key in convert_dict.items():
+                    if ori_key in k:
+                        state_dict[k.replace(ori_key, convert_key)] = state_dict[k]
+                        del state_dict[k]
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _base_config(self):
+        cfg = _C.HeadConfig()
+        cfg.B, cfg.N, cfg.C_in, cfg.H, cfg.W = 1, 1, self.in_channels, 2, 2
+        cfg.num_query, cfg.num_layers, cfg.num_heads = self.num_query, self._nl, self._heads
+        cfg.embed_dims, cfg.ffn_dims, cfg.depth_num = self.embed_dims, self._ffn, self.depth_num
+        cfg.num_classes, cfg.code_size = self.cls_out_channels, self.code_size
+        cfg.v2 = cfg.with_fpe = cfg.with_time = cfg.with_multi = 0
+        cfg.shared_branches, cfg.LID, cfg.depth_start = 1, int(self.LID), float(self.depth_start)
+        cfg.position_range = (C.c_float * 6)(*[float(v) for v in self.position_range])
+        cfg.pc_range = (C.c_float * 6)(*[float(v) for v in self.pc_range])
+        cfg.pad_h = cfg.pad_w = 0.0
+        cfg.has_mask, cfg.training = 0, 1
+        return cfg
+
+    def _flatten(self):
+        """(Re)build the flat fp32 buffer on the parameters' device and alias every Parameter onto it."""
+        L = _C.lib()
+        lay = _C.HeadLayout()
+        _C.check(L.petr_head_layout(C.byref(self._base_config()), C.byref(lay)), 'petr_head_layout')
+        sd = dict(self.named_parameters(remove_duplicate=False))
+        dev = self.input_proj.weight.device
+        flat = torch.zeros(lay.total, dtype=torch.float32, device=dev)
+        grad = torch.zeros(lay.total, dtype=torch.float32, device=dev)
+        self._grad_views = []
+        seen = {}
+        for i in range(lay.count):
+            name = lay.name[i].value.decode()
+            shape = tuple(lay.shape[i][j] for j in range(lay.ndim[i]))
+            p = sd.get(name)
+            if p is None:
+                raise _C.PetrHipError(f'layout names a tensor the module does not have: {name}')
+            if tuple(p.shape) != shape:
+                raise _C.PetrHipError(f'{name}: module shape {tuple(p.shape)} != layout shape {shape}')
+            if id(p) in seen:
+                assert seen[id(p)] == lay.offset[i], f'aliased tensor {name} must share one slot'
+                continue
+            off, n = lay.offset[i], p.numel()
+            seen[id(p)] = off
+            view = flat[off:off + n].view(shape)
+            view.copy_(p.data)
+            p.data = view
+            self._grad_views.append((p, grad[off:off + n].view(shape)))
+        missing = [k for k, p in sd.items() if id(p) not in seen]
+        if missing:
+            raise _C.PetrHipError(f'parameters without a slot in the flat layout: {missing}')
+        self._flat, self._flat_grad, self._layout = flat, grad, lay
+        self._runs.clear()
+        self._free_ws.clear()
+        self._anchor = torch.zeros((), device=dev, requires_grad=True)
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._flat = None          # storage moved or changed dtype: re-flatten lazily
+        return out
+
+    def _ensure_flat(self):
+        w = self.input_proj.weight
+        if (self._flat is None or w.device != self._flat.device
+                or w.data_ptr() < self._flat.data_ptr()
+                or w.data_ptr() >= self._flat.data_ptr() + self._flat.numel() * 4):
+            if w.dtype != torch.float32:
+                raise _C.PetrHipError('PETRHead runs fp32 parameters (the reference head is fp32: fp16_enabled=False)')
+            self._flatten()
+
+    def flat_parameters(self):
+        self._ensure_flat()
+        return self._flat
+
+    def flat_gradients(self):
+        """The single contiguous gradient buffer (every ``p.grad`` is a view of it)."""
+        self._ensure_flat()
+        self._attach_grads(zero_if_detached=False)
+        return self._flat_grad
+
+    def gradient_buckets(self):
+        """[(begin, end)] flat ranges that become final after each backward stage, in completion order."""
+        self._ensure_flat()
+        L = _C.lib()
+        cfg = self._base_config()
+        out = []
+        for s in range(L.petr_head_bwd_num_stages(C.byref(cfg))):
+            b, e = C.c_long(), C.c_long()
+            _C.check(L.petr_head_bwd_stage_range(C.byref(cfg), s, C.byref(b), C.byref(e)), 'petr_head_bwd_stage_range')
+            out.append((b.value, e.value))
+        return out
+
+    def _attach_grads(self, zero_if_detached=True):
+        sentinel = self._grad_views[0]
+        if sentinel[0].grad is None or sentinel[0].grad.data_ptr() != sentinel[1].data_ptr():
+            if zero_if_detached:
+                self._flat_grad.zero_()
+            for p, gv in self._grad_views:
+                if p.requires_grad:
+                    p.grad = gv
+
+    # ------------------------------------------------------------------ host-side input preparation
+    def _prepare(self, feats, img_metas):
+        B, N, Cin, H, W = feats.shape
+        assert Cin == self.in_channels, f'expected {self.in_channels} input channels, got {Cin}'
+        assert len(img_metas) == B
+        pad_h, pad_w, _ = img_metas[0]['pad_shape'][0]
+        mask_np = padding_mask_closed_form(img_metas, N, (H, W))
+        has_mask = bool(mask_np.any())
+        key = (B, N, H, W, int(pad_h), int(pad_w), has_mask, feats.device)
+        L = _C.lib()
+        if key not in self._runs:
+            cfg = self._base_config()
+            cfg.B, cfg.N, cfg.H, cfg.W = B, N, H, W
+            cfg.pad_h, cfg.pad_w, cfg.has_mask = float(pad_h), float(pad_w), int(has_mask)
+            ws_bytes = L.petr_head_workspace_bytes(C.byref(cfg))
+            if ws_bytes == 0:
+                raise _C.PetrHipError(f'petr_head_workspace_bytes: {L.petr_last_error().decode()}')
+            self._runs[key] = (cfg, ws_bytes)
+            self._free_ws[key] = []
+        cfg, ws_bytes = self._runs[key]
+        run = _Run()
+        run.key, run.cfg, run.time_div = key, cfg, 0.0
+        pool = self._free_ws[key]
+        run.ws = pool.pop() if pool else torch.empty(ws_bytes // 4, dtype=torch.float32, device=feats.device)
+        # img2lidar: float64 inverse per view on the host, as the reference (petr_head.py:308-315)
+        l2i = np.asarray([[np.asarray(m) for m in meta['lidar2img']] for meta in img_metas], dtype=np.float64)
+        i2l = np.linalg.inv(l2i).astype(np.float32).reshape(B * N, 16)
+        run.img2lidar = torch.from_numpy(i2l).to(feats.device, non_blocking=True)
+        run.mask = torch.from_numpy(mask_np).to(feats.device, non_blocking=True) if has_mask else None
+        return run
+
+    def _time_div(self, img_metas, batch_size):
+        return 0.0
+
+    def _launch_forward(self, run, feats):
+        L = _C.lib()
+        B, N = run.cfg.B, run.cfg.N
+        run.feats = feats.contiguous()
+        run.cls = torch.empty((self._nl, B, self.num_query, self.cls_out_channels), dtype=torch.float32, device=feats.device)
+        run.bbox = torch.empty((self._nl, B, self.num_query, self.code_size), dtype=torch.float32, device=feats.device)
+        io = _C.HeadIO()
+        io.params = self._flat.data_ptr()
+        io.feats = run.feats.data_ptr()
+        io.img2lidar = run.img2lidar.data_ptr()
+        io.depth = self._depth.data_ptr()
+        io.dim_t = self._dim_t.data_ptr()
+        io.mask = run.mask.data_ptr() if run.mask is not None else None
+        io.time_div = float(run.time_div)
+        io.all_cls_scores = run.cls.data_ptr()
+        io.all_bbox_preds = run.bbox.data_ptr()
+        io.ws = run.ws.data_ptr()
+        io.ws_bytes = run.ws.numel() * 4
+        run.io = io
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _C.check(L.petr_head_fwd(C.byref(run.cfg), C.byref(io), stream), 'petr_head_fwd')
+        return run.cls, run.bbox
+
+    def _launch_backward(self, run, d_cls, d_bbox, want_dfeats, stage_hook=None):
+        L = _C.lib()
+        self._attach_grads()
+        g = _C.HeadGrads()
+        g.d_cls, g.d_bbox = d_cls.data_ptr(), d_bbox.data_ptr()
+        g.d_params = self._flat_grad.data_ptr()
+        d_feats = torch.empty_like(run.feats) if want_dfeats else None
+        g.d_feats = d_feats.data_ptr() if want_dfeats else None
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        n_stages = L.petr_head_bwd_num_stages(C.byref(run.cfg))
+        hook = stage_hook or getattr(self, '_stage_hook', None)
+        if hook is None:
+            _C.check(L.petr_head_bwd(C.byref(run.cfg), C.byref(run.io), C.byref(g), 0, n_stages, stream), 'petr_head_bwd')
+        else:   # data-parallel: hand each finished gradient bucket to the all-reducer while backward continues
+            for s in range(n_stages):
+                _C.check(L.petr_head_bwd(C.byref(run.cfg), C.byref(run.io), C.byref(g), s, s + 1, stream), 'petr_head_bwd')
+                hook(s)
+        self._free_ws[run.key].append(run.ws)
+        return d_feats
+
+    # ------------------------------------------------------------------ the hot path
+    def forward(self, mlvl_feats, img_metas):
+        """reference petr_head.py:366-468.  mlvl_feats[0]: [B,N,C_in,H,W] fp32 CUDA; returns the same dict."""
+        x = mlvl_feats[self.position_level]
+        if not x.is_cuda:
+            raise _C.PetrHipError('PETRHead (petr_amd) runs on the GPU only; there is no CPU fallback')
+        if x.dtype != torch.float32:
+            raise _C.PetrHipError('PETRHead expects fp32 features (the reference forces fp32: petr3d.py:101)')
+        self._ensure_flat()
+        run = self._prepare(x, img_metas)
+        run.time_div = self._time_div(img_metas, x.shape[0])
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p, _ in self._grad_views)):
+            cls, bbox = _HeadFn.apply(self, x, self._anchor, run)
+        else:
+            cls, bbox = self._launch_forward(run, x)
+            self._free_ws[run.key].append(run.ws)     # stream-ordered reuse: the next forward runs after this one
+        self._last_run = run
+        return {'all_cls_scores': cls, 'all_bbox_preds': bbox, 'enc_cls_scores': None, 'enc_bbox_preds': None}
+
+    def workspace_view(self, name, run=None):
+        """Named view into the forward workspace of the most recent call (tests / per-module API)."""
+        run = run or self._last_run
+        L = _C.lib()
+        off, n = C.c_long(), C.c_long()
+        _C.check(L.petr_head_ws_view(C.byref(run.cfg), name.encode(), C.byref(off), C.byref(n)), 'petr_head_ws_view')
+        return run.ws[off.value:off.value + n.value]
+
+    def position_embeding(self, img_feats, img_metas, masks=None):
+        """reference petr_head.py:286-334: returns (coords_position_embeding [B,N,256,H,W], coords_mask)."""
+        B, N, _, H, W = img_feats[self.position_level].shape
+        dev = img_feats[self.position_level].device
+        pad_h, pad_w, _ = img_metas[0]['pad_shape'][0]
+        l2i = np.asarray([[np.asarray(m) for m in meta['lidar2img']] for meta in img_metas], dtype=np.float64)
+        i2l = torch.from_numpy(np.linalg.inv(l2i).astype(np.float32).reshape(B * N, 16)).to(dev)
+        vol, cmask = ops.coords3d(i2l, self._depth.to(dev), B, N, H, W, pad_h, pad_w, self.position_range,
+                                  want_mask=True)
+        if masks is not None:
+            cmask = masks | cmask
+        with torch.no_grad():
+            pe0, pe2 = self.position_encoder[0], self.position_encoder[2]
+            hid = ops.conv1x1(vol.view(B * N, -1, H * W), pe0.weight.view(pe0.out_channels, -1), pe0.bias, relu=True)
+            out = ops.linear(hid, pe2.weight.view(pe2.out_channels, -1), pe2.bias)
+        pe = out.view(B, N, H, W, self.embed_dims).permute(0, 1, 4, 2, 3).contiguous()
+        return pe, cmask
+
+    # ------------------------------------------------------------------ §8(f) "next" rows
+    def loss(self, *args, **kwargs):
+        raise NotImplementedError('PETRHead.loss (Hungarian matching + focal/L1) is SURVEY §8(f) rank 1: not built yet')
+
+    def get_bboxes(self, *args, **kwargs):
+        raise NotImplementedError('PETRHead.get_bboxes (NMS-free decode) is SURVEY §8(f) rank 2: not built yet')

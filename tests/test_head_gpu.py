@@ -1,0 +1,167 @@
+"""GPU parity of the whole hot path (petr_amd.PETRHead -> petr_head_fwd / petr_head_bwd) against the
+CPU oracle and the golden vectors captured from the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import petr_oracle as O  # noqa: E402  (checker only)
+
+REL = 1e-4     # north_star: decoder outputs within 1e-4 rel of the reference (fp32 config)
+
+
+@pytest.fixture(scope='module')
+def pa():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import petr_amd
+    return petr_amd
+
+
+def rel(got, want):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    return ((got - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
+
+
+def make_pair(pa, oracle, **cfg_kw):
+    head = pa.build_head(pa.petr_head_cfg(**cfg_kw))
+    head.load_state_dict(oracle.state_dict())
+    return head.cuda().eval()
+
+
+def metas_from(fx):
+    N = fx['lidar2img'].shape[0]
+    ph, pw = [int(v) for v in fx['pad_hw']]
+    ih, iw = [int(v) for v in fx['img_hw']]
+    return [{'pad_shape': [(ph, pw, 3)] * N, 'img_shape': [(ih, iw, 3)] * N, 'lidar2img': list(fx['lidar2img'])}]
+
+
+@pytest.mark.parametrize('name', ['head_toy', 'head_toy_masked'])
+def test_head_golden(pa, golden_dir, name):
+    """fixture = outputs of the REFERENCE PETRHead.forward (oracle/make_golden.py)."""
+    fx = np.load(os.path.join(golden_dir, name + '.npz'))
+    oracle = O.seeded_head(2, 1234, num_query=16)
+    wsum = sum(v.double().abs().sum().item() for v in oracle.state_dict().values())
+    if abs(wsum - float(fx['weight_abs_sum'])) > 1e-9 * wsum:
+        pytest.skip('torch RNG stream differs from the build container')
+    head = make_pair(pa, oracle, num_query=16)
+    with torch.no_grad():
+        out = head([torch.from_numpy(fx['feats']).cuda()], metas_from(fx))
+    assert out['all_cls_scores'].shape == (6, 1, 16, 10) and out['all_bbox_preds'].shape == (6, 1, 16, 10)
+    assert out['enc_cls_scores'] is None and out['enc_bbox_preds'] is None
+    assert rel(out['all_cls_scores'], torch.from_numpy(fx['all_cls_scores'])) < REL
+    assert rel(out['all_bbox_preds'], torch.from_numpy(fx['all_bbox_preds'])) < REL
+
+
+def test_head_c5_forward_and_intermediates(pa):
+    """BASELINE configs[1]: c5 shape, 900 queries, 6 layers, fp32, vs configs[0] (the CPU path)."""
+    oracle = O.seeded_head(0, None, num_query=900)
+    head = make_pair(pa, oracle, num_query=900)
+    metas = O.synthetic_img_metas(1, 6, (512, 1408), seed=0)
+    feats = torch.randn(1, 6, 256, 16, 44, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        want = oracle([feats], metas, return_intermediates=True)
+        got = head([feats.cuda()], metas)
+    L = 6 * 16 * 44
+    mem = head.workspace_view('memory').view(1, 6, 16, 44, 256).permute(0, 1, 4, 2, 3)
+    pos = head.workspace_view('pos_embed').view(1, 6, 16, 44, 256).permute(0, 1, 4, 2, 3)
+    assert rel(mem, want['_memory']) < 1e-5
+    assert rel(pos, want['_pos_embed']) < 1e-5
+    assert rel(head.workspace_view('query_embed').view(900, 256), want['_query_embeds']) < 1e-5
+    outs = head.workspace_view('outs_dec').view(6, 1, 900, 256)
+    assert rel(outs, want['_outs_dec']) < REL
+    assert rel(got['all_cls_scores'], want['all_cls_scores']) < REL
+    assert rel(got['all_bbox_preds'], want['all_bbox_preds']) < REL
+    # golden samples captured from the reference head at this exact configuration
+    fx = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'head_c5_samples.npz'))
+    wsum = sum(v.double().abs().sum().item() for v in oracle.state_dict().values())
+    if abs(wsum - float(fx['weight_abs_sum'])) <= 1e-9 * wsum:
+        idx = torch.from_numpy(fx['idx'])
+        assert (got['all_cls_scores'].cpu().flatten()[idx] - torch.from_numpy(fx['cls'])).abs().max() < 1e-3
+        assert (got['all_bbox_preds'].cpu().flatten()[idx] - torch.from_numpy(fx['bbox'])).abs().max() < 1e-3
+    # same input twice -> bit-identical (no atomics on the forward path)
+    with torch.no_grad():
+        again = head([feats.cuda()], metas)
+    assert torch.equal(again['all_cls_scores'], got['all_cls_scores'])
+    assert torch.equal(again['all_bbox_preds'], got['all_bbox_preds'])
+    del L
+
+
+def _grad_case(pa, B, N, H, W, pad_hw, img_hw, Q, seed):
+    oracle = O.seeded_head(seed, 77, num_query=Q)
+    head = make_pair(pa, oracle, num_query=Q)
+    oracle.train(False)
+    metas = O.synthetic_img_metas(B, N, pad_hw, img_hw, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(B, N, 256, H, W, generator=g)
+    g_cls, g_box = torch.randn(6, B, Q, 10, generator=g), torch.randn(6, B, Q, 10, generator=g)
+    fo = feats.clone().requires_grad_(True)
+    want = oracle([fo], metas)
+    (want['all_cls_scores'] * g_cls).sum().add((want['all_bbox_preds'] * g_box).sum()).backward()
+    fg = feats.cuda().requires_grad_(True)
+    got = head([fg], metas)
+    torch.autograd.backward([got['all_cls_scores'], got['all_bbox_preds']], [g_cls.cuda(), g_box.cuda()])
+    assert rel(got['all_cls_scores'], want['all_cls_scores']) < REL
+    assert rel(fg.grad, fo.grad) < 2e-3
+    worst = {}
+    op = dict(oracle.named_parameters())
+    for name, p in head.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, name
+        worst[name] = rel(p.grad, op[name].grad)
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    assert not bad, f'gradient mismatch: {sorted(bad.items(), key=lambda kv: -kv[1])[:8]}'
+    return head, metas, feats, (g_cls, g_box)
+
+
+def test_head_backward_toy_batch2_masked(pa):
+    _grad_case(pa, 2, 2, 4, 6, (128, 192), (100, 150), 16, seed=4)
+
+
+def test_head_backward_c5(pa):
+    head, metas, feats, (g_cls, g_box) = _grad_case(pa, 1, 6, 16, 44, (512, 1408), (512, 1408), 900, seed=5)
+    # gradient accumulation semantics: a second backward adds onto .grad
+    g1 = head.flat_gradients().clone()
+    got = head([feats.cuda()], metas)
+    torch.autograd.backward([got['all_cls_scores'], got['all_bbox_preds']], [g_cls.cuda(), g_box.cuda()])
+    assert rel(head.flat_gradients(), 2 * g1) < 1e-4
+    head.zero_grad(set_to_none=True)
+    got = head([feats.cuda()], metas)
+    torch.autograd.backward([got['all_cls_scores'], got['all_bbox_preds']], [g_cls.cuda(), g_box.cuda()])
+    assert rel(head.flat_gradients(), g1) < 1e-4
+
+
+def test_position_embeding_api(pa, golden_dir):
+    """PETRHead.position_embeding keeps the reference signature and layout ([B,N,256,H,W], mask)."""
+    fx = np.load(os.path.join(golden_dir, 'coords3d_toy_masked.npz'))
+    oracle = O.seeded_head(2, 1234, num_query=16)
+    head = make_pair(pa, oracle, num_query=16)
+    N, H, W = [int(v) for v in fx['shape']]
+    metas = metas_from(fx)
+    masks = torch.from_numpy(fx['masks'])
+    with torch.no_grad():
+        want_pe, want_mask = oracle.position_embeding(1, N, H, W, metas, masks)
+    pe, cmask = head.position_embeding([torch.zeros(1, N, 256, H, W).cuda()], metas, masks.cuda())
+    assert pe.shape == (1, N, 256, H, W)
+    assert rel(pe, want_pe) < 1e-5
+    assert (cmask.cpu() != want_mask).sum().item() <= 1
+
+
+def test_transformer_module_api(pa):
+    """PETRTransformer.forward(x, mask, query_embed, pos_embed) drop-in (inference) vs the oracle transformer."""
+    oracle = O.seeded_head(2, 1234, num_query=16)
+    head = make_pair(pa, oracle, num_query=16)
+    g = torch.Generator().manual_seed(1)
+    x, pos = torch.randn(2, 2, 256, 4, 6, generator=g), torch.randn(2, 2, 256, 4, 6, generator=g)
+    qe = torch.randn(16, 256, generator=g)
+    mask = torch.zeros(2, 2, 4, 6, dtype=torch.bool)
+    mask[1, :, :, 4:] = True
+    with torch.no_grad():
+        want, _ = oracle.transformer(x, mask, qe, pos)
+        got, mem = head.transformer(x.cuda(), mask.cuda(), qe.cuda(), pos.cuda())
+    assert got.shape == (6, 2, 16, 256) and mem.shape == x.shape
+    assert rel(got, want) < REL

@@ -1,0 +1,274 @@
+#!/usr/bin/env python
+"""Benchmark of the PETRHead hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one pass of the hot path over one batch of synthetic input on every rank:
+zero the flat gradient buffer, PETRHead forward, backward from a fixed seeded upstream gradient, and
+(N>1) the bucketed RCCL all-reduce of the gradients overlapped with the backward.  Inputs (features,
+upstream gradients) are resident in HBM before the timed region; ``img_metas`` stay host-side as in the
+reference (float64 ``lidar2img`` inverted on the host every forward, petr_head.py:308-315).
+
+One JSON line on rank 0: metric/value/unit as BASELINE.json (samples/s fwd+bwd, whole job), plus
+  roofline      dominant kernel = cross-attention forward (mha_fwd_kernel): algorithmic FLOPs per launch
+                (4*Q*L*C) / its mean launch duration measured with HIP events on the launch
+                stream inside real steps, against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
+  cpu_baseline  the CPU oracle (a port of the reference's PyTorch path) timed on this box's host cores
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (N views, H, W, pad_h, pad_w, description)
+    'c5': (6, 16, 44, 512, 1408, 'petr_r50dcn_gridmask_c5 head-only: 6x(256x16x44) features'),
+    'p4_1408': (6, 32, 88, 512, 1408, 'petr_r50dcn_gridmask_p4 1408x512: 6x(256x32x88) features'),
+    'p4_1600': (6, 40, 100, 640, 1600, 'petr_vovnet_p4 1600x640: 6x(256x40x100) features'),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+HBM_PEAK_GBS = 8000.0
+
+
+def log(msg):
+    print(f'[bench] {msg}', file=sys.stderr, flush=True)
+
+
+def synthetic_metas(batch, n_views, pad_hw, seed):
+    """nuScenes-like lidar2img; kept in bench.py so the product path never imports oracle/."""
+    import numpy as np
+    metas = []
+    for b in range(batch):
+        rng = np.random.RandomState(seed + b)
+        r = pad_hw[1] / 1600.0
+        K = np.eye(4)
+        K[0, 0] = K[1, 1] = 1266.0 * r
+        K[0, 2], K[1, 2] = 816.0 * r, 491.0 * r
+        yaws = np.deg2rad([0.0, -55.0, 55.0, 180.0, 110.0, -110.0])
+        swap = np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]], dtype=np.float64)
+        mats = []
+        for i in range(n_views):
+            c, s = np.cos(yaws[i % 6]), np.sin(yaws[i % 6])
+            Rz = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float64)
+            R = swap @ Rz.T
+            t = rng.uniform(-1.5, 1.5, size=3)
+            rt = np.eye(4)
+            rt[:3, :3] = R
+            rt[:3, 3] = -R @ t
+            mats.append(K @ rt)
+        metas.append({'pad_shape': [(pad_hw[0], pad_hw[1], 3)] * n_views, 'img_shape': [(pad_hw[0], pad_hw[1], 3)] * n_views,
+                      'lidar2img': mats})
+    return metas
+
+
+def cpu_baseline(workload, batch, num_query, budget_s=25.0):
+    """The oracle (CPU restatement of the reference's PyTorch path) on the host cores: fwd+bwd and fwd-only."""
+    from oracle import petr_oracle as O
+    n, h, w, ph, pw, _ = WORKLOADS[workload]
+    # the box's CPU share, not the host's core count (oversubscribed OpenMP threads crawl)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(cores, 16)))
+    head = O.seeded_head(0, None, num_query=num_query)
+    metas = O.synthetic_img_metas(batch, n, (ph, pw), seed=0)
+    g = torch.Generator().manual_seed(0)
+    feats = torch.randn(batch, n, 256, h, w, generator=g)
+    g_cls, g_box = torch.randn(6, batch, num_query, 10, generator=g), torch.randn(6, batch, num_query, 10, generator=g)
+
+    def step():
+        head.zero_grad(set_to_none=True)
+        out = head([feats], metas)
+        torch.autograd.backward([out['all_cls_scores'], out['all_bbox_preds']], [g_cls, g_box])
+
+    step()   # warm-up
+    log(f'cpu baseline: warm-up done, {torch.get_num_threads()} threads')
+    t0 = time.perf_counter()
+    n_steps = 0
+    while n_steps < 3 or (time.perf_counter() - t0 < budget_s * 0.6 and n_steps < 20):
+        step()
+        n_steps += 1
+    dt = (time.perf_counter() - t0) / n_steps
+    with torch.no_grad():
+        head([feats], metas)
+        t1 = time.perf_counter()
+        n_f = 0
+        while n_f < 3 or (time.perf_counter() - t1 < budget_s * 0.3 and n_f < 20):
+            head([feats], metas)
+            n_f += 1
+        dtf = (time.perf_counter() - t1) / n_f
+    return {'value': round(batch / dt, 4), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n_steps} fwd+bwd steps (and {n_f} fwd-only) of the same workload, batch {batch}, fp32, eval mode',
+            'fwd_value': round(batch / dtf, 4), 'ms_per_step': round(dt * 1e3, 2), 'fwd_ms': round(dtf * 1e3, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='c5', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=1, help='samples per GPU (the reference configs use 1)')
+    ap.add_argument('--queries', type=int, default=900)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fwd-only', action='store_true', help='time the forward only (diagnostic; not the metric)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import petr_amd
+    from petr_amd import _C
+    from petr_amd.dist import BucketedGradAllReduce
+
+    n, h, w, ph, pw, desc = WORKLOADS[args.workload]
+    B, Q = args.batch, args.queries
+    torch.manual_seed(0)                     # identical weights on every rank (reference init rules)
+    head = petr_amd.build_head(petr_amd.petr_head_cfg(num_query=Q))
+    head.init_weights()
+    head = head.to(dev).eval()               # eval: the reference's dropouts are identities
+    metas = synthetic_metas(B, n, (ph, pw), seed=rank * 1000)
+    g = torch.Generator().manual_seed(1234 + rank)           # rank-offset seed: every rank has its own samples
+    feats = torch.randn(B, n, 256, h, w, generator=g).to(dev).requires_grad_(not args.fwd_only)
+    g_cls = torch.randn(6, B, Q, 10, generator=g).to(dev)
+    g_box = torch.randn(6, B, Q, 10, generator=g).to(dev)
+    reducer = BucketedGradAllReduce(head, merge=2) if world > 1 else None
+
+    def step():
+        if args.fwd_only:
+            with torch.no_grad():
+                head([feats], metas)
+            return
+        head.zero_grad_flat()
+        feats.grad = None
+        out = head([feats], metas)
+        torch.autograd.backward([out['all_cls_scores'], out['all_bbox_preds']], [g_cls, g_box])
+        if reducer is not None:
+            reducer.finish()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if rank == 0:
+        log('warm-up done')
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        log(f'timed region done: {elapsed / args.steps * 1e3:.3f} ms/step')
+    # ---- forward-only rate (for the ">= 10x the host-CPU forward" target), same steady state ----
+    fwd_ms = None
+    if not args.fwd_only:
+        with torch.no_grad():
+            for _ in range(3):
+                head([feats], metas)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                head([feats], metas)
+            torch.cuda.synchronize()
+            fwd_ms = (time.perf_counter() - t1) / args.steps * 1e3
+
+    # ---- roofline leg: HIP events around the tagged kernels inside real steps (rank 0) ----
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        L = _C.lib()
+        prof_steps = min(args.steps, 20)
+        _C.check(L.petr_prof_begin(prof_steps * 64), 'petr_prof_begin')
+        for _ in range(prof_steps):
+            step()
+        torch.cuda.synchronize()
+        cap = prof_steps * 64
+        ms = (C.c_float * cap)()
+        tags = (C.c_int * cap)()
+        cnt = C.c_int()
+        _C.check(L.petr_prof_end(ms, tags, cap, C.byref(cnt)), 'petr_prof_end')
+        acc = {}
+        for i in range(cnt.value):
+            acc.setdefault(tags[i], []).append(ms[i])
+        names = {1: 'mha_fwd_self', 17: 'mha_fwd_cross', 2: 'mha_bwd_self', 18: 'mha_bwd_cross', 4: 'coords3d'}
+        for tag, v in acc.items():
+            kernels[names.get(tag, str(tag))] = {'launches': len(v), 'mean_us': round(sum(v) / len(v) * 1e3, 2)}
+        Ltok = n * h * w
+        if 'mha_fwd_cross' in kernels:
+            us = kernels['mha_fwd_cross']['mean_us']
+            flops = 4.0 * B * Q * Ltok * 256            # QK^T + PV of one layer
+            ach = flops / (us * 1e-6) / 1e12
+            roofline = {'kernel': 'mha_fwd_kernel (cross-attention, one decoder layer)', 'bound': 'mfma',
+                        'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                        'flops_per_launch': flops, 'mean_launch_us': us}
+        if 'mha_bwd_cross' in kernels:
+            us = kernels['mha_bwd_cross']['mean_us']
+            kernels['mha_bwd_cross']['tflops'] = round(10.0 * B * Q * Ltok * 256 / (us * 1e-6) / 1e12, 2)
+        if 'coords3d' in kernels:
+            us = kernels['coords3d']['mean_us']
+            kernels['coords3d']['gbs'] = round(B * Ltok * 192 * 4 / (us * 1e-6) / 1e9, 1)   # volume bytes
+            kernels['coords3d']['hbm_frac'] = round(kernels['coords3d']['gbs'] / HBM_PEAK_GBS, 4)
+
+    if rank == 0:
+        log('kernel timing done')
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload, B, Q)
+
+    if rank == 0:
+        samples = world * B * args.steps
+        out = {
+            'metric': 'samples/sec PETRHead fwd+bwd' if not args.fwd_only else 'samples/sec PETRHead fwd',
+            'value': round(samples / elapsed, 3), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{desc}, {Q} queries, 6 decoder layers, fp32 (BASELINE configs[1])'
+                       if args.workload == 'c5' else f'{desc}, {Q} queries, 6 decoder layers, fp32',
+                       'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}',
+                       'dropout': 'off (eval mode, as the CPU baseline)'},
+            'fwd_ms': round(fwd_ms, 4) if fwd_ms is not None else None,
+            'fwd_samples_per_s': round(B / (fwd_ms * 1e-3), 2) if fwd_ms else None,
+            'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu,
+        }
+        if cpu and fwd_ms:
+            out['fwd_speedup_vs_cpu'] = round((B / (fwd_ms * 1e-3)) / cpu['fwd_value'], 1)
+            out['fwdbwd_speedup_vs_cpu'] = round(out['value'] / cpu['value'], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

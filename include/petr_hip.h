@@ -165,6 +165,9 @@ typedef struct {
   float* dz; float* dgamma; float* dbeta;
   void* ws;
   int M, C; int flags; int dz_accumulate;
+  /* upstream gradient = sum_{p<dy_partials} dy[p*dy_partial_stride + ...] + dy_residual (both optional):
+   * lets a split-K input-gradient contraction hand its slabs over without a reduce launch */
+  int dy_partials; long dy_partial_stride; const float* dy_residual;
 } petr_layernorm_bwd_args;
 size_t petr_layernorm_bwd_workspace_bytes(int M, int C);
 int petr_layernorm_bwd(const petr_layernorm_bwd_args* a, void* stream);

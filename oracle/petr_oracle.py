@@ -6,6 +6,11 @@ checked against it; it is never imported by the product package
 (``petr_amd``).  Only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` may import it.
 
+``torch.float32`` / ``.float()`` of the reference are written ``torch.get_default_dtype()`` here: with
+the default dtype (float32) the arithmetic is the reference's bit for bit (tests/test_oracle_golden.py);
+under ``torch.set_default_dtype(torch.float64)`` the same code is a float64 yardstick used by the
+gradient tests to tell fp32 rounding noise from real disagreement.
+
 Every function cites the reference lines it follows (paths relative to
 ``/root/reference/projects/mmdet3d_plugin``).  Pinning status:
 
@@ -45,7 +50,7 @@ def pos2posemb3d(pos, num_pos_feats=128, temperature=10000):
     """models/dense_heads/petr_head.py:31-43.  Output order (y, x, z)."""
     scale = 2 * math.pi
     pos = pos * scale
-    dim_t = torch.arange(num_pos_feats, dtype=torch.float32, device=pos.device)
+    dim_t = torch.arange(num_pos_feats, dtype=torch.get_default_dtype(), device=pos.device)
     dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
     pos_x = pos[..., 0, None] / dim_t
     pos_y = pos[..., 1, None] / dim_t
@@ -58,7 +63,7 @@ def pos2posemb3d(pos, num_pos_feats=128, temperature=10000):
 
 def sine_dim_t(num_feats=128, temperature=10000):
     """models/utils/positional_encoding.py:82-84 (and petr_head.py:34-35)."""
-    dim_t = torch.arange(num_feats, dtype=torch.float32)
+    dim_t = torch.arange(num_feats, dtype=torch.get_default_dtype())
     return temperature ** (2 * (dim_t // 2) / num_feats)
 
 
@@ -68,14 +73,14 @@ def sine_positional_encoding_3d(mask, num_feats=128, temperature=10000,
     """models/utils/positional_encoding.py:58-100.  mask [B,N,H,W] -> [B,N,3F,H,W]."""
     mask = mask.to(torch.int)
     not_mask = 1 - mask
-    n_embed = not_mask.cumsum(1, dtype=torch.float32)
-    y_embed = not_mask.cumsum(2, dtype=torch.float32)
-    x_embed = not_mask.cumsum(3, dtype=torch.float32)
+    n_embed = not_mask.cumsum(1, dtype=torch.get_default_dtype())
+    y_embed = not_mask.cumsum(2, dtype=torch.get_default_dtype())
+    x_embed = not_mask.cumsum(3, dtype=torch.get_default_dtype())
     if normalize:
         n_embed = (n_embed + offset) / (n_embed[:, -1:, :, :] + eps) * scale
         y_embed = (y_embed + offset) / (y_embed[:, :, -1:, :] + eps) * scale
         x_embed = (x_embed + offset) / (x_embed[:, :, :, -1:] + eps) * scale
-    dim_t = torch.arange(num_feats, dtype=torch.float32, device=mask.device)
+    dim_t = torch.arange(num_feats, dtype=torch.get_default_dtype(), device=mask.device)
     dim_t = temperature ** (2 * (dim_t // 2) / num_feats)
     pos_n = n_embed[:, :, :, :, None] / dim_t
     pos_x = x_embed[:, :, :, :, None] / dim_t
@@ -87,7 +92,7 @@ def sine_positional_encoding_3d(mask, num_feats=128, temperature=10000,
     return torch.cat((pos_n, pos_y, pos_x), dim=4).permute(0, 1, 4, 2, 3)
 
 
-def padding_masks(batch_size, num_cams, img_metas, feat_hw, dtype=torch.float32):
+def padding_masks(batch_size, num_cams, img_metas, feat_hw, dtype=torch.get_default_dtype()):
     """models/dense_heads/petr_head.py:383-394: ones, zero the valid region, nearest-resize, to bool."""
     input_img_h, input_img_w, _ = img_metas[0]['pad_shape'][0]
     masks = torch.ones((batch_size, num_cams, input_img_h, input_img_w), dtype=dtype)
@@ -100,7 +105,7 @@ def padding_masks(batch_size, num_cams, img_metas, feat_hw, dtype=torch.float32)
 
 def depth_bins(depth_num, depth_start, position_range, LID):
     """models/dense_heads/petr_head.py:293-301."""
-    index = torch.arange(start=0, end=depth_num, step=1).float()
+    index = torch.arange(start=0, end=depth_num, step=1).to(torch.get_default_dtype())
     if LID:
         index_1 = index + 1
         bin_size = (position_range[3] - depth_start) / (depth_num * (1 + depth_num))
@@ -114,7 +119,7 @@ def img2lidar_matrices(img_metas):
     out = []
     for img_meta in img_metas:
         out.append(np.asarray([np.linalg.inv(m) for m in img_meta['lidar2img']]))
-    return torch.tensor(np.asarray(out), dtype=torch.float32)
+    return torch.tensor(np.asarray(out), dtype=torch.float32).to(torch.get_default_dtype())
 
 
 def coords3d_volume(B, N, H, W, img_metas, depth_num=64, depth_start=1,
@@ -126,8 +131,8 @@ def coords3d_volume(B, N, H, W, img_metas, depth_num=64, depth_start=1,
     normalised coords [B,N,W,H,D,3] before the logit)."""
     eps = 1e-5
     pad_h, pad_w, _ = img_metas[0]['pad_shape'][0]
-    coords_h = torch.arange(H).float() * pad_h / H
-    coords_w = torch.arange(W).float() * pad_w / W
+    coords_h = torch.arange(H).to(torch.get_default_dtype()) * pad_h / H
+    coords_w = torch.arange(W).to(torch.get_default_dtype()) * pad_w / W
     coords_d = depth_bins(depth_num, depth_start, position_range, LID)
     D = coords_d.shape[0]
     coords = torch.stack(torch.meshgrid([coords_w, coords_h, coords_d], indexing='ij')).permute(1, 2, 3, 0)

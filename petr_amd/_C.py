@@ -63,7 +63,8 @@ class LayerNormBwdArgs(C.Structure):
     _fields_ = _fields(('z', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('gamma', C.c_void_p),
                        ('dy', C.c_void_p), ('y', C.c_void_p), ('dz', C.c_void_p), ('dgamma', C.c_void_p),
                        ('dbeta', C.c_void_p), ('ws', C.c_void_p), ('M', C.c_int), ('C', C.c_int), ('flags', C.c_int),
-                       ('dz_accumulate', C.c_int))
+                       ('dz_accumulate', C.c_int), ('dy_partials', C.c_int), ('dy_partial_stride', C.c_long),
+                       ('dy_residual', C.c_void_p))
 
 
 class MhaFwdArgs(C.Structure):

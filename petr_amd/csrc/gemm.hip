@@ -24,67 +24,75 @@ struct OperandView {
   const float* p;
   long ld;
   int rows;    // valid rows (M or N)
-  int vec_ok;  // 16-byte vector loads legal (alignment + extents)
 };
 
 // ---- global -> register stage -------------------------------------------------------------
-template <int ROWS, bool KC>
+// Every load is UNCONDITIONAL (addresses clamped into the operand, the value zeroed afterwards by a
+// select): a load inside an exec-masked branch makes hipcc wait vmcnt(0) at the end of the branch, which
+// serialises the whole prefetch ring into one exposed memory latency per float4 (cdna guide §5 trap (c)).
+template <int ROWS, bool KC, bool VEC, bool A2>
 struct Stage {
   static constexpr int NV = ROWS * BK / 4 / 256;
   static constexpr int LD = KC ? ROWS + 1 : ROWS + 4;
   float4 v[NV];
+  float4 w[A2 ? NV : 1];
+
+  __device__ __forceinline__ static float4 ld4(const float* base, long off0, long off1, long off2, long off3) {
+    return make_float4(base[off0], base[off1], base[off2], base[off3]);
+  }
 
   __device__ __forceinline__ void load(const OperandView& o, long seg_off, int row0, int k0, int kend, const float* a2,
-                                       int a2_rows) {
+                                       int a2_rows, bool a2_on) {
     const int t = threadIdx.x;
+    const float* base = o.p + seg_off;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = t + 256 * i;
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 r, r2 = make_float4(0.f, 0.f, 0.f, 0.f);
+      bool ok0, ok1, ok2, ok3;
       if (KC) {
         const int row = row0 + (idx >> 3);
         const int k = k0 + 4 * (idx & 7);
-        if (row < o.rows && k < kend) {
-          const float* src = o.p + seg_off + (long)row * o.ld + k;
-          if (o.vec_ok && k + 3 < kend) {
-            r = *reinterpret_cast<const float4*>(src);
+        const int rowc = min(row, o.rows - 1);
+        const bool rok = row < o.rows;
+        ok0 = rok && k < kend; ok1 = rok && k + 1 < kend; ok2 = rok && k + 2 < kend; ok3 = rok && k + 3 < kend;
+        if (VEC) {
+          const int kc = min(k, kend - 4);
+          r = *reinterpret_cast<const float4*>(base + (long)rowc * o.ld + kc);
+          ok1 = ok2 = ok3 = ok0;       // K % 4 == 0: a float4 is entirely inside or outside
+        } else {
+          const long ro = (long)rowc * o.ld;
+          r = ld4(base, ro + min(k, kend - 1), ro + min(k + 1, kend - 1), ro + min(k + 2, kend - 1), ro + min(k + 3, kend - 1));
+        }
+        if (A2) {
+          const int r2row = a2_rows > 0 ? rowc % a2_rows : rowc;
+          const float* b2 = a2 + seg_off;
+          if (VEC) {
+            r2 = *reinterpret_cast<const float4*>(b2 + (long)r2row * o.ld + min(k, kend - 4));
           } else {
-            r.x = src[0];
-            if (k + 1 < kend) r.y = src[1];
-            if (k + 2 < kend) r.z = src[2];
-            if (k + 3 < kend) r.w = src[3];
-          }
-          if (a2) {
-            const int r2 = a2_rows > 0 ? row % a2_rows : row;
-            const float* s2 = a2 + seg_off + (long)r2 * o.ld + k;
-            if (o.vec_ok && k + 3 < kend) {
-              const float4 q = *reinterpret_cast<const float4*>(s2);
-              r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
-            } else {
-              r.x += s2[0];
-              if (k + 1 < kend) r.y += s2[1];
-              if (k + 2 < kend) r.z += s2[2];
-              if (k + 3 < kend) r.w += s2[3];
-            }
+            const long ro = (long)r2row * o.ld;
+            r2 = ld4(b2, ro + min(k, kend - 1), ro + min(k + 1, kend - 1), ro + min(k + 2, kend - 1), ro + min(k + 3, kend - 1));
           }
         }
       } else {
         constexpr int RPK = ROWS / 4;
         const int k = k0 + idx / RPK;
         const int row = row0 + 4 * (idx % RPK);
-        if (k < kend && row < o.rows) {
-          const float* src = o.p + seg_off + (long)k * o.ld + row;
-          if (o.vec_ok && row + 3 < o.rows) {
-            r = *reinterpret_cast<const float4*>(src);
-          } else {
-            r.x = src[0];
-            if (row + 1 < o.rows) r.y = src[1];
-            if (row + 2 < o.rows) r.z = src[2];
-            if (row + 3 < o.rows) r.w = src[3];
-          }
+        const int kc = min(k, kend - 1);
+        const bool kok = k < kend;
+        ok0 = kok && row < o.rows; ok1 = kok && row + 1 < o.rows; ok2 = kok && row + 2 < o.rows; ok3 = kok && row + 3 < o.rows;
+        if (VEC) {
+          r = *reinterpret_cast<const float4*>(base + (long)kc * o.ld + min(row, o.rows - 4));
+          ok1 = ok2 = ok3 = ok0;       // rows % 4 == 0
+        } else {
+          const long ko = (long)kc * o.ld;
+          r = ld4(base, ko + min(row, o.rows - 1), ko + min(row + 1, o.rows - 1), ko + min(row + 2, o.rows - 1),
+                  ko + min(row + 3, o.rows - 1));
         }
       }
-      v[i] = r;
+      v[i] = make_float4(ok0 ? r.x : 0.f, ok1 ? r.y : 0.f, ok2 ? r.z : 0.f, ok3 ? r.w : 0.f);
+      if (A2) w[i] = make_float4(ok0 && a2_on ? r2.x : 0.f, ok1 && a2_on ? r2.y : 0.f, ok2 && a2_on ? r2.z : 0.f,
+                                 ok3 && a2_on ? r2.w : 0.f);
     }
   }
 
@@ -93,29 +101,30 @@ struct Stage {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = t + 256 * i;
+      float4 x = v[i];
+      if (A2) { x.x += w[i].x; x.y += w[i].y; x.z += w[i].z; x.w += w[i].w; }
       if (KC) {
         const int row = idx >> 3, kq = idx & 7;
         float* d = lds + (4 * kq) * LD + row;
-        d[0] = v[i].x;
-        d[LD] = v[i].y;
-        d[2 * LD] = v[i].z;
-        d[3 * LD] = v[i].w;
+        d[0] = x.x;
+        d[LD] = x.y;
+        d[2 * LD] = x.z;
+        d[3 * LD] = x.w;
       } else {
         constexpr int RPK = ROWS / 4;
         const int k = idx / RPK, r4 = idx % RPK;
-        *reinterpret_cast<float4*>(lds + k * LD + 4 * r4) = v[i];
+        *reinterpret_cast<float4*>(lds + k * LD + 4 * r4) = x;
       }
     }
   }
 };
 
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
-__global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const int a_vec, const int b_vec,
-                                                    const int tiles_m, const int tiles_n) {
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, bool VEC, bool A2>
+__global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const int tiles_m, const int tiles_n) {
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
   constexpr int TM = WM / 32, TN = WN / 32;
-  using SA = Stage<BM, AKC>;
-  using SB = Stage<BN, BKC>;
+  using SA = Stage<BM, AKC, VEC, A2>;
+  using SB = Stage<BN, BKC, VEC, false>;
   __shared__ __attribute__((aligned(16))) float lds[BK * SA::LD + BK * SB::LD];
   float* As = lds;
   float* Bs = lds + BK * SA::LD;
@@ -129,9 +138,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
   z /= g.split_k;
   const int z1 = z % g.nb1, z0 = z / g.nb1;
 
-  OperandView A{g.a + z0 * g.a_bs0 + z1 * g.a_bs1, g.lda, g.M, a_vec};
-  OperandView B{g.b + z0 * g.b_bs0 + z1 * g.b_bs1, g.ldb, g.N, b_vec};
-  const float* a2 = (g.a2 && (g.a2_ncols <= 0 || n0 < g.a2_ncols)) ? g.a2 : nullptr;
+  OperandView A{g.a + z0 * g.a_bs0 + z1 * g.a_bs1, g.lda, g.M};
+  OperandView B{g.b + z0 * g.b_bs0 + z1 * g.b_bs1, g.ldb, g.N};
+  // the addend applies to the first a2_ncols output columns only (block-uniform)
+  const bool use_a2 = A2 && (g.a2_ncols <= 0 || n0 < g.a2_ncols);
+  const float* a2 = g.a2;
 
   // K may be cut into segments that live at different base addresses (k = seg*k_seg + kk):
   // sums over (layer, channel), (view, pixel) or (batch, token) in the backward contractions.
@@ -161,37 +172,48 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
   const bool do_colsum = g.a_colsum != nullptr && tn_i == 0;
   float colacc = 0.f;
 
-  SA sa;
-  SB sb;
-  auto stage_load = [&](int kt) {
+  // Register prefetch ring, PD tiles deep: these contractions are short chains of k-tiles whose
+  // per-tile MFMA time (16 MFMAs) is far below one global-load latency, so ONE tile of look-ahead
+  // leaves every iteration waiting ~1-2 us on its loads; PD tiles in flight hide it.
+  constexpr int PD = (BM * BN <= 128 * 64) ? 3 : 2;
+  SA sa[PD];
+  SB sb[PD];
+  auto stage_load = [&](SA& ra, SB& rb, int kt) {
     const int seg = kt / tps, k0 = (kt - seg * tps) * BK;
-    sa.load(A, (long)seg * g.a_seg_stride, m0, k0, kseg, a2, g.a2_rows);
-    sb.load(B, (long)seg * g.b_seg_stride, n0, k0, kseg, nullptr, 0);
+    ra.load(A, (long)seg * g.a_seg_stride, m0, k0, kseg, a2, g.a2_rows, use_a2);
+    rb.load(B, (long)seg * g.b_seg_stride, n0, k0, kseg, nullptr, 0, false);
   };
-  if (kt_begin < kt_end) stage_load(kt_begin);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    __syncthreads();
-    sa.store(As);
-    sb.store(Bs);
-    __syncthreads();
-    if (kt + 1 < kt_end) stage_load(kt + 1);
-    if (do_colsum && threadIdx.x < BM) {
-      float cs = 0.f;
 #pragma unroll
-      for (int k = 0; k < BK; ++k) cs += As[k * SA::LD + threadIdx.x];
-      colacc += cs;
-    }
+  for (int i = 0; i < PD; ++i)
+    if (kt_begin + i < kt_end) stage_load(sa[i], sb[i], kt_begin + i);
+  for (int kt0 = kt_begin; kt0 < kt_end; kt0 += PD) {
+#pragma unroll
+    for (int j = 0; j < PD; ++j) {
+      const int kt = kt0 + j;
+      if (kt >= kt_end) break;
+      __syncthreads();
+      sa[j].store(As);
+      sb[j].store(Bs);
+      __syncthreads();
+      if (kt + PD < kt_end) stage_load(sa[j], sb[j], kt + PD);
+      if (do_colsum && threadIdx.x < BM) {
+        float cs = 0.f;
+#pragma unroll
+        for (int k = 0; k < BK; ++k) cs += As[k * SA::LD + threadIdx.x];
+        colacc += cs;
+      }
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
       float af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = As[(2 * s + h) * SA::LD + wm0 + i * 32 + c];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * s + h) * SB::LD + wn0 + j * 32 + c];
+      for (int jj = 0; jj < TN; ++jj) bf[jj] = Bs[(2 * s + h) * SB::LD + wn0 + jj * 32 + c];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int jj = 0; jj < TN; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[jj], acc[i][jj], 0, 0, 0);
+      }
     }
   }
 
@@ -208,47 +230,237 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn0 + j * 32 + c;
-    if (n >= g.N) continue;
-    const float bv = bias ? bias[n] : 0.f;
-    const long ccol = g.c_nblk > 0 ? (long)(n / g.c_nblk) * g.c_nblk_stride + (n % g.c_nblk) : (long)n;
+    const int nc = min(n, g.N - 1);                 // clamped for loads; stores are predicated
+    const float bv = bias ? bias[nc] : 0.f;
+    const long ccol = g.c_nblk > 0 ? (long)(nc / g.c_nblk) * g.c_nblk_stride + (nc % g.c_nblk) : (long)nc;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + i * 32 + mfma32_row(r, h);
-        if (m >= g.M) continue;
+        const int mc = min(m, g.M - 1);
+        const bool ok = m < g.M && n < g.N;
         float v = acc[i][j][r] * g.alpha + bv;
-        if (flags & PETR_GEMM_SIGMOID_MUL) {
-          v = R[(long)m * g.ldr + n] * (1.f / (1.f + expf(-v)));
-        } else if (flags & PETR_GEMM_RELU_MASK) {
-          v = R[(long)m * g.ldr + n] > 0.f ? v : 0.f;
-        } else if (R) {
-          v += R[(long)m * g.ldr + n];
-        }
+        float* dst = C + (long)mc * g.ldc + ccol;
+        const float rv = R ? R[(long)mc * g.ldr + nc] : 0.f;      // R is kernel-uniform: no exec-masked load
+        const float old = (flags & PETR_GEMM_ACCUMULATE) ? *dst : 0.f;
+        if (flags & PETR_GEMM_SIGMOID_MUL) v = rv * (1.f / (1.f + expf(-v)));
+        else if (flags & PETR_GEMM_RELU_MASK) v = rv > 0.f ? v : 0.f;
+        else v += rv;
         if (flags & PETR_GEMM_RELU) v = fmaxf(v, 0.f);
-        float* dst = C + (long)m * g.ldc + ccol;
-        if (atomic) {
-          atomicAdd(dst, v);
-        } else {
-          if (flags & PETR_GEMM_ACCUMULATE) v += *dst;
-          *dst = v;
+        v += old;
+        if (ok) {
+          if (atomic) atomicAdd(dst, v);
+          else *dst = v;
         }
       }
     }
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_cfg(const petr_gemm_args& g, int a_vec, int b_vec, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------
+// "Skinny" contraction for the query side of the decoder and for weight gradients: outputs with few
+// 64x64 tiles (900 x 256, 256 x 256, ...) where the tiled kernel above leaves 3/4 of the CUs idle and
+// spends its time in a serial chain of k-tiles (load -> LDS -> barrier -> 16 MFMAs).
+//   workgroup = one 32x32 output tile, its NW waves split K between them (K-split INSIDE the
+//   workgroup: the partial tiles are summed through LDS, so there are no float atomics and no slab
+//   pass even for weight gradients); operands go global -> registers directly in MFMA fragment order
+//   (lane (c,h) holds row c, k = 16h..16h+15 of a 32-deep chunk), no LDS staging, no barrier in the
+//   main loop, the next chunk is in flight while the 16 MFMAs of the current one run.
+// 900x256x256 becomes 232 workgroups x 8 waves with ONE chunk (16 MFMAs) per wave instead of
+// 60 workgroups x 8 serial k-tiles.
+// ---------------------------------------------------------------------------------------------
+template <bool KC, bool VEC>
+__device__ __forceinline__ void skinny_load(const float* base, long ld, int row, int rows, int k0, int kend, float f[16]) {
+  // fragment order: element s of lane-half h is k = k0 + 16h + s (h folded into k0 by the caller)
+  const int rowc = min(row, rows - 1);
+  const bool rok = row < rows;
+  if (KC) {
+    const float* p = base + (long)rowc * ld;
+    if (VEC) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + 4 * j;
+        const float4 v = *reinterpret_cast<const float4*>(p + min(k, kend - 4));
+        const bool ok = rok && k < kend;
+        f[4 * j] = ok ? v.x : 0.f; f[4 * j + 1] = ok ? v.y : 0.f; f[4 * j + 2] = ok ? v.z : 0.f; f[4 * j + 3] = ok ? v.w : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float v = p[min(k0 + s, kend - 1)];
+        f[s] = (rok && k0 + s < kend) ? v : 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float v = base[(long)min(k0 + s, kend - 1) * ld + rowc];
+      f[s] = (rok && k0 + s < kend) ? v : 0.f;
+    }
+  }
+}
+
+template <bool AKC, bool BKC, bool VEC, bool A2>
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(const petr_gemm_args g, const int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [NW][16][64] partial tiles (+ [NW][64] column sums)
+  const int NW = blockDim.x >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int h = lane >> 5, c = lane & 31;
+  const int tiles = gridDim.x;
+  const int tile = xcd_remap(blockIdx.x, tiles);
+  const int tm_i = tile / tiles_n, tn_i = tile - tm_i * tiles_n;
+  const int m0 = tm_i * 32, n0 = tn_i * 32;
+  const int z1 = blockIdx.z % g.nb1, z0 = blockIdx.z / g.nb1;
+  const float* Ab = g.a + z0 * g.a_bs0 + z1 * g.a_bs1;
+  const float* Bb = g.b + z0 * g.b_bs0 + z1 * g.b_bs1;
+  const bool use_a2 = A2 && (g.a2_ncols <= 0 || n0 < g.a2_ncols);
+
+  const int kseg = g.k_seg > 0 ? g.k_seg : g.K;
+  const int nseg = g.k_seg > 0 ? g.K / g.k_seg : 1;
+  const int cps = (kseg + 31) >> 5;                    // 32-deep chunks per segment
+  const int chunks = nseg * cps;
+  const int per = (chunks + NW - 1) / NW;
+  const int ch_begin = wave * per, ch_end = min(chunks, ch_begin + per);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float colacc = 0.f;
+  const bool do_colsum = g.a_colsum != nullptr && tn_i == 0;
+
+  float fa[2][16], fb[2][16], fa2[A2 ? 16 : 1];
+  auto load_chunk = [&](int ch, float (&da)[16], float (&db)[16]) {
+    const int seg = ch / cps, k0 = (ch - seg * cps) * 32 + 16 * h;
+    skinny_load<AKC, VEC>(Ab + (long)seg * g.a_seg_stride, g.lda, m0 + c, g.M, k0, kseg, da);
+    skinny_load<BKC, VEC>(Bb + (long)seg * g.b_seg_stride, g.ldb, n0 + c, g.N, k0, kseg, db);
+    if (A2) {
+      const int row = m0 + c;
+      const int r2 = g.a2_rows > 0 ? min(row, g.M - 1) % g.a2_rows : row;
+      skinny_load<true, VEC>(g.a2 + (long)seg * g.a_seg_stride, g.lda, r2, g.a2_rows > 0 ? g.a2_rows : g.M, k0, kseg, fa2);
+      const bool on = use_a2 && row < g.M;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) da[s] += on ? fa2[s] : 0.f;
+    }
+  };
+  if (ch_begin < ch_end) load_chunk(ch_begin, fa[0], fb[0]);
+  for (int ch = ch_begin; ch < ch_end; ch += 2) {
+    if (ch + 1 < ch_end) load_chunk(ch + 1, fa[1], fb[1]);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][s], fb[0][s], acc, 0, 0, 0);
+      colacc += fa[0][s];
+    }
+    if (ch + 1 < ch_end) {
+      if (ch + 2 < ch_end) load_chunk(ch + 2, fa[0], fb[0]);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][s], fb[1][s], acc, 0, 0, 0);
+        colacc += fa[1][s];
+      }
+    }
+  }
+
+  // ---- sum the NW partial tiles through LDS (deterministic order) ----
+  float* csum = red + NW * 1024;
+  if (NW > 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    if (do_colsum) csum[wave * 64 + lane] = colacc;
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[r];
+      for (int w = 1; w < NW; ++w) v += red[(w * 16 + r) * 64 + lane];
+      acc[r] = v;
+    }
+    if (do_colsum)
+      for (int w = 1; w < NW; ++w) colacc += csum[w * 64 + lane];
+  }
+  if (do_colsum) {
+    const float tot = xhalf_sum(colacc);              // the two lane halves hold the two k halves of row c
+    if (h == 0 && m0 + c < g.M) {
+      float* dst = g.a_colsum + z0 * g.cs_bs0 + z1 * g.cs_bs1 + m0 + c;
+      *dst += tot;                                     // single owner per row: plain read-modify-write
+    }
+  }
+
+  // ---- epilogue (same semantics as the tiled kernel; PETR_GEMM_ATOMIC degrades to a plain += here) ----
+  float* C = g.c + z0 * g.c_bs0 + z1 * g.c_bs1;
+  const float* bias = g.bias ? g.bias + z0 * g.bias_bs0 + z1 * g.bias_bs1 : nullptr;
+  const float* R = g.r ? g.r + z0 * g.r_bs0 + z1 * g.r_bs1 : nullptr;
+  const int flags = g.flags;
+  const bool accumulate = (flags & (PETR_GEMM_ACCUMULATE | PETR_GEMM_ATOMIC)) != 0;
+  const int n = n0 + c;
+  const int nc = min(n, g.N - 1);
+  const float bv = bias ? bias[nc] : 0.f;
+  const long ccol = g.c_nblk > 0 ? (long)(nc / g.c_nblk) * g.c_nblk_stride + (nc % g.c_nblk) : (long)nc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + mfma32_row(r, h);
+    const int mc = min(m, g.M - 1);
+    float v = acc[r] * g.alpha + bv;
+    float* dst = C + (long)mc * g.ldc + ccol;
+    const float rv = R ? R[(long)mc * g.ldr + nc] : 0.f;
+    const float old = accumulate ? *dst : 0.f;
+    if (flags & PETR_GEMM_SIGMOID_MUL) v = rv * (1.f / (1.f + expf(-v)));
+    else if (flags & PETR_GEMM_RELU_MASK) v = rv > 0.f ? v : 0.f;
+    else v += rv;
+    if (flags & PETR_GEMM_RELU) v = fmaxf(v, 0.f);
+    v += old;
+    if (m < g.M && n < g.N) *dst = v;
+  }
+}
+
+template <bool VEC>
+int launch_skinny(const petr_gemm_args& g, hipStream_t s) {
+  const int tiles_m = (int)cdiv(g.M, 32), tiles_n = (int)cdiv(g.N, 32);
+  const long tiles = (long)tiles_m * tiles_n * g.nb0 * g.nb1;
+  const int kseg = g.k_seg > 0 ? g.k_seg : g.K;
+  const long chunks = (long)(g.k_seg > 0 ? g.K / g.k_seg : 1) * cdiv(kseg, 32);
+  // enough waves to cover the 1024 SIMDs ~1.5x, but never less than one chunk per wave
+  int nw = 1;
+  while (nw < 8 && tiles * nw < 1536 && chunks >= 2L * nw) nw *= 2;
+  while (nw < 8 && chunks > 8L * nw) nw *= 2;           // keep each wave's MFMA chain short
+  dim3 grid(tiles_m * tiles_n, 1, g.nb0 * g.nb1), block(64 * nw);
+  const size_t lds = (size_t)nw * (1024 + 64) * sizeof(float);
+#define PETR_SKINNY_LAUNCH(AKC, BKC, A2) \
+  hipLaunchKernelGGL((gemm_skinny_kernel<AKC, BKC, VEC, A2>), grid, block, lds, s, g, tiles_n)
+  if (g.a_kcontig && g.b_kcontig) {
+    if (g.a2) PETR_SKINNY_LAUNCH(true, true, true);
+    else PETR_SKINNY_LAUNCH(true, true, false);
+  } else if (g.a_kcontig) {
+    if (g.a2) PETR_SKINNY_LAUNCH(true, false, true);
+    else PETR_SKINNY_LAUNCH(true, false, false);
+  } else if (g.b_kcontig) {
+    PETR_SKINNY_LAUNCH(false, true, false);
+  } else {
+    PETR_SKINNY_LAUNCH(false, false, false);
+  }
+#undef PETR_SKINNY_LAUNCH
+  PETR_LAUNCH_CHECK("gemm_skinny");
+  return PETR_OK;
+}
+
+template <int BM, int BN, int WM, int WN, bool VEC>
+int launch_cfg(const petr_gemm_args& g, hipStream_t s) {
   const int tiles_m = (int)cdiv(g.M, BM), tiles_n = (int)cdiv(g.N, BN);
   dim3 grid(tiles_m * tiles_n, 1, g.nb0 * g.nb1 * g.split_k);
   dim3 block(256);
-#define PETR_GEMM_LAUNCH(AKC, BKC) \
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKC, BKC>), grid, block, 0, s, g, a_vec, b_vec, tiles_m, tiles_n)
-  if (g.a_kcontig && g.b_kcontig) PETR_GEMM_LAUNCH(true, true);
-  else if (g.a_kcontig) PETR_GEMM_LAUNCH(true, false);
-  else if (g.b_kcontig) PETR_GEMM_LAUNCH(false, true);
-  else PETR_GEMM_LAUNCH(false, false);
+#define PETR_GEMM_LAUNCH(AKC, BKC, A2) \
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKC, BKC, VEC, A2>), grid, block, 0, s, g, tiles_m, tiles_n)
+  if (g.a_kcontig && g.b_kcontig) {
+    if (g.a2) PETR_GEMM_LAUNCH(true, true, true);
+    else PETR_GEMM_LAUNCH(true, true, false);
+  } else if (g.a_kcontig) {
+    if (g.a2) PETR_GEMM_LAUNCH(true, false, true);
+    else PETR_GEMM_LAUNCH(true, false, false);
+  } else if (g.b_kcontig) {
+    PETR_GEMM_LAUNCH(false, true, false);
+  } else {
+    PETR_GEMM_LAUNCH(false, false, false);
+  }
 #undef PETR_GEMM_LAUNCH
   PETR_LAUNCH_CHECK("gemm");
   return PETR_OK;
@@ -256,7 +468,7 @@ int launch_cfg(const petr_gemm_args& g, int a_vec, int b_vec, hipStream_t s) {
 
 bool operand_vec_ok(const float* p, long ld, long bs0, long bs1, long seg, int kcontig, int rows, int K) {
   if (!aligned16(p) || (ld & 3) || (bs0 & 3) || (bs1 & 3) || (seg & 3)) return false;
-  // contiguous extent must be a multiple of 4 so that a float4 never straddles the valid edge
+  // contiguous extent must be a multiple of 4 (>= 4) so that a float4 never straddles the valid edge
   return kcontig ? (K % 4 == 0) : (rows % 4 == 0);
 }
 
@@ -280,14 +492,27 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
   PETR_CHECK((long)g.nb0 * g.nb1 * g.split_k <= 65535, PETR_ERR_UNSUPPORTED, "gemm: too many batches");
   PETR_CHECK(g.k_seg <= 0 || g.K % g.k_seg == 0, PETR_ERR_INVALID, "gemm: K=%d is not a multiple of k_seg=%d", g.K, g.k_seg);
   const int kseg = g.k_seg > 0 ? g.k_seg : g.K;
-  const int a_vec = operand_vec_ok(g.a, g.lda, g.a_bs0, g.a_bs1, g.a_seg_stride, g.a_kcontig, g.M, kseg) &&
-                    (!g.a2 || aligned16(g.a2));
-  const int b_vec = operand_vec_ok(g.b, g.ldb, g.b_bs0, g.b_bs1, g.b_seg_stride, g.b_kcontig, g.N, kseg);
+  const bool vec = operand_vec_ok(g.a, g.lda, g.a_bs0, g.a_bs1, g.a_seg_stride, g.a_kcontig, g.M, kseg) &&
+                   (!g.a2 || aligned16(g.a2)) &&
+                   operand_vec_ok(g.b, g.ldb, g.b_bs0, g.b_bs1, g.b_seg_stride, g.b_kcontig, g.N, kseg);
   hipStream_t s = (hipStream_t)stream;
+  // Few output tiles AND a long contraction: the latency-optimised kernel (K split inside the workgroup, no
+  // LDS staging, no atomics).  It re-reads operands once per tile row/column, so it only pays while the
+  // output is small (<= 256 tiles of 32x32: 900x256, 256x256, 256x10 ...); measured on MI355X it ties the
+  // tiled kernel at K = 256 and is 2x faster at K >= 1024 for K-contiguous operands (float4 fragment loads);
+  // with row-contiguous operands (gradients) its 4-byte loads lose to the tiled kernel.  Slabs stay tiled.
+  const long tiles32 = cdiv(g.M, 32) * cdiv(g.N, 32) * (long)g.nb0 * g.nb1;
+  const bool slabs = g.split_k > 1 && !(g.flags & PETR_GEMM_ATOMIC);
+  if (!slabs && tiles32 <= 256 && g.K >= 512 && g.a_kcontig && g.b_kcontig && !(g.flags & PETR_GEMM_ATOMIC)) {
+    petr_gemm_args q = g;
+    q.split_k = 1;
+    return vec ? launch_skinny<true>(q, s) : launch_skinny<false>(q, s);
+  }
+  if (!vec) return launch_cfg<64, 64, 32, 32, false>(g, s);   // generic scalar-load path (odd shapes)
   const long nz = (long)g.nb0 * g.nb1 * g.split_k;
   const long b128 = cdiv(g.M, 128) * cdiv(g.N, 128) * nz;
   const long b12864 = cdiv(g.M, 128) * cdiv(g.N, 64) * nz;
-  if (b128 >= 384 && g.N > 64) return launch_cfg<128, 128, 64, 64>(g, a_vec, b_vec, s);
-  if (b12864 >= 256 && g.N > 32) return launch_cfg<128, 64, 64, 32>(g, a_vec, b_vec, s);
-  return launch_cfg<64, 64, 32, 32>(g, a_vec, b_vec, s);
+  if (b128 >= 384 && g.N > 64) return launch_cfg<128, 128, 64, 64, true>(g, s);
+  if (b12864 >= 256 && g.N > 32) return launch_cfg<128, 64, 64, 32, true>(g, s);
+  return launch_cfg<64, 64, 32, 32, true>(g, s);
 }

@@ -306,7 +306,7 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
   const long wide = d.BQ * (d.F > 3 * C ? d.F : 3 * C);
   W.ga = wb.add("ga", d.R * C > wide ? d.R * C : wide);
   W.gb = wb.add("gb", d.R * C > wide ? d.R * C : wide);
-  W.gc = wb.add("gc", d.R * C);
+  W.gc = wb.add("gc", d.R * C > 4 * d.BQ * C ? d.R * C : 4 * d.BQ * C);
   W.gd = wb.add("gd", d.R * C);
   W.d_mempos = wb.add("d_mempos", d.BL * C);
   W.d_mem = wb.add("d_mem", d.BL * C);
@@ -385,9 +385,11 @@ static int ln_fwd(const float* x, int np, long pstride, const float* bias, const
 }
 
 static int ln_bwd(const float* z, const float* mean, const float* rstd, const float* g, const float* dy, const float* y,
-                  float* dz, float* dg, float* db, long M, int C, int flags, int accumulate, void* s) {
+                  float* dz, float* dg, float* db, long M, int C, int flags, int accumulate, void* s, int dy_partials = 1,
+                  long dy_pstride = 0, const float* dy_res = nullptr) {
   petr_layernorm_bwd_args a;
   memset(&a, 0, sizeof a);
+  a.dy_partials = dy_partials; a.dy_partial_stride = dy_pstride; a.dy_residual = dy_res;
   a.z = z; a.mean = mean; a.rstd = rstd; a.gamma = g; a.dy = dy; a.y = y; a.dz = dz; a.dgamma = dg; a.dbeta = db;
   a.ws = nullptr; a.M = (int)M; a.C = C; a.flags = flags; a.dz_accumulate = accumulate;
   return petr_layernorm_bwd(&a, s);
@@ -763,14 +765,18 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       RUN(petr_gemm(&g, s));
       g = lin_wgrad(d_h, d.F, Wm + lw.x2, C, Gp + lp.f1_w, Gp + lp.f1_b, d.BQ, d.F, C);
       RUN(petr_gemm(&g, s));
+      // d_x2 = d_h @ W1 + d_z2 (identity path): K = F is long and there are only BQ/64 x 4 output tiles, so the
+      // contraction is split over K into slabs that the LayerNorm backward sums in its prologue
       float* d_x2 = Wm + W.gc;
+      const int sk = W.ffn_split;
       g = lin_dgrad(d_h, Pm + lp.f1_w, d_x2, d.BQ, d.F, C);
-      g.r = d_z2; g.ldr = C;                                    // + identity path
+      if (sk > 1) { g.split_k = sk; g.c_split_stride = d.BQ * C; }
+      else { g.r = d_z2; g.ldr = C; }
       RUN(petr_gemm(&g, s));
       // LN1 / cross-attention
-      float* d_z1 = Wm + W.ga;
+      float* d_z1 = Wm + W.gd;
       RUN(ln_bwd(Wm + lw.z1, Wm + lw.mean1, Wm + lw.rstd1, Pm + lp.n_g[1], d_x2, nullptr, d_z1, Gp + lp.n_g[1],
-                 Gp + lp.n_b[1], d.BQ, C, 0, 0, s));
+                 Gp + lp.n_b[1], d.BQ, C, 0, 0, s, sk, d.BQ * C, sk > 1 ? d_z2 : nullptr));
       g = lin_wgrad(d_z1, C, Wm + lw.ao_c, C, Gp + lp.ca_out_w, Gp + lp.ca_out_b, d.BQ, C, C);
       RUN(petr_gemm(&g, s));
       float* d_ao = Wm + W.gb;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(const petr_mha_bwd_args 
   if (d4 == 0) delta[row] = s;
 }
 
-template <bool HAS_MASK>
+template <bool HAS_MASK, bool VEC>
 __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
   __shared__ __attribute__((aligned(16))) float Qs[32 * P33];
   __shared__ __attribute__((aligned(16))) float dOs[32 * P33];
@@ -87,9 +87,10 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
     const float* ks = kp + (long)key_ld * a.k_rs + 16 * h;
     const float* vs = vp + (long)key_ld * a.v_rs + 16 * h;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      kf[i] = key_ok ? ks[i] : 0.f;
-      vf[i] = key_ok ? vs[i] : 0.f;
+    for (int i = 0; i < 16; ++i) {   // unconditional loads (clamped row) + select
+      const float kx = ks[i], vx = vs[i];
+      kf[i] = key_ok ? kx : 0.f;
+      vf[i] = key_ok ? vx : 0.f;
     }
   }
   // K also in LDS, natural [key][d], as the B operand of the dQ product (lane = d)
@@ -98,12 +99,11 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
     const int idx = t + 256 * i;
     const int kr = idx >> 3, c4 = idx & 7;
     const int kg = kb * 128 + kr;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kg < a.L) {
-      const float* s = kp + (long)kg * a.k_rs + 4 * c4;
-      v = make_float4(s[0], s[1], s[2], s[3]);
-    }
-    *reinterpret_cast<float4*>(Ks + kr * 32 + 4 * c4) = v;
+    const float* s = kp + (long)min(kg, a.L - 1) * a.k_rs + 4 * c4;
+    const bool ok = kg < a.L;
+    const float4 v = make_float4(s[0], s[1], s[2], s[3]);
+    *reinterpret_cast<float4*>(Ks + kr * 32 + 4 * c4) =
+        make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
   }
   float key_bias = key_ok ? 0.f : -INFINITY;
   if (HAS_MASK && key_ok && a.kpm[(long)b * a.L + key]) key_bias = -INFINITY;
@@ -123,23 +123,27 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
   float lreg = 0.f, dreg = 0.f;
   auto gload = [&](int qt) {
     const int row = qt * 32 + (t >> 3), c4 = t & 7;
-    qreg = greg = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < a.Q) {
-      const float* s = qp + (long)row * a.q_rs + 4 * c4;
-      const float* g = gp + (long)row * a.do_rs + 4 * c4;
-      if (p.vec) {
-        qreg = *reinterpret_cast<const float4*>(s);
-        greg = *reinterpret_cast<const float4*>(g);
-      } else {
-        qreg = make_float4(s[0], s[1], s[2], s[3]);
-        greg = make_float4(g[0], g[1], g[2], g[3]);
-      }
+    const int rowc = min(row, a.Q - 1);
+    const float* s = qp + (long)rowc * a.q_rs + 4 * c4;
+    const float* g = gp + (long)rowc * a.do_rs + 4 * c4;
+    float4 qv, gv;
+    if (VEC) {
+      qv = *reinterpret_cast<const float4*>(s);
+      gv = *reinterpret_cast<const float4*>(g);
+    } else {
+      qv = make_float4(s[0], s[1], s[2], s[3]);
+      gv = make_float4(g[0], g[1], g[2], g[3]);
     }
-    if (t < 32) {
-      const int r = qt * 32 + t;
+    const bool ok = row < a.Q;
+    qreg = make_float4(ok ? qv.x : 0.f, ok ? qv.y : 0.f, ok ? qv.z : 0.f, ok ? qv.w : 0.f);
+    greg = make_float4(ok ? gv.x : 0.f, ok ? gv.y : 0.f, ok ? gv.z : 0.f, ok ? gv.w : 0.f);
+    {
+      const int r = qt * 32 + (t & 31);
+      const int rc = min(r, a.Q - 1);
+      const float lv = a.lse[(long)bh * a.Q + rc], dv = p.delta[(long)bh * a.Q + rc];
       // rows beyond Q: -LSE/scale = -inf  =>  p = 0
-      lreg = r < a.Q ? -a.lse[(long)bh * a.Q + r] * inv_scale : -INFINITY;
-      dreg = r < a.Q ? -p.delta[(long)bh * a.Q + r] : 0.f;
+      lreg = r < a.Q ? -lv * inv_scale : -INFINITY;
+      dreg = r < a.Q ? -dv : 0.f;
     }
   };
 
@@ -281,8 +285,13 @@ extern "C" int petr_mha_bwd(const petr_mha_bwd_args* ap, void* stream) {
   const long total = (long)p.nkb * a.B * a.H * p.q_splits;
   PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_bwd: grid too large");
   const int rec = petr_prof_open_record(PETR_PROF_MHA_BWD + 16 * (a.L > a.Q ? 1 : 0), stream);
-  if (a.kpm) hipLaunchKernelGGL(mha_bwd_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(mha_bwd_kernel<false>, dim3((unsigned)total), dim3(256), 0, s, p);
+  if (a.kpm) {
+    if (p.vec) hipLaunchKernelGGL((mha_bwd_kernel<true, true>), dim3((unsigned)total), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((mha_bwd_kernel<true, false>), dim3((unsigned)total), dim3(256), 0, s, p);
+  } else {
+    if (p.vec) hipLaunchKernelGGL((mha_bwd_kernel<false, true>), dim3((unsigned)total), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((mha_bwd_kernel<false, false>), dim3((unsigned)total), dim3(256), 0, s, p);
+  }
   petr_prof_close_record(rec, stream);
   PETR_LAUNCH_CHECK("mha_bwd");
   return PETR_OK;

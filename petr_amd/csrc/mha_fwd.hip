@@ -36,7 +36,7 @@ struct MhaFwdParams {
   int q_vec, kv_vec;
 };
 
-template <bool HAS_MASK>
+template <bool HAS_MASK, bool VEC>
 __global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   __shared__ __attribute__((aligned(16))) float Kt[32 * KT_PITCH];
   __shared__ __attribute__((aligned(16))) float Vs[KV_TILE * 32];
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   const int h = lane >> 5, c = lane & 31;
   const int q_row = qb * 128 + wave * 32 + c;
   const int q_ld = min(q_row, a.Q - 1);
+  const bool wave_active = qb * 128 + wave * 32 < a.Q;
 
   const int k_begin = split * p.tiles_per_split * KV_TILE;
   const int k_end = min(a.L, k_begin + p.tiles_per_split * KV_TILE);
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   {
     const float* qp = a.q + (long)b * a.q_bs + (long)hd * a.q_hs + (long)q_ld * a.q_rs + 16 * h;
     const float sc = a.scale * LOG2E;
-    if (p.q_vec) {
+    if (VEC) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float4 v = reinterpret_cast<const float4*>(qp)[i];
@@ -82,30 +83,35 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
 
   float4 kreg[2], vreg[2];
   float breg = 0.f;
+  // unconditional loads from clamped addresses + select (a load under an exec-masked branch is waited for
+  // at the end of the branch, which would serialise the four tile loads)
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = t + 256 * i;
       const int kg = k0 + (idx >> 3), c4 = idx & 7;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-      if (kg < k_end) {
-        const float* ks = kp + (long)kg * a.k_rs + 4 * c4;
-        const float* vs = vp + (long)kg * a.v_rs + 4 * c4;
-        if (p.kv_vec) {
-          kv = *reinterpret_cast<const float4*>(ks);
-          vv = *reinterpret_cast<const float4*>(vs);
-        } else {
-          kv = make_float4(ks[0], ks[1], ks[2], ks[3]);
-          vv = make_float4(vs[0], vs[1], vs[2], vs[3]);
-        }
+      const int kgc = min(kg, a.L - 1);
+      const float* ks = kp + (long)kgc * a.k_rs + 4 * c4;
+      const float* vs = vp + (long)kgc * a.v_rs + 4 * c4;
+      float4 kv, vv;
+      if (VEC) {
+        kv = *reinterpret_cast<const float4*>(ks);
+        vv = *reinterpret_cast<const float4*>(vs);
+      } else {
+        kv = make_float4(ks[0], ks[1], ks[2], ks[3]);
+        vv = make_float4(vs[0], vs[1], vs[2], vs[3]);
       }
-      kreg[i] = kv;
-      vreg[i] = vv;
+      const bool ok = kg < k_end;
+      kreg[i] = make_float4(ok ? kv.x : 0.f, ok ? kv.y : 0.f, ok ? kv.z : 0.f, ok ? kv.w : 0.f);
+      vreg[i] = make_float4(ok ? vv.x : 0.f, ok ? vv.y : 0.f, ok ? vv.z : 0.f, ok ? vv.w : 0.f);
     }
-    if (t < KV_TILE) {
-      const int kg = k0 + t;
+    {
+      const int kg = k0 + (t & (KV_TILE - 1));
       bool dead = kg >= k_end;
-      if (HAS_MASK && !dead) dead = mp[kg] != 0;
+      if (HAS_MASK) {
+        const uint8_t mb = mp[min(kg, a.L - 1)];
+        dead = dead || mb != 0;
+      }
       breg = dead ? -INFINITY : 0.f;
     }
   };
@@ -136,15 +142,25 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
     __syncthreads();
     if (k0 + KV_TILE < k_end) gload(k0 + KV_TILE);
     const bool use_bias = HAS_MASK || (k0 + KV_TILE > k_end);
+    if (!wave_active) continue;            // wave-uniform: a wave whose 32 queries are all padding only stages K/V
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       if (k0 + sub * 32 >= k_end) break;   // uniform: whole sub-tile beyond the slice
+      // all 16 K fragments are requested before the first MFMA so that one LDS latency, not sixteen,
+      // sits in front of the dependent MFMA chain (the compiler otherwise emits read->wait->2 MFMA)
+      float kfr[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) kfr[s] = Kt[(16 * h + s) * KT_PITCH + sub * 32 + c];
+      __builtin_amdgcn_sched_barrier(0);
       f32x16 S;
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-        S = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[(16 * h + s) * KT_PITCH + sub * 32 + c], qf[s], S, 0, 0, 0);
+      for (int s = 0; s < 16; ++s) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kfr[s], qf[s], S, 0, 0, 0);
+      // V fragments: requested now, consumed after the softmax (their latency hides under its VALU work)
+      float vfr[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) vfr[s] = Vs[(sub * 32 + mfma32_row(s, h)) * 32 + c];
       if (use_bias) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] += bias_s[sub * 32 + mfma32_row(r, h)];
@@ -168,8 +184,7 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[r] *= alpha;
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-        O = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(sub * 32 + mfma32_row(s, h)) * 32 + c], S[s], O, 0, 0, 0);
+      for (int s = 0; s < 16; ++s) O = __builtin_amdgcn_mfma_f32_32x32x2f32(vfr[s], S[s], O, 0, 0, 0);
     }
   }
 
@@ -282,8 +297,14 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
   const long total = (long)p.nqb * a.B * a.H * ns;
   PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_fwd: grid too large");
   const int rec = petr_prof_open_record(PETR_PROF_MHA_FWD + 16 * (a.L > a.Q ? 1 : 0), stream);
-  if (a.kpm) hipLaunchKernelGGL(mha_fwd_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(mha_fwd_kernel<false>, dim3((unsigned)total), dim3(256), 0, s, p);
+  const bool vec = p.q_vec && p.kv_vec;
+  if (a.kpm) {
+    if (vec) hipLaunchKernelGGL((mha_fwd_kernel<true, true>), dim3((unsigned)total), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((mha_fwd_kernel<true, false>), dim3((unsigned)total), dim3(256), 0, s, p);
+  } else {
+    if (vec) hipLaunchKernelGGL((mha_fwd_kernel<false, true>), dim3((unsigned)total), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((mha_fwd_kernel<false, false>), dim3((unsigned)total), dim3(256), 0, s, p);
+  }
   petr_prof_close_record(rec, stream);
   PETR_LAUNCH_CHECK("mha_fwd");
   if (ns > 1) {

@@ -114,6 +114,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(petr_layernorm_bwd_a
       if (i4 < nv) {
         const float4 z = reinterpret_cast<const float4*>(a.z + (size_t)row * a.C)[i4];
         float4 dy = reinterpret_cast<const float4*>(a.dy + (size_t)row * a.C)[i4];
+        for (int p = 1; p < a.dy_partials; ++p) {   // split-K slabs of the producing contraction
+          const float4 t = reinterpret_cast<const float4*>(a.dy + (size_t)p * a.dy_partial_stride + (size_t)row * a.C)[i4];
+          dy.x += t.x; dy.y += t.y; dy.z += t.z; dy.w += t.w;
+        }
+        if (a.dy_residual) {
+          const float4 t = reinterpret_cast<const float4*>(a.dy_residual + (size_t)row * a.C)[i4];
+          dy.x += t.x; dy.y += t.y; dy.z += t.z; dy.w += t.w;
+        }
         if (a.flags & PETR_LN_RELU) {
           const float4 y = reinterpret_cast<const float4*>(a.y + (size_t)row * a.C)[i4];
           dy.x = y.x > 0.f ? dy.x : 0.f; dy.y = y.y > 0.f ? dy.y : 0.f;

@@ -9,6 +9,12 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
+try:  # the CPU oracle: use the box's CPU share, not the host's core count (oversubscription crawls)
+    import torch
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+except Exception:  # noqa: BLE001
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')

@@ -90,31 +90,56 @@ def test_head_c5_forward_and_intermediates(pa):
     del L
 
 
+def _oracle_grads(oracle, feats, metas, g_cls, g_box, dtype):
+    """fwd+bwd of the oracle in `dtype` (float64 = yardstick that separates fp32 noise from disagreement)."""
+    import copy
+    o = copy.deepcopy(oracle).to(dtype)
+    f = feats.to(dtype).clone().requires_grad_(True)
+    torch.set_default_dtype(dtype)
+    try:
+        out = o([f], metas)
+        (out['all_cls_scores'] * g_cls.to(dtype)).sum().add((out['all_bbox_preds'] * g_box.to(dtype)).sum()).backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return out, {k: p.grad for k, p in o.named_parameters() if p.grad is not None}, f.grad
+
+
 def _grad_case(pa, B, N, H, W, pad_hw, img_hw, Q, seed):
+    """Gradients vs the float64 oracle.  Two metrics per tensor, both relative to max(|want|_inf, 1e-4*global):
+    L2 (tight) and max-abs (loose): a ReLU whose pre-activation sits within 1e-7 of zero flips its mask
+    between ANY two fp32 evaluations (the CPU fp32 oracle shows the same O(1e-2) single-element jumps against
+    float64), so max-abs cannot be tight; tensors whose true gradient is identically zero (softmax shift
+    invariance: position_encoder/adapt_pos3d last bias; layer-0 self-attention in_proj with query = 0) are
+    checked absolutely."""
     oracle = O.seeded_head(seed, 77, num_query=Q)
     head = make_pair(pa, oracle, num_query=Q)
-    oracle.train(False)
     metas = O.synthetic_img_metas(B, N, pad_hw, img_hw, seed=seed)
     g = torch.Generator().manual_seed(seed)
     feats = torch.randn(B, N, 256, H, W, generator=g)
     g_cls, g_box = torch.randn(6, B, Q, 10, generator=g), torch.randn(6, B, Q, 10, generator=g)
-    fo = feats.clone().requires_grad_(True)
-    want = oracle([fo], metas)
-    (want['all_cls_scores'] * g_cls).sum().add((want['all_bbox_preds'] * g_box).sum()).backward()
+    want, wgrads, wfeat = _oracle_grads(oracle, feats, metas, g_cls, g_box, torch.float64)
     fg = feats.cuda().requires_grad_(True)
     got = head([fg], metas)
     torch.autograd.backward([got['all_cls_scores'], got['all_bbox_preds']], [g_cls.cuda(), g_box.cuda()])
     assert rel(got['all_cls_scores'], want['all_cls_scores']) < REL
-    assert rel(fg.grad, fo.grad) < 2e-3
-    worst = {}
-    op = dict(oracle.named_parameters())
+    assert rel(got['all_bbox_preds'], want['all_bbox_preds']) < REL
+    gmax = max(v.abs().max().item() for v in wgrads.values())
+
+    def errs(a, b):
+        a, b = a.detach().double().cpu(), b.double()
+        sc = max(b.abs().max().item(), 1e-4 * gmax)
+        return (a - b).norm().item() / max(b.norm().item(), sc), (a - b).abs().max().item() / sc
+    l2, mx = errs(fg.grad, wfeat)
+    assert l2 < 5e-3 and mx < 5e-2, f'd_feats: l2 {l2:.2e} max {mx:.2e}'
+    bad = {}
     for name, p in head.named_parameters():
         if not p.requires_grad:
             continue
         assert p.grad is not None, name
-        worst[name] = rel(p.grad, op[name].grad)
-    bad = {k: v for k, v in worst.items() if v > 2e-3}
-    assert not bad, f'gradient mismatch: {sorted(bad.items(), key=lambda kv: -kv[1])[:8]}'
+        l2, mx = errs(p.grad, wgrads[name])
+        if l2 > 5e-3 or mx > 5e-2:
+            bad[name] = (round(l2, 5), round(mx, 5))
+    assert not bad, f'gradient mismatch (l2, max): {sorted(bad.items(), key=lambda kv: -kv[1][0])[:8]}'
     return head, metas, feats, (g_cls, g_box)
 
 

@@ -277,6 +277,17 @@ typedef struct {
   int training;                 /* 1: keep what backward needs                              */
 } petr_head_config;
 
+/* Execution context: a few side HIP streams + an event ring, so that work off the critical path
+ * (weight-gradient contractions, the position-embedding branch, the second box branch) runs
+ * concurrently with the dependent chain of small decoder kernels that otherwise leaves most of the 256
+ * CUs idle at B=1.  Created/destroyed by the host (the only allocating calls of the library); passing
+ * ctx = NULL in petr_head_io serialises everything on the caller's stream with identical results
+ * (up to float-atomic ordering in the gradients).  Fork/join are plain event record/wait pairs, so the
+ * calls remain capturable into a hipGraph.                                                        */
+typedef struct petr_ctx petr_ctx;
+int petr_ctx_create(petr_ctx** out, int n_side_streams);
+int petr_ctx_destroy(petr_ctx* ctx);
+
 #define PETR_MAX_PARAMS 512
 typedef struct {
   int count;
@@ -300,6 +311,7 @@ typedef struct {
   float* all_cls_scores;        /* [num_layers,B,Q,num_classes]                            */
   float* all_bbox_preds;        /* [num_layers,B,Q,code_size]                              */
   void* ws; size_t ws_bytes;    /* activations + scratch (petr_head_workspace_bytes)       */
+  void* ctx;                    /* petr_ctx* (side streams) or NULL: everything on `stream` */
 } petr_head_io;
 size_t petr_head_workspace_bytes(const petr_head_config* cfg);
 int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io, void* stream);

@@ -123,7 +123,7 @@ class HeadIO(C.Structure):
     _fields_ = _fields(('params', C.c_void_p), ('feats', C.c_void_p), ('img2lidar', C.c_void_p), ('depth', C.c_void_p),
                        ('dim_t', C.c_void_p), ('mask', C.c_void_p), ('time_div', C.c_float),
                        ('all_cls_scores', C.c_void_p), ('all_bbox_preds', C.c_void_p),
-                       ('ws', C.c_void_p), ('ws_bytes', C.c_size_t))
+                       ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('ctx', C.c_void_p))
 
 
 class HeadGrads(C.Structure):
@@ -178,6 +178,8 @@ def lib():
     missing = [n for n in EXPORTS if not hasattr(L, n)]
     if missing:
         raise PetrHipError(f'{LIB_PATH} is stale: missing exports {missing}; rebuild it')
+    L.petr_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.petr_ctx_destroy.argtypes = [C.c_void_p]
     L.petr_head_layout.argtypes = [C.POINTER(HeadConfig), C.POINTER(HeadLayout)]
     L.petr_head_workspace_bytes.argtypes = [C.POINTER(HeadConfig)]
     L.petr_head_workspace_bytes.restype = C.c_size_t
@@ -199,6 +201,7 @@ EXPORTS = [
     'petr_mha_bwd', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows', 'petr_prof_begin', 'petr_prof_end',
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
+    'petr_ctx_create', 'petr_ctx_destroy',
 ]
 
 

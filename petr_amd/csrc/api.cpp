@@ -85,3 +85,32 @@ extern "C" int petr_prof_end(float* ms, int* tags, int cap, int* n_out) {
   *n_out = n;
   return PETR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Execution context: side streams + event ring (see petr_hip.h).
+// ---------------------------------------------------------------------------------------------
+extern "C" int petr_ctx_create(petr_ctx** out, int n_side_streams) {
+  PETR_CHECK(out && n_side_streams >= 1 && n_side_streams <= PETR_CTX_MAX_SIDE, PETR_ERR_INVALID,
+             "ctx_create: 1..%d side streams", PETR_CTX_MAX_SIDE);
+  petr_ctx* c = new petr_ctx();
+  c->n_side = n_side_streams;
+  c->next_event = 0;
+  for (int i = 0; i < n_side_streams; ++i) {
+    hipError_t e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
+    PETR_CHECK(e == hipSuccess, PETR_ERR_LAUNCH, "ctx_create: hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  for (int i = 0; i < PETR_CTX_EVENTS; ++i) {
+    hipError_t e = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming);
+    PETR_CHECK(e == hipSuccess, PETR_ERR_LAUNCH, "ctx_create: hipEventCreate: %s", hipGetErrorString(e));
+  }
+  *out = c;
+  return PETR_OK;
+}
+
+extern "C" int petr_ctx_destroy(petr_ctx* c) {
+  if (!c) return PETR_OK;
+  for (int i = 0; i < c->n_side; ++i) (void)hipStreamDestroy(c->side[i]);
+  for (int i = 0; i < PETR_CTX_EVENTS; ++i) (void)hipEventDestroy(c->ev[i]);
+  delete c;
+  return PETR_OK;
+}

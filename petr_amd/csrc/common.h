@@ -18,6 +18,47 @@ enum { PETR_PROF_MHA_FWD = 1, PETR_PROF_MHA_BWD = 2, PETR_PROF_GEMM = 3, PETR_PR
 int petr_prof_open_record(int tag, void* stream);
 void petr_prof_close_record(int rec, void* stream);
 
+// execution context (side streams + event ring), owned by the host through petr_ctx_create/destroy
+#define PETR_CTX_MAX_SIDE 4
+#define PETR_CTX_EVENTS 512
+struct petr_ctx {
+  int n_side;
+  int next_event;
+  hipStream_t side[PETR_CTX_MAX_SIDE];
+  hipEvent_t ev[PETR_CTX_EVENTS];
+};
+
+// fork/join helper: with ctx == nullptr every side stream IS the main stream and fork/join are no-ops
+struct Lanes {
+  hipStream_t main;
+  petr_ctx* ctx;
+  void* m() const { return (void*)main; }
+  void* side(int i) const { return ctx ? (void*)ctx->side[i % ctx->n_side] : (void*)main; }
+  hipEvent_t next() const {
+    hipEvent_t e = ctx->ev[ctx->next_event];
+    ctx->next_event = (ctx->next_event + 1) % PETR_CTX_EVENTS;
+    return e;
+  }
+  // side stream i starts after everything enqueued on main so far
+  void fork(int i) const {
+    if (!ctx) return;
+    hipEvent_t e = next();
+    (void)hipEventRecord(e, main);
+    (void)hipStreamWaitEvent(ctx->side[i % ctx->n_side], e, 0);
+  }
+  // main continues after everything enqueued on side stream i so far
+  void join(int i) const {
+    if (!ctx) return;
+    hipEvent_t e = next();
+    (void)hipEventRecord(e, ctx->side[i % ctx->n_side]);
+    (void)hipStreamWaitEvent(main, e, 0);
+  }
+  void join_all() const {
+    if (!ctx) return;
+    for (int i = 0; i < ctx->n_side; ++i) join(i);
+  }
+};
+
 #define PETR_CHECK(cond, code, ...)     \
   do {                                  \
     if (!(cond)) {                      \

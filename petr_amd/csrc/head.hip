@@ -208,17 +208,21 @@ struct WOff {
   // ---- backward scratch ----
   long zero_begin, zero_end;     // cleared once per backward (atomic / += targets)
   long d_qc, d_qkv, dk_all, dv_all, d_ref_tmp;
-  long d_outs, d_xs, ga, gb, gc, gd, d_mempos, d_mem, d_hpe, d_e_slab, d_e, d_qe_h, d_posemb;
+  long d_outs, d_xs, d_mempos, d_mem, d_hpe[2], d_e_slab, d_e, d_qe_h, d_posemb;
+  // private gradient scratch (never reused inside one backward, so weight-gradient contractions can run on
+  // side streams long after the critical path has moved on)
+  long s0_raw, s0_r2, s0_r1, s0_c2n, s0_c2, s0_c1n, s0_c1;
+  struct LayerG { long d_z2, d_h, d_x2, d_z1, d_ao, d_x1, d_z0, d_ao_s; } lg[8];
   long total;
 };
 
 struct WsBuilder {
   long cur = 0;
-  struct Entry { const char* name; long off, n; } table[256];
+  struct Entry { const char* name; long off, n; } table[384];
   int count = 0;
   long add(const char* name, long n) {
     const long off = cur;
-    if (count < 256) table[count++] = {name, off, n};
+    if (count < 384) table[count++] = {name, off, n};
     cur = align4(cur + n);
     return off;
   }
@@ -303,14 +307,28 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
   W.zero_end = wb.cur;
   W.d_outs = wb.add("d_outs", d.R * C);
   W.d_xs = wb.add("d_xs", d.R * C);
-  const long wide = d.BQ * (d.F > 3 * C ? d.F : 3 * C);
-  W.ga = wb.add("ga", d.R * C > wide ? d.R * C : wide);
-  W.gb = wb.add("gb", d.R * C > wide ? d.R * C : wide);
-  W.gc = wb.add("gc", d.R * C > 4 * d.BQ * C ? d.R * C : 4 * d.BQ * C);
-  W.gd = wb.add("gd", d.R * C);
+  W.s0_raw = wb.add("s0_raw", d.R * d.code);
+  W.s0_r2 = wb.add("s0_r2", d.R * C);
+  W.s0_r1 = wb.add("s0_r1", d.R * C);
+  W.s0_c2n = wb.add("s0_c2n", d.R * C);
+  W.s0_c2 = wb.add("s0_c2", d.R * C);
+  W.s0_c1n = wb.add("s0_c1n", d.R * C);
+  W.s0_c1 = wb.add("s0_c1", d.R * C);
+  for (int l = 0; l < d.NL; ++l) {
+    WOff::LayerG& g = W.lg[l];
+    g.d_z2 = wb.add("g_d_z2", d.BQ * C);
+    g.d_h = wb.add("g_d_h", d.BQ * d.F);
+    g.d_x2 = wb.add("g_d_x2", (long)W.ffn_split * d.BQ * C);
+    g.d_z1 = wb.add("g_d_z1", d.BQ * C);
+    g.d_ao = wb.add("g_d_ao", d.BQ * C);
+    g.d_x1 = wb.add("g_d_x1", d.BQ * C);
+    g.d_z0 = wb.add("g_d_z0", d.BQ * C);
+    g.d_ao_s = wb.add("g_d_ao_s", d.BQ * C);
+  }
   W.d_mempos = wb.add("d_mempos", d.BL * C);
   W.d_mem = wb.add("d_mem", d.BL * C);
-  W.d_hpe = wb.add("d_hpe", d.BL * 4 * C);
+  W.d_hpe[0] = wb.add("d_hpe", d.BL * 4 * C);
+  W.d_hpe[1] = wb.add("d_hpe", d.BL * 4 * C);
   W.d_e_slab = wb.add("d_e_slab", (long)d.NL * d.BQ * C);
   W.d_e = wb.add("d_e", (long)d.Q * C);
   W.d_qe_h = wb.add("d_qe_h", (long)d.Q * C);
@@ -498,7 +516,7 @@ extern "C" int petr_head_bwd_stage_range(const petr_head_config* cfg, int stage,
 // =============================================================================================
 // forward
 // =============================================================================================
-extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io, void* s) {
+extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io, void* stream) {
   RUN(check_config(cfg));
   PETR_CHECK(io && io->params && io->feats && io->img2lidar && io->depth && io->dim_t && io->all_cls_scores &&
                  io->all_bbox_preds && io->ws,
@@ -517,19 +535,36 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   float* Wm = (float*)io->ws;
   const int C = d.C;
   const uint8_t* kpm = cfg->has_mask ? io->mask : nullptr;
-
-  // ---- query embedding: pos2posemb3d + MLP (petr_head.py:422-423) ----
-  RUN(petr_posemb3d_fwd(Pm + P.ref, io->dim_t, Wm + W.posemb, d.Q, C / 2, s));
-  {
-    petr_gemm_args g = lin_fwd(Wm + W.posemb, Pm + P.qe_w1, Pm + P.qe_b1, Wm + W.qe_h, d.Q, C, C * 3 / 2);
-    g.flags = PETR_GEMM_RELU;
-    RUN(petr_gemm(&g, s));
-    g = lin_fwd(Wm + W.qe_h, Pm + P.qe_w2, Pm + P.qe_b2, Wm + W.qe, d.Q, C, C);
-    RUN(petr_gemm(&g, s));
-  }
+  const Lanes ln{(hipStream_t)stream, (petr_ctx*)io->ctx};
+  void* s = ln.m();        // critical path
+  void* s1 = ln.side(0);   // position-embedding branch A (coords3d MLP) / K projection / reg branch
+  void* s2 = ln.side(1);   // position-embedding branch B (sine MLP, input_proj) / V projection
+  const int V = d.B * d.N;
   const float* E = Wm + W.qe;
 
-  // ---- 3D position embedding (petr_head.py:286-334) + sine 3D (positional_encoding.py:58-100) ----
+  ln.fork(0);
+  ln.fork(1);
+  // ---- side 2: input_proj (petr_head.py:390) + sine 3D (positional_encoding.py:58-100) + adapt_pos3d hidden ----
+  {
+    petr_gemm_args g = gemm0();   // NCHW view [C_in][HW] read as an M-contiguous operand -> token-major memory
+    g.a = io->feats; g.lda = d.HW; g.a_kcontig = 0; g.a_bs0 = (long)d.Cin * d.HW;
+    g.b = Pm + P.in_w; g.ldb = d.Cin; g.b_kcontig = 1;
+    g.c = Wm + W.mem; g.ldc = C; g.c_bs0 = (long)d.HW * C; g.bias = Pm + P.in_b;
+    g.M = d.HW; g.N = C; g.K = d.Cin; g.nb0 = V;
+    RUN(petr_gemm(&g, s2));
+    petr_sine3d_args b;
+    memset(&b, 0, sizeof b);
+    b.mask = kpm; b.dim_t = io->dim_t; b.out = Wm + W.sine; b.B = d.B; b.N = d.N; b.H = d.H; b.W = d.W; b.F = C / 2;
+    b.normalize = 1; b.scale = 6.283185307179586f; b.eps = 1e-6f; b.offset = 0.f;
+    RUN(petr_sine3d_fwd(&b, s2));
+    g = gemm0();
+    g.a = Wm + W.sine; g.lda = d.HW; g.a_kcontig = 0; g.a_bs0 = (long)(C * 3 / 2) * d.HW;
+    g.b = Pm + P.ad_w1; g.ldb = C * 3 / 2; g.b_kcontig = 1;
+    g.c = Wm + W.h2; g.ldc = 4 * C; g.c_bs0 = (long)d.HW * 4 * C; g.bias = Pm + P.ad_b1;
+    g.M = d.HW; g.N = 4 * C; g.K = C * 3 / 2; g.nb0 = V; g.flags = PETR_GEMM_RELU;
+    RUN(petr_gemm(&g, s2));
+  }
+  // ---- side 1: 3D position embedding (petr_head.py:286-334): coords3d, conv 3D->4C, ReLU, conv 4C->C ----
   {
     petr_coords3d_args a;
     memset(&a, 0, sizeof a);
@@ -537,53 +572,54 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     a.B = d.B; a.N = d.N; a.H = d.H; a.W = d.W; a.D = d.D; a.pad_h = cfg->pad_h; a.pad_w = cfg->pad_w;
     for (int i = 0; i < 6; ++i) a.range[i] = cfg->position_range[i];
     a.eps = 1e-5f;
-    RUN(petr_coords3d_fwd(&a, s));
-    petr_sine3d_args b;
-    memset(&b, 0, sizeof b);
-    b.mask = kpm; b.dim_t = io->dim_t; b.out = Wm + W.sine; b.B = d.B; b.N = d.N; b.H = d.H; b.W = d.W; b.F = C / 2;
-    b.normalize = 1; b.scale = 6.283185307179586f; b.eps = 1e-6f; b.offset = 0.f;
-    RUN(petr_sine3d_fwd(&b, s));
-  }
-  const int V = d.B * d.N;
-  {
-    // input_proj (petr_head.py:390): NCHW view [C_in][HW] read as an M-contiguous operand -> token-major memory
+    RUN(petr_coords3d_fwd(&a, s1));
     petr_gemm_args g = gemm0();
-    g.a = io->feats; g.lda = d.HW; g.a_kcontig = 0; g.a_bs0 = (long)d.Cin * d.HW;
-    g.b = Pm + P.in_w; g.ldb = d.Cin; g.b_kcontig = 1;
-    g.c = Wm + W.mem; g.ldc = C; g.c_bs0 = (long)d.HW * C; g.bias = Pm + P.in_b;
-    g.M = d.HW; g.N = C; g.K = d.Cin; g.nb0 = V;
-    RUN(petr_gemm(&g, s));
-    // position_encoder: conv1x1 3D->4C, ReLU, conv1x1 4C->C (petr_head.py:263-267,332)
-    g = gemm0();
     g.a = Wm + W.vol; g.lda = d.HW; g.a_kcontig = 0; g.a_bs0 = (long)3 * d.D * d.HW;
     g.b = Pm + P.pe_w1; g.ldb = 3 * d.D; g.b_kcontig = 1;
     g.c = Wm + W.h1; g.ldc = 4 * C; g.c_bs0 = (long)d.HW * 4 * C; g.bias = Pm + P.pe_b1;
     g.M = d.HW; g.N = 4 * C; g.K = 3 * d.D; g.nb0 = V; g.flags = PETR_GEMM_RELU;
-    RUN(petr_gemm(&g, s));
+    RUN(petr_gemm(&g, s1));
     g = lin_fwd(Wm + W.h1, Pm + P.pe_w2, Pm + P.pe_b2, Wm + W.pos, d.BL, C, 4 * C);
-    RUN(petr_gemm(&g, s));
-    // adapt_pos3d on the sine features, summed into pos (petr_head.py:400-402)
-    g = gemm0();
-    g.a = Wm + W.sine; g.lda = d.HW; g.a_kcontig = 0; g.a_bs0 = (long)(C * 3 / 2) * d.HW;
-    g.b = Pm + P.ad_w1; g.ldb = C * 3 / 2; g.b_kcontig = 1;
-    g.c = Wm + W.h2; g.ldc = 4 * C; g.c_bs0 = (long)d.HW * 4 * C; g.bias = Pm + P.ad_b1;
-    g.M = d.HW; g.N = 4 * C; g.K = C * 3 / 2; g.nb0 = V; g.flags = PETR_GEMM_RELU;
-    RUN(petr_gemm(&g, s));
+    RUN(petr_gemm(&g, s1));
+    // wait for side 2 (sine hidden, memory), then pos += adapt_pos3d(sine) (petr_head.py:400-402)
+    if (ln.ctx) {
+      hipEvent_t e = ln.next();
+      (void)hipEventRecord(e, (hipStream_t)s2);
+      (void)hipStreamWaitEvent((hipStream_t)s1, e, 0);
+    }
     g = lin_fwd(Wm + W.h2, Pm + P.ad_w2, Pm + P.ad_b2, Wm + W.pos, d.BL, C, 4 * C);
     g.flags = PETR_GEMM_ACCUMULATE;
-    RUN(petr_gemm(&g, s));
+    RUN(petr_gemm(&g, s1));
     // key = memory + key_pos (petr_transformer.py:343-344), once for all layers
-    RUN(petr_add_rows(Wm + W.mem, Wm + W.pos, Wm + W.mempos, d.BL, 0, C, s));
-    // K_l = (mem+pos) Wk_l^T + bk_l ; V_l = mem Wv_l^T + bv_l for ALL layers: [B][NL][L][C]
-    for (int kv = 0; kv < 2; ++kv) {
-      g = gemm0();
-      g.a = kv == 0 ? Wm + W.mempos : Wm + W.mem; g.lda = C; g.a_kcontig = 1; g.a_bs0 = d.L * C;
-      g.b = Pm + P.lay[0].ca_in_w + (long)(kv + 1) * C * C; g.ldb = C; g.b_kcontig = 1; g.b_bs1 = P.ca_in_stride;
-      g.bias = Pm + P.lay[0].ca_in_b + (kv + 1) * C; g.bias_bs1 = P.ca_in_stride;
-      g.c = Wm + (kv == 0 ? W.k_all : W.v_all); g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
-      g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
-      RUN(petr_gemm(&g, s));
-    }
+    RUN(petr_add_rows(Wm + W.mem, Wm + W.pos, Wm + W.mempos, d.BL, 0, C, s1));
+    // K_l = (mem+pos) Wk_l^T + bk_l for ALL layers: [B][NL][L][C]
+    g = gemm0();
+    g.a = Wm + W.mempos; g.lda = C; g.a_kcontig = 1; g.a_bs0 = d.L * C;
+    g.b = Pm + P.lay[0].ca_in_w + (long)C * C; g.ldb = C; g.b_kcontig = 1; g.b_bs1 = P.ca_in_stride;
+    g.bias = Pm + P.lay[0].ca_in_b + C; g.bias_bs1 = P.ca_in_stride;
+    g.c = Wm + W.k_all; g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
+    g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
+    RUN(petr_gemm(&g, s1));
+  }
+  {
+    // V_l = mem Wv_l^T + bv_l on side 2 (memory was produced there)
+    petr_gemm_args g = gemm0();
+    g.a = Wm + W.mem; g.lda = C; g.a_kcontig = 1; g.a_bs0 = d.L * C;
+    g.b = Pm + P.lay[0].ca_in_w + (long)2 * C * C; g.ldb = C; g.b_kcontig = 1; g.b_bs1 = P.ca_in_stride;
+    g.bias = Pm + P.lay[0].ca_in_b + 2 * C; g.bias_bs1 = P.ca_in_stride;
+    g.c = Wm + W.v_all; g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
+    g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
+    RUN(petr_gemm(&g, s2));
+  }
+
+  // ---- main: query embedding pos2posemb3d + MLP (petr_head.py:422-423) ----
+  RUN(petr_posemb3d_fwd(Pm + P.ref, io->dim_t, Wm + W.posemb, d.Q, C / 2, s));
+  {
+    petr_gemm_args g = lin_fwd(Wm + W.posemb, Pm + P.qe_w1, Pm + P.qe_b1, Wm + W.qe_h, d.Q, C, C * 3 / 2);
+    g.flags = PETR_GEMM_RELU;
+    RUN(petr_gemm(&g, s));
+    g = lin_fwd(Wm + W.qe_h, Pm + P.qe_w2, Pm + P.qe_b2, Wm + W.qe, d.Q, C, C);
+    RUN(petr_gemm(&g, s));
   }
 
   // ---- decoder (petr_transformer.py:95-107,440-446; layer op order A.3) ----
@@ -608,6 +644,10 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     // cross-attention: q = x1 + query_pos, k = mem + pos, v = mem (petr_transformer.py:341-362)
     g = lin_fwd(Wm + lw.xe1, Pm + lp.ca_in_w, Pm + lp.ca_in_b, Wm + lw.qc, d.BQ, C, C);
     RUN(petr_gemm(&g, s));
+    if (l == 0) {          // K/V of all layers come from the side streams
+      ln.join(0);
+      ln.join(1);
+    }
     RUN(mha_f(Wm + lw.qc, (long)d.Q * C, C, Wm + W.k_all + (long)l * d.L * C, (long)d.NL * d.L * C, C,
               Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, s));
     g = lin_fwd(Wm + lw.ao_c, Pm + lp.ca_out_w, Pm + lp.ca_out_b, Wm + lw.z1, d.BQ, C, C);
@@ -638,7 +678,24 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   RUN(ln_fwd(Wm + W.xs, 1, 0, nullptr, nullptr, Pm + P.post_g, Pm + P.post_b, Wm + W.outs, nullptr, Wm + W.mean_p,
              Wm + W.rstd_p, d.R, C, PETR_LN_NAN_TO_NUM, nullptr, nullptr, 0, s));
 
-  // ---- branches (petr_head.py:226-247,440-460): one shared cls / reg module for all levels ----
+  // ---- branches (petr_head.py:226-247,440-460): one shared cls / reg module for all levels; reg on a side stream ----
+  ln.fork(0);
+  {
+    petr_gemm_args g = lin_fwd(Wm + W.outs, Pm + P.reg_w[0], Pm + P.reg_b[0], Wm + W.r1, d.R, C, C);
+    g.flags = PETR_GEMM_RELU;
+    RUN(petr_gemm(&g, s1));
+    g = lin_fwd(Wm + W.r1, Pm + P.reg_w[1], Pm + P.reg_b[1], Wm + W.r2, d.R, C, C);
+    g.flags = PETR_GEMM_RELU;
+    RUN(petr_gemm(&g, s1));
+    g = lin_fwd(Wm + W.r2, Pm + P.reg_w[2], Pm + P.reg_b[2], Wm + W.reg_raw, d.R, d.code, C);
+    RUN(petr_gemm(&g, s1));
+    petr_bbox_args a;
+    memset(&a, 0, sizeof a);
+    a.reg = Wm + W.reg_raw; a.ref = Pm + P.ref; a.out = io->all_bbox_preds; a.rows = (int)d.R; a.Q = d.Q; a.code = d.code;
+    for (int i = 0; i < 6; ++i) a.pc_range[i] = cfg->pc_range[i];
+    a.time_div = 0.f; a.eps = 1e-5f;
+    RUN(petr_bbox_epilogue_fwd(&a, s1));
+  }
   {
     petr_gemm_args g = lin_fwd(Wm + W.outs, Pm + P.cls_w[0], Pm + P.cls_b[0], Wm + W.c1, d.R, C, C);
     RUN(petr_gemm(&g, s));
@@ -650,21 +707,8 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
                Wm + W.c2_rstd, d.R, C, PETR_LN_RELU, nullptr, nullptr, 0, s));
     g = lin_fwd(Wm + W.c2n, Pm + P.cls_w[2], Pm + P.cls_b[2], io->all_cls_scores, d.R, d.ncls, C);
     RUN(petr_gemm(&g, s));
-    g = lin_fwd(Wm + W.outs, Pm + P.reg_w[0], Pm + P.reg_b[0], Wm + W.r1, d.R, C, C);
-    g.flags = PETR_GEMM_RELU;
-    RUN(petr_gemm(&g, s));
-    g = lin_fwd(Wm + W.r1, Pm + P.reg_w[1], Pm + P.reg_b[1], Wm + W.r2, d.R, C, C);
-    g.flags = PETR_GEMM_RELU;
-    RUN(petr_gemm(&g, s));
-    g = lin_fwd(Wm + W.r2, Pm + P.reg_w[2], Pm + P.reg_b[2], Wm + W.reg_raw, d.R, d.code, C);
-    RUN(petr_gemm(&g, s));
-    petr_bbox_args a;
-    memset(&a, 0, sizeof a);
-    a.reg = Wm + W.reg_raw; a.ref = Pm + P.ref; a.out = io->all_bbox_preds; a.rows = (int)d.R; a.Q = d.Q; a.code = d.code;
-    for (int i = 0; i < 6; ++i) a.pc_range[i] = cfg->pc_range[i];
-    a.time_div = 0.f; a.eps = 1e-5f;
-    RUN(petr_bbox_epilogue_fwd(&a, s));
   }
+  ln.join(0);
   return PETR_OK;
 }
 
@@ -672,7 +716,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
 // backward
 // =============================================================================================
 extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io, const petr_head_grads* gr,
-                             int stage_begin, int stage_end, void* s) {
+                             int stage_begin, int stage_end, void* stream) {
   RUN(check_config(cfg));
   PETR_CHECK(io && io->params && io->feats && io->ws && io->all_bbox_preds && gr && gr->d_cls && gr->d_bbox && gr->d_params,
              PETR_ERR_INVALID, "head_bwd: null pointer");
@@ -689,14 +733,22 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   float* Wm = (float*)io->ws;
   const int C = d.C;
   const uint8_t* kpm = cfg->has_mask ? io->mask : nullptr;
-  const float* E = Wm + W.qe;
   float* mws = Wm + W.mha_ws;
-  hipStream_t hs = (hipStream_t)s;
+  const Lanes ln{(hipStream_t)stream, (petr_ctx*)io->ctx};
+  void* s = ln.m();
+  // Weight-gradient contractions only feed d_params: they leave the critical path (the chain of input-gradient
+  // kernels) and alternate over the side streams.  Every dy they read lives in private scratch (WOff::lg / s0_*).
+  int wg_rr = 0;
+  auto wgrad = [&](petr_gemm_args g) -> int {
+    const int lane = wg_rr++ & 1;
+    ln.fork(lane);
+    return petr_gemm(&g, ln.side(lane));
+  };
 
   for (int stage = stage_begin; stage < stage_end; ++stage) {
     if (stage == 0) {
       // clear every += / atomic target of this backward pass
-      hipError_t e = hipMemsetAsync(Wm + W.zero_begin, 0, (size_t)(W.zero_end - W.zero_begin) * sizeof(float), hs);
+      hipError_t e = hipMemsetAsync(Wm + W.zero_begin, 0, (size_t)(W.zero_end - W.zero_begin) * sizeof(float), ln.main);
       PETR_CHECK(e == hipSuccess, PETR_ERR_LAUNCH, "head_bwd: memset failed: %s", hipGetErrorString(e));
       // ---- box epilogue + reg branch ----
       petr_bbox_args a;
@@ -704,43 +756,37 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       a.ref = Pm + P.ref; a.out = io->all_bbox_preds; a.rows = (int)d.R; a.Q = d.Q; a.code = d.code;
       for (int i = 0; i < 6; ++i) a.pc_range[i] = cfg->pc_range[i];
       a.time_div = 0.f; a.eps = 1e-5f;
-      float* d_raw = Wm + W.ga;   // [R, code]
+      float* d_raw = Wm + W.s0_raw;   // [R, code]
       RUN(petr_bbox_epilogue_bwd(&a, gr->d_bbox, d_raw, Wm + W.d_ref_tmp, s));
-      petr_gemm_args g = lin_wgrad(d_raw, d.code, Wm + W.r2, C, Gp + P.reg_w[2], Gp + P.reg_b[2], d.R, d.code, C);
-      RUN(petr_gemm(&g, s));
-      float* d_r2 = Wm + W.gb;
-      g = lin_dgrad(d_raw, Pm + P.reg_w[2], d_r2, d.R, d.code, C);
+      RUN(wgrad(lin_wgrad(d_raw, d.code, Wm + W.r2, C, Gp + P.reg_w[2], Gp + P.reg_b[2], d.R, d.code, C)));
+      float* d_r2 = Wm + W.s0_r2;
+      petr_gemm_args g = lin_dgrad(d_raw, Pm + P.reg_w[2], d_r2, d.R, d.code, C);
       g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.r2; g.ldr = C;
       RUN(petr_gemm(&g, s));
-      g = lin_wgrad(d_r2, C, Wm + W.r1, C, Gp + P.reg_w[1], Gp + P.reg_b[1], d.R, C, C);
-      RUN(petr_gemm(&g, s));
-      float* d_r1 = Wm + W.gc;
+      RUN(wgrad(lin_wgrad(d_r2, C, Wm + W.r1, C, Gp + P.reg_w[1], Gp + P.reg_b[1], d.R, C, C)));
+      float* d_r1 = Wm + W.s0_r1;
       g = lin_dgrad(d_r2, Pm + P.reg_w[1], d_r1, d.R, C, C);
       g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.r1; g.ldr = C;
       RUN(petr_gemm(&g, s));
-      g = lin_wgrad(d_r1, C, Wm + W.outs, C, Gp + P.reg_w[0], Gp + P.reg_b[0], d.R, C, C);
-      RUN(petr_gemm(&g, s));
+      RUN(wgrad(lin_wgrad(d_r1, C, Wm + W.outs, C, Gp + P.reg_w[0], Gp + P.reg_b[0], d.R, C, C)));
       g = lin_dgrad(d_r1, Pm + P.reg_w[0], Wm + W.d_outs, d.R, C, C);
       RUN(petr_gemm(&g, s));
       // ---- cls branch ----
-      g = lin_wgrad(gr->d_cls, d.ncls, Wm + W.c2n, C, Gp + P.cls_w[2], Gp + P.cls_b[2], d.R, d.ncls, C);
-      RUN(petr_gemm(&g, s));
-      float* d_c2n = Wm + W.ga;
+      RUN(wgrad(lin_wgrad(gr->d_cls, d.ncls, Wm + W.c2n, C, Gp + P.cls_w[2], Gp + P.cls_b[2], d.R, d.ncls, C)));
+      float* d_c2n = Wm + W.s0_c2n;
       g = lin_dgrad(gr->d_cls, Pm + P.cls_w[2], d_c2n, d.R, d.ncls, C);
       RUN(petr_gemm(&g, s));
-      float* d_c2 = Wm + W.gb;
+      float* d_c2 = Wm + W.s0_c2;
       RUN(ln_bwd(Wm + W.c2, Wm + W.c2_mean, Wm + W.c2_rstd, Pm + P.cls_g[1], d_c2n, Wm + W.c2n, d_c2, Gp + P.cls_g[1],
                  Gp + P.cls_be[1], d.R, C, PETR_LN_RELU, 0, s));
-      g = lin_wgrad(d_c2, C, Wm + W.c1n, C, Gp + P.cls_w[1], Gp + P.cls_b[1], d.R, C, C);
-      RUN(petr_gemm(&g, s));
-      float* d_c1n = Wm + W.ga;
+      RUN(wgrad(lin_wgrad(d_c2, C, Wm + W.c1n, C, Gp + P.cls_w[1], Gp + P.cls_b[1], d.R, C, C)));
+      float* d_c1n = Wm + W.s0_c1n;
       g = lin_dgrad(d_c2, Pm + P.cls_w[1], d_c1n, d.R, C, C);
       RUN(petr_gemm(&g, s));
-      float* d_c1 = Wm + W.gb;
+      float* d_c1 = Wm + W.s0_c1;
       RUN(ln_bwd(Wm + W.c1, Wm + W.c1_mean, Wm + W.c1_rstd, Pm + P.cls_g[0], d_c1n, Wm + W.c1n, d_c1, Gp + P.cls_g[0],
                  Gp + P.cls_be[0], d.R, C, PETR_LN_RELU, 0, s));
-      g = lin_wgrad(d_c1, C, Wm + W.outs, C, Gp + P.cls_w[0], Gp + P.cls_b[0], d.R, C, C);
-      RUN(petr_gemm(&g, s));
+      RUN(wgrad(lin_wgrad(d_c1, C, Wm + W.outs, C, Gp + P.cls_w[0], Gp + P.cls_b[0], d.R, C, C)));
       g = lin_dgrad(d_c1, Pm + P.cls_w[0], Wm + W.d_outs, d.R, C, C);
       g.flags = PETR_GEMM_ACCUMULATE;
       RUN(petr_gemm(&g, s));
@@ -751,35 +797,33 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       const int l = d.NL - stage;
       const LayerP& lp = P.lay[l];
       const LayerW& lw = W.lay[l];
+      const WOff::LayerG& lg = W.lg[l];
       const float* x_in = l == 0 ? Wm + W.x0 : Wm + W.xs + (long)(l - 1) * d.BQ * C;
       const float* G = Wm + W.d_xs + (long)l * d.BQ * C;     // d(x3_l): post-norm path (+ layer l+1's input grad)
       // LN2 / FFN
-      float* d_z2 = Wm + W.ga;
+      float* d_z2 = Wm + lg.d_z2;
       RUN(ln_bwd(Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, Pm + lp.n_g[2], G, nullptr, d_z2, Gp + lp.n_g[2], Gp + lp.n_b[2],
                  d.BQ, C, 0, 0, s));
-      petr_gemm_args g = lin_wgrad(d_z2, C, Wm + lw.hff, d.F, Gp + lp.f2_w, Gp + lp.f2_b, d.BQ, C, d.F);
-      RUN(petr_gemm(&g, s));
-      float* d_h = Wm + W.gb;                                   // [BQ, F]
-      g = lin_dgrad(d_z2, Pm + lp.f2_w, d_h, d.BQ, C, d.F);
+      RUN(wgrad(lin_wgrad(d_z2, C, Wm + lw.hff, d.F, Gp + lp.f2_w, Gp + lp.f2_b, d.BQ, C, d.F)));
+      float* d_h = Wm + lg.d_h;                                 // [BQ, F]
+      petr_gemm_args g = lin_dgrad(d_z2, Pm + lp.f2_w, d_h, d.BQ, C, d.F);
       g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + lw.hff; g.ldr = d.F;
       RUN(petr_gemm(&g, s));
-      g = lin_wgrad(d_h, d.F, Wm + lw.x2, C, Gp + lp.f1_w, Gp + lp.f1_b, d.BQ, d.F, C);
-      RUN(petr_gemm(&g, s));
+      RUN(wgrad(lin_wgrad(d_h, d.F, Wm + lw.x2, C, Gp + lp.f1_w, Gp + lp.f1_b, d.BQ, d.F, C)));
       // d_x2 = d_h @ W1 + d_z2 (identity path): K = F is long and there are only BQ/64 x 4 output tiles, so the
       // contraction is split over K into slabs that the LayerNorm backward sums in its prologue
-      float* d_x2 = Wm + W.gc;
+      float* d_x2 = Wm + lg.d_x2;
       const int sk = W.ffn_split;
       g = lin_dgrad(d_h, Pm + lp.f1_w, d_x2, d.BQ, d.F, C);
       if (sk > 1) { g.split_k = sk; g.c_split_stride = d.BQ * C; }
       else { g.r = d_z2; g.ldr = C; }
       RUN(petr_gemm(&g, s));
       // LN1 / cross-attention
-      float* d_z1 = Wm + W.gd;
+      float* d_z1 = Wm + lg.d_z1;
       RUN(ln_bwd(Wm + lw.z1, Wm + lw.mean1, Wm + lw.rstd1, Pm + lp.n_g[1], d_x2, nullptr, d_z1, Gp + lp.n_g[1],
                  Gp + lp.n_b[1], d.BQ, C, 0, 0, s, sk, d.BQ * C, sk > 1 ? d_z2 : nullptr));
-      g = lin_wgrad(d_z1, C, Wm + lw.ao_c, C, Gp + lp.ca_out_w, Gp + lp.ca_out_b, d.BQ, C, C);
-      RUN(petr_gemm(&g, s));
-      float* d_ao = Wm + W.gb;
+      RUN(wgrad(lin_wgrad(d_z1, C, Wm + lw.ao_c, C, Gp + lp.ca_out_w, Gp + lp.ca_out_b, d.BQ, C, C)));
+      float* d_ao = Wm + lg.d_ao;
       g = lin_dgrad(d_z1, Pm + lp.ca_out_w, d_ao, d.BQ, C, C);
       RUN(petr_gemm(&g, s));
       float* d_qc = Wm + W.d_qc + (long)l * d.BQ * C;
@@ -787,29 +831,26 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
                 Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, d_ao, Wm + lw.lse_c, kpm, d_qc,
                 Wm + W.dk_all + (long)l * d.L * C, Wm + W.dv_all + (long)l * d.L * C, d, (int)d.L, mws, W.mha_ws_bytes, s));
       // q projection of the cross-attention (rows 0..C of in_proj): weight grads live in the final block
-      g = lin_wgrad(d_qc, C, Wm + lw.xe1, C, Gp + lp.ca_in_w, Gp + lp.ca_in_b, d.BQ, C, C);
-      RUN(petr_gemm(&g, s));
-      float* d_x1 = Wm + W.gc;
+      RUN(wgrad(lin_wgrad(d_qc, C, Wm + lw.xe1, C, Gp + lp.ca_in_w, Gp + lp.ca_in_b, d.BQ, C, C)));
+      float* d_x1 = Wm + lg.d_x1;
       g = lin_dgrad(d_qc, Pm + lp.ca_in_w, d_x1, d.BQ, C, C);
       g.r = d_z1; g.ldr = C;
       RUN(petr_gemm(&g, s));
       // LN0 / self-attention
-      float* d_z0 = Wm + W.ga;
+      float* d_z0 = Wm + lg.d_z0;
       RUN(ln_bwd(Wm + lw.z0, Wm + lw.mean0, Wm + lw.rstd0, Pm + lp.n_g[0], d_x1, nullptr, d_z0, Gp + lp.n_g[0],
                  Gp + lp.n_b[0], d.BQ, C, 0, 0, s));
-      g = lin_wgrad(d_z0, C, Wm + lw.ao_s, C, Gp + lp.sa_out_w, Gp + lp.sa_out_b, d.BQ, C, C);
-      RUN(petr_gemm(&g, s));
-      float* d_ao_s = Wm + W.gb;
+      RUN(wgrad(lin_wgrad(d_z0, C, Wm + lw.ao_s, C, Gp + lp.sa_out_w, Gp + lp.sa_out_b, d.BQ, C, C)));
+      float* d_ao_s = Wm + lg.d_ao_s;
       g = lin_dgrad(d_z0, Pm + lp.sa_out_w, d_ao_s, d.BQ, C, C);
       RUN(petr_gemm(&g, s));
       float* d_qkv = Wm + W.d_qkv + (long)l * d.BQ * 3 * C;
       RUN(mha_b(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
                 Wm + lw.ao_s, d_ao_s, Wm + lw.lse_s, nullptr, d_qkv, d_qkv + C, d_qkv + 2 * C, d, d.Q, mws, W.mha_ws_bytes, s));
       // in_proj: q,k rows see x + query_pos, v rows see x
-      g = lin_wgrad(d_qkv, 3 * C, Wm + lw.xe_in, C, Gp + lp.sa_in_w, Gp + lp.sa_in_b, d.BQ, 2 * C, C);
-      RUN(petr_gemm(&g, s));
-      g = lin_wgrad(d_qkv + 2 * C, 3 * C, x_in, C, Gp + lp.sa_in_w + (long)2 * C * C, Gp + lp.sa_in_b + 2 * C, d.BQ, C, C);
-      RUN(petr_gemm(&g, s));
+      RUN(wgrad(lin_wgrad(d_qkv, 3 * C, Wm + lw.xe_in, C, Gp + lp.sa_in_w, Gp + lp.sa_in_b, d.BQ, 2 * C, C)));
+      RUN(wgrad(lin_wgrad(d_qkv + 2 * C, 3 * C, x_in, C, Gp + lp.sa_in_w + (long)2 * C * C, Gp + lp.sa_in_b + 2 * C, d.BQ, C,
+                          C)));
       if (l > 0) {
         // d(x_in) = d_z0 (identity) + d_qkv @ W_in, added to the post-norm gradient of level l-1
         float* dst = Wm + W.d_xs + (long)(l - 1) * d.BQ * C;
@@ -820,39 +861,12 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       }
     } else {
       // ================= final stage =================
-      // query_pos gradient: sum over layers and batch of d(q-proj inputs) (deferred from the layers)
-      petr_gemm_args g = gemm0();
-      g.a = Wm + W.d_qc; g.lda = C; g.a_kcontig = 1; g.a_bs0 = d.BQ * C;
-      g.b = Pm + P.lay[0].ca_in_w; g.ldb = C; g.b_kcontig = 0; g.b_bs0 = P.ca_in_stride;
-      g.c = Wm + W.d_e_slab; g.ldc = C; g.c_bs0 = d.BQ * C;
-      g.M = (int)d.BQ; g.N = C; g.K = C; g.nb0 = d.NL;
-      RUN(petr_gemm(&g, s));
-      for (int l = 0; l < d.NL; ++l) {   // self-attention q,k rows (layer blocks are not uniformly strided by design)
-        g = lin_dgrad(Wm + W.d_qkv + (long)l * d.BQ * 3 * C, Pm + P.lay[l].sa_in_w, Wm + W.d_e_slab + (long)l * d.BQ * C,
-                      d.BQ, 2 * C, C);
-        g.lda = 3 * C;
-        g.flags = PETR_GEMM_ACCUMULATE;
-        RUN(petr_gemm(&g, s));
-      }
-      RUN(petr_reduce_batch(Wm + W.d_e_slab, d.NL * d.B, d.Q, C, Wm + W.d_e, 0, s));
-      // query_embedding MLP + pos2posemb3d (petr_head.py:422-423)
-      g = lin_wgrad(Wm + W.d_e, C, Wm + W.qe_h, C, Gp + P.qe_w2, Gp + P.qe_b2, d.Q, C, C);
-      RUN(petr_gemm(&g, s));
-      g = lin_dgrad(Wm + W.d_e, Pm + P.qe_w2, Wm + W.d_qe_h, d.Q, C, C);
-      g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.qe_h; g.ldr = C;
-      RUN(petr_gemm(&g, s));
-      g = lin_wgrad(Wm + W.d_qe_h, C, Wm + W.posemb, C * 3 / 2, Gp + P.qe_w1, Gp + P.qe_b1, d.Q, C, C * 3 / 2);
-      RUN(petr_gemm(&g, s));
-      g = lin_dgrad(Wm + W.d_qe_h, Pm + P.qe_w1, Wm + W.d_posemb, d.Q, C, C * 3 / 2);
-      RUN(petr_gemm(&g, s));
-      RUN(petr_posemb3d_bwd(Pm + P.ref, io->dim_t, Wm + W.d_posemb, Wm + W.d_ref_tmp, d.Q, C / 2, s));
-      RUN(petr_axpy(Gp + P.ref, Wm + W.d_ref_tmp, 1.f, (long)d.Q * 3, s));
-
-      // K/V projections of all layers: k index = (batch, token) for the weights, (layer, channel) for the inputs
+      const int V = d.B * d.N;
+      // K/V projections of all layers (need every layer's dK/dV): input gradients on main, weights on the sides
       for (int kv = 0; kv < 2; ++kv) {
         const float* dkv = Wm + (kv == 0 ? W.dk_all : W.dv_all);
         const float* src = kv == 0 ? Wm + W.mempos : Wm + W.mem;
-        g = gemm0();      // dW_l[C,C] += sum_{b,t} dKV[b][l][t][o] * src[b][t][c]
+        petr_gemm_args g = gemm0();      // dW_l[C,C] += sum_{b,t} dKV[b][l][t][o] * src[b][t][c]
         g.a = dkv; g.lda = C; g.a_kcontig = 0; g.a_bs0 = d.L * C;
         g.b = src; g.ldb = C; g.b_kcontig = 0;
         g.c = Gp + P.lay[0].ca_in_w + (long)(kv + 1) * C * C; g.ldc = C; g.c_bs0 = P.ca_in_stride;
@@ -861,7 +875,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g.k_seg = (int)d.L; g.a_seg_stride = (long)d.NL * d.L * C; g.b_seg_stride = d.L * C;
         g.flags = PETR_GEMM_ATOMIC;
         g.split_k = 8;
-        RUN(petr_gemm(&g, s));
+        RUN(wgrad(g));
         g = gemm0();      // d_src[b][t][c] = sum_{l,o} dKV[b][l][t][o] * W_l[o][c]
         g.a = dkv; g.lda = C; g.a_kcontig = 1; g.a_bs0 = (long)d.NL * d.L * C;
         g.b = Pm + P.lay[0].ca_in_w + (long)(kv + 1) * C * C; g.ldb = C; g.b_kcontig = 0;
@@ -873,7 +887,6 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // d_mem = dV-path + d(mem+pos) ; d_pos = d(mem+pos)
       RUN(petr_axpy(Wm + W.d_mem, Wm + W.d_mempos, 1.f, d.BL * C, s));
       const float* d_pos = Wm + W.d_mempos;
-      const int V = d.B * d.N;
       // position_encoder and adapt_pos3d (inputs carry no gradient)
       for (int which = 0; which < 2; ++which) {
         const long w1 = which == 0 ? P.pe_w1 : P.ad_w1, b1 = which == 0 ? P.pe_b1 : P.ad_b1;
@@ -881,38 +894,68 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         const float* hid = Wm + (which == 0 ? W.h1 : W.h2);
         const float* feat = Wm + (which == 0 ? W.vol : W.sine);
         const int Kin = which == 0 ? 3 * d.D : C * 3 / 2;
-        g = lin_wgrad(d_pos, C, hid, 4 * C, Gp + w2, Gp + b2, d.BL, C, 4 * C);
-        RUN(petr_gemm(&g, s));
-        g = lin_dgrad(d_pos, Pm + w2, Wm + W.d_hpe, d.BL, C, 4 * C);
+        float* d_hpe = Wm + W.d_hpe[which];
+        RUN(wgrad(lin_wgrad(d_pos, C, hid, 4 * C, Gp + w2, Gp + b2, d.BL, C, 4 * C)));
+        petr_gemm_args g = lin_dgrad(d_pos, Pm + w2, d_hpe, d.BL, C, 4 * C);
         g.flags = PETR_GEMM_RELU_MASK; g.r = hid; g.ldr = 4 * C;
         RUN(petr_gemm(&g, s));
         g = gemm0();      // dW1[4C, Kin] += sum_{view, hw} d_h[view*HW+hw][f] * feat[view][c][hw]
-        g.a = Wm + W.d_hpe; g.lda = 4 * C; g.a_kcontig = 0;
+        g.a = d_hpe; g.lda = 4 * C; g.a_kcontig = 0;
         g.b = feat; g.ldb = d.HW; g.b_kcontig = 1;
         g.c = Gp + w1; g.ldc = Kin; g.a_colsum = Gp + b1;
         g.M = 4 * C; g.N = Kin; g.K = V * d.HW;
         g.k_seg = d.HW; g.a_seg_stride = (long)d.HW * 4 * C; g.b_seg_stride = (long)Kin * d.HW;
         g.flags = PETR_GEMM_ATOMIC; g.split_k = 8;
-        RUN(petr_gemm(&g, s));
+        RUN(wgrad(g));
       }
       // input_proj
-      g = gemm0();        // dW[C, Cin] += sum_{view,hw} d_mem[view*HW+hw][o] * x[view][ci][hw]
-      g.a = Wm + W.d_mem; g.lda = C; g.a_kcontig = 0;
-      g.b = io->feats; g.ldb = d.HW; g.b_kcontig = 1;
-      g.c = Gp + P.in_w; g.ldc = d.Cin; g.a_colsum = Gp + P.in_b;
-      g.M = C; g.N = d.Cin; g.K = V * d.HW;
-      g.k_seg = d.HW; g.a_seg_stride = (long)d.HW * C; g.b_seg_stride = (long)d.Cin * d.HW;
-      g.flags = PETR_GEMM_ATOMIC; g.split_k = 16;
-      RUN(petr_gemm(&g, s));
-      if (gr->d_feats) {
-        g = gemm0();      // d_x[view][ci][hw] = sum_o W[o][ci] * d_mem[view*HW+hw][o]
-        g.a = Pm + P.in_w; g.lda = d.Cin; g.a_kcontig = 0;
-        g.b = Wm + W.d_mem; g.ldb = C; g.b_kcontig = 1; g.b_bs0 = (long)d.HW * C;
-        g.c = gr->d_feats; g.ldc = d.HW; g.c_bs0 = (long)d.Cin * d.HW;
-        g.M = d.Cin; g.N = d.HW; g.K = C; g.nb0 = V;
+      {
+        petr_gemm_args g = gemm0();        // dW[C, Cin] += sum_{view,hw} d_mem[view*HW+hw][o] * x[view][ci][hw]
+        g.a = Wm + W.d_mem; g.lda = C; g.a_kcontig = 0;
+        g.b = io->feats; g.ldb = d.HW; g.b_kcontig = 1;
+        g.c = Gp + P.in_w; g.ldc = d.Cin; g.a_colsum = Gp + P.in_b;
+        g.M = C; g.N = d.Cin; g.K = V * d.HW;
+        g.k_seg = d.HW; g.a_seg_stride = (long)d.HW * C; g.b_seg_stride = (long)d.Cin * d.HW;
+        g.flags = PETR_GEMM_ATOMIC; g.split_k = 16;
+        RUN(wgrad(g));
+        if (gr->d_feats) {
+          g = gemm0();      // d_x[view][ci][hw] = sum_o W[o][ci] * d_mem[view*HW+hw][o]
+          g.a = Pm + P.in_w; g.lda = d.Cin; g.a_kcontig = 0;
+          g.b = Wm + W.d_mem; g.ldb = C; g.b_kcontig = 1; g.b_bs0 = (long)d.HW * C;
+          g.c = gr->d_feats; g.ldc = d.HW; g.c_bs0 = (long)d.Cin * d.HW;
+          g.M = d.Cin; g.N = d.HW; g.K = C; g.nb0 = V;
+          RUN(petr_gemm(&g, s));
+        }
+      }
+      // query_pos gradient: sum over layers and batch of d(q-proj inputs) (deferred from the layers)
+      {
+        petr_gemm_args g = gemm0();
+        g.a = Wm + W.d_qc; g.lda = C; g.a_kcontig = 1; g.a_bs0 = d.BQ * C;
+        g.b = Pm + P.lay[0].ca_in_w; g.ldb = C; g.b_kcontig = 0; g.b_bs0 = P.ca_in_stride;
+        g.c = Wm + W.d_e_slab; g.ldc = C; g.c_bs0 = d.BQ * C;
+        g.M = (int)d.BQ; g.N = C; g.K = C; g.nb0 = d.NL;
         RUN(petr_gemm(&g, s));
+        for (int l = 0; l < d.NL; ++l) {   // self-attention q,k rows (layer blocks are not uniformly strided by design)
+          g = lin_dgrad(Wm + W.d_qkv + (long)l * d.BQ * 3 * C, Pm + P.lay[l].sa_in_w, Wm + W.d_e_slab + (long)l * d.BQ * C,
+                        d.BQ, 2 * C, C);
+          g.lda = 3 * C;
+          g.flags = PETR_GEMM_ACCUMULATE;
+          RUN(petr_gemm(&g, s));
+        }
+        RUN(petr_reduce_batch(Wm + W.d_e_slab, d.NL * d.B, d.Q, C, Wm + W.d_e, 0, s));
+        // query_embedding MLP + pos2posemb3d (petr_head.py:422-423)
+        RUN(wgrad(lin_wgrad(Wm + W.d_e, C, Wm + W.qe_h, C, Gp + P.qe_w2, Gp + P.qe_b2, d.Q, C, C)));
+        g = lin_dgrad(Wm + W.d_e, Pm + P.qe_w2, Wm + W.d_qe_h, d.Q, C, C);
+        g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.qe_h; g.ldr = C;
+        RUN(petr_gemm(&g, s));
+        RUN(wgrad(lin_wgrad(Wm + W.d_qe_h, C, Wm + W.posemb, C * 3 / 2, Gp + P.qe_w1, Gp + P.qe_b1, d.Q, C, C * 3 / 2)));
+        g = lin_dgrad(Wm + W.d_qe_h, Pm + P.qe_w1, Wm + W.d_posemb, d.Q, C, C * 3 / 2);
+        RUN(petr_gemm(&g, s));
+        RUN(petr_posemb3d_bwd(Pm + P.ref, io->dim_t, Wm + W.d_posemb, Wm + W.d_ref_tmp, d.Q, C / 2, s));
+        RUN(petr_axpy(Gp + P.ref, Wm + W.d_ref_tmp, 1.f, (long)d.Q * 3, s));
       }
     }
   }
+  ln.join_all();     // everything (gradient buckets of the stages just run included) is ordered on the caller's stream
   return PETR_OK;
 }

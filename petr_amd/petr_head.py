@@ -13,6 +13,7 @@ Host-side work kept in Python because the reference does it on the host too:
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -143,7 +144,7 @@ class PETRHead(nn.Module):
         self._runs = {}
         self._free_ws = {}
         self._anchor = None
-        self._stream_events = None
+        self._ctx = None
 
     # ------------------------------------------------------------------ construction
     def _init_layers(self):
@@ -325,6 +326,25 @@ class PETRHead(nn.Module):
         run.mask = torch.from_numpy(mask_np).to(feats.device, non_blocking=True) if has_mask else None
         return run
 
+    def _context(self):
+        """side streams for the work off the critical path (petr_ctx); PETR_AMD_SIDE_STREAMS=0 serialises."""
+        n = int(os.environ.get('PETR_AMD_SIDE_STREAMS', '2'))
+        if n <= 0:
+            return None
+        if self._ctx is None:
+            h = C.c_void_p()
+            _C.check(_C.lib().petr_ctx_create(C.byref(h), n), 'petr_ctx_create')
+            self._ctx = h
+        return self._ctx
+
+    def __del__(self):
+        ctx = getattr(self, '_ctx', None)
+        if ctx is not None:
+            try:
+                _C.lib().petr_ctx_destroy(ctx)
+            except Exception:  # noqa: BLE001 - interpreter shutdown
+                pass
+
     def _time_div(self, img_metas, batch_size):
         return 0.0
 
@@ -346,6 +366,7 @@ class PETRHead(nn.Module):
         io.all_bbox_preds = run.bbox.data_ptr()
         io.ws = run.ws.data_ptr()
         io.ws_bytes = run.ws.numel() * 4
+        io.ctx = self._context()
         run.io = io
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         _C.check(L.petr_head_fwd(C.byref(run.cfg), C.byref(io), stream), 'petr_head_fwd')

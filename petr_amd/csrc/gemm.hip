@@ -34,8 +34,9 @@ template <int ROWS, bool KC, bool VEC, bool A2>
 struct Stage {
   static constexpr int NV = ROWS * BK / 4 / 256;
   static constexpr int LD = KC ? ROWS + 1 : ROWS + 4;
-  float4 v[NV];
+  float4 v[NV];            // RAW loaded values: nothing may read them before store(), or hipcc waits at the load
   float4 w[A2 ? NV : 1];
+  unsigned okm[NV];        // 4 validity bits per float4 (+16: addend active), applied in store()
 
   __device__ __forceinline__ static float4 ld4(const float* base, long off0, long off1, long off2, long off3) {
     return make_float4(base[off0], base[off1], base[off2], base[off3]);
@@ -90,9 +91,9 @@ struct Stage {
                   ko + min(row + 3, o.rows - 1));
         }
       }
-      v[i] = make_float4(ok0 ? r.x : 0.f, ok1 ? r.y : 0.f, ok2 ? r.z : 0.f, ok3 ? r.w : 0.f);
-      if (A2) w[i] = make_float4(ok0 && a2_on ? r2.x : 0.f, ok1 && a2_on ? r2.y : 0.f, ok2 && a2_on ? r2.z : 0.f,
-                                 ok3 && a2_on ? r2.w : 0.f);
+      v[i] = r;
+      if (A2) w[i] = r2;
+      okm[i] = (ok0 ? 1u : 0u) | (ok1 ? 2u : 0u) | (ok2 ? 4u : 0u) | (ok3 ? 8u : 0u) | (a2_on ? 16u : 0u);
     }
   }
 
@@ -102,7 +103,9 @@ struct Stage {
     for (int i = 0; i < NV; ++i) {
       const int idx = t + 256 * i;
       float4 x = v[i];
-      if (A2) { x.x += w[i].x; x.y += w[i].y; x.z += w[i].z; x.w += w[i].w; }
+      const unsigned m = okm[i];
+      if (A2 && (m & 16u)) { x.x += w[i].x; x.y += w[i].y; x.z += w[i].z; x.w += w[i].w; }
+      x.x = (m & 1u) ? x.x : 0.f; x.y = (m & 2u) ? x.y : 0.f; x.z = (m & 4u) ? x.z : 0.f; x.w = (m & 8u) ? x.w : 0.f;
       if (KC) {
         const int row = idx >> 3, kq = idx & 7;
         float* d = lds + (4 * kq) * LD + row;
@@ -125,9 +128,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
   constexpr int TM = WM / 32, TN = WN / 32;
   using SA = Stage<BM, AKC, VEC, A2>;
   using SB = Stage<BN, BKC, VEC, false>;
-  __shared__ __attribute__((aligned(16))) float lds[BK * SA::LD + BK * SB::LD];
-  float* As = lds;
-  float* Bs = lds + BK * SA::LD;
+  // two LDS images of (A tile, B tile): tile t+1 is written while the MFMAs of tile t read the other image,
+  // ONE barrier per k-tile, and the ds_writes/global loads sit in the same basic block as the MFMAs so the
+  // compiler interleaves them (a single wave per SIMD otherwise serialises store -> barrier -> read -> MFMA)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BUF = BK * SA::LD + BK * SB::LD;
 
   // ---- which tile / batch / K-slice ----
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -178,41 +183,57 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
   constexpr int PD = (BM * BN <= 128 * 64) ? 3 : 2;
   SA sa[PD];
   SB sb[PD];
+  // Tiles past kt_end are loaded from clamped addresses with an all-zero validity mask and multiplied as zeros:
+  // the loop body stays branch-free straight-line code ([store t+1][load t+1+PD][MFMA t][barrier] x PD), which is
+  // what lets hipcc keep COUNTED vmcnt waits (two stages in flight) instead of draining the ring at every store.
   auto stage_load = [&](SA& ra, SB& rb, int kt) {
-    const int seg = kt / tps, k0 = (kt - seg * tps) * BK;
+    const bool live = kt < kt_end;
+    const int ktc = live ? kt : kt_end - 1;
+    const int seg = ktc / tps;
+    const int k0 = live ? (ktc - seg * tps) * BK : kseg;      // k0 >= kseg: every element masked out
     ra.load(A, (long)seg * g.a_seg_stride, m0, k0, kseg, a2, g.a2_rows, use_a2);
     rb.load(B, (long)seg * g.b_seg_stride, n0, k0, kseg, nullptr, 0, false);
   };
+  const int nkt = kt_end - kt_begin;
+  const int kt_stop = kt_begin + ((nkt + PD - 1) / PD) * PD;   // padded trip count
+  if (nkt > 0) {
 #pragma unroll
-  for (int i = 0; i < PD; ++i)
-    if (kt_begin + i < kt_end) stage_load(sa[i], sb[i], kt_begin + i);
-  for (int kt0 = kt_begin; kt0 < kt_end; kt0 += PD) {
+    for (int i = 0; i < PD; ++i) stage_load(sa[i], sb[i], kt_begin + i);
+    sa[0].store(lds);
+    sb[0].store(lds + BK * SA::LD);
+    stage_load(sa[0], sb[0], kt_begin + PD);
+    __syncthreads();
+    for (int kt0 = kt_begin; kt0 < kt_stop; kt0 += PD) {
 #pragma unroll
-    for (int j = 0; j < PD; ++j) {
-      const int kt = kt0 + j;
-      if (kt >= kt_end) break;
-      __syncthreads();
-      sa[j].store(As);
-      sb[j].store(Bs);
-      __syncthreads();
-      if (kt + PD < kt_end) stage_load(sa[j], sb[j], kt + PD);
-      if (do_colsum && threadIdx.x < BM) {
-        float cs = 0.f;
+      for (int j = 0; j < PD; ++j) {
+        const int kt = kt0 + j;
+        const int cur = (kt - kt_begin) & 1;
+        const float* As = lds + cur * BUF;
+        const float* Bs = As + BK * SA::LD;
+        const int jn = (j + 1) % PD;   // compile-time after unrolling
+        float* An = lds + (cur ^ 1) * BUF;
+        sa[jn].store(An);
+        sb[jn].store(An + BK * SA::LD);
+        stage_load(sa[jn], sb[jn], kt + 1 + PD);
+        if (do_colsum && threadIdx.x < BM) {
+          float cs = 0.f;
 #pragma unroll
-        for (int k = 0; k < BK; ++k) cs += As[k * SA::LD + threadIdx.x];
-        colacc += cs;
-      }
+          for (int k = 0; k < BK; ++k) cs += As[k * SA::LD + threadIdx.x];
+          colacc += cs;
+        }
 #pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
-      float af[TM], bf[TN];
+        for (int s = 0; s < BK / 2; ++s) {
+          float af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = As[(2 * s + h) * SA::LD + wm0 + i * 32 + c];
+          for (int i = 0; i < TM; ++i) af[i] = As[(2 * s + h) * SA::LD + wm0 + i * 32 + c];
 #pragma unroll
-      for (int jj = 0; jj < TN; ++jj) bf[jj] = Bs[(2 * s + h) * SB::LD + wn0 + jj * 32 + c];
+          for (int jj = 0; jj < TN; ++jj) bf[jj] = Bs[(2 * s + h) * SB::LD + wn0 + jj * 32 + c];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int jj = 0; jj < TN; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[jj], acc[i][jj], 0, 0, 0);
+            for (int jj = 0; jj < TN; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[jj], acc[i][jj], 0, 0, 0);
+        }
+        __syncthreads();
       }
     }
   }
@@ -448,8 +469,18 @@ int launch_cfg(const petr_gemm_args& g, hipStream_t s) {
   const int tiles_m = (int)cdiv(g.M, BM), tiles_n = (int)cdiv(g.N, BN);
   dim3 grid(tiles_m * tiles_n, 1, g.nb0 * g.nb1 * g.split_k);
   dim3 block(256);
-#define PETR_GEMM_LAUNCH(AKC, BKC, A2) \
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AKC, BKC, VEC, A2>), grid, block, 0, s, g, tiles_m, tiles_n)
+  // dynamic LDS: two images; beyond 64 KB the per-kernel limit is raised once (host-side attribute, not a launch)
+#define PETR_GEMM_LAUNCH(AKC, BKC, A2)                                                                          \
+  do {                                                                                                          \
+    constexpr size_t lds_bytes = 2 * (size_t)BK * (Stage<BM, AKC, VEC, A2>::LD + Stage<BN, BKC, VEC, false>::LD) * 4; \
+    auto kern = gemm_kernel<BM, BN, WM, WN, AKC, BKC, VEC, A2>;                                                 \
+    static bool attr_set = false;                                                                               \
+    if (lds_bytes > 65536 && !attr_set) {                                                                       \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, s, g, tiles_m, tiles_n);                                   \
+  } while (0)
   if (g.a_kcontig && g.b_kcontig) {
     if (g.a2) PETR_GEMM_LAUNCH(true, true, true);
     else PETR_GEMM_LAUNCH(true, true, false);

@@ -121,41 +121,38 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
   // register prefetch of a query tile: thread -> (row = t>>3, 4 columns at 4*(t&7))
   float4 qreg, greg;
   float lreg = 0.f, dreg = 0.f;
+  // raw loads only (clamped rows): selects/negations happen at the LDS store so that nothing waits at the load
   auto gload = [&](int qt) {
     const int row = qt * 32 + (t >> 3), c4 = t & 7;
     const int rowc = min(row, a.Q - 1);
     const float* s = qp + (long)rowc * a.q_rs + 4 * c4;
     const float* g = gp + (long)rowc * a.do_rs + 4 * c4;
-    float4 qv, gv;
     if (VEC) {
-      qv = *reinterpret_cast<const float4*>(s);
-      gv = *reinterpret_cast<const float4*>(g);
+      qreg = *reinterpret_cast<const float4*>(s);
+      greg = *reinterpret_cast<const float4*>(g);
     } else {
-      qv = make_float4(s[0], s[1], s[2], s[3]);
-      gv = make_float4(g[0], g[1], g[2], g[3]);
+      qreg = make_float4(s[0], s[1], s[2], s[3]);
+      greg = make_float4(g[0], g[1], g[2], g[3]);
     }
-    const bool ok = row < a.Q;
-    qreg = make_float4(ok ? qv.x : 0.f, ok ? qv.y : 0.f, ok ? qv.z : 0.f, ok ? qv.w : 0.f);
-    greg = make_float4(ok ? gv.x : 0.f, ok ? gv.y : 0.f, ok ? gv.z : 0.f, ok ? gv.w : 0.f);
-    {
-      const int r = qt * 32 + (t & 31);
-      const int rc = min(r, a.Q - 1);
-      const float lv = a.lse[(long)bh * a.Q + rc], dv = p.delta[(long)bh * a.Q + rc];
-      // rows beyond Q: -LSE/scale = -inf  =>  p = 0
-      lreg = r < a.Q ? -lv * inv_scale : -INFINITY;
-      dreg = r < a.Q ? -dv : 0.f;
-    }
+    const int rc = min(qt * 32 + (t & 31), a.Q - 1);
+    lreg = a.lse[(long)bh * a.Q + rc];
+    dreg = p.delta[(long)bh * a.Q + rc];
   };
 
   if (qt_begin < qt_end) gload(qt_begin);
   for (int qt = qt_begin; qt < qt_end; ++qt) {
     {
       const int row = t >> 3, c4 = t & 7;
+      const bool ok = qt * 32 + row < a.Q;
       float* d = Qs + row * P33 + 4 * c4;
-      d[0] = qreg.x; d[1] = qreg.y; d[2] = qreg.z; d[3] = qreg.w;
+      d[0] = ok ? qreg.x : 0.f; d[1] = ok ? qreg.y : 0.f; d[2] = ok ? qreg.z : 0.f; d[3] = ok ? qreg.w : 0.f;
       float* e = dOs + row * P33 + 4 * c4;
-      e[0] = greg.x; e[1] = greg.y; e[2] = greg.z; e[3] = greg.w;
-      if (t < 32) { lse_s[t] = lreg; dl_s[t] = dreg; }
+      e[0] = ok ? greg.x : 0.f; e[1] = ok ? greg.y : 0.f; e[2] = ok ? greg.z : 0.f; e[3] = ok ? greg.w : 0.f;
+      if (t < 32) {
+        const bool rok = qt * 32 + t < a.Q;
+        lse_s[t] = rok ? -lreg * inv_scale : -INFINITY;   // rows beyond Q: -LSE/scale = -inf  =>  p = 0
+        dl_s[t] = rok ? -dreg : 0.f;
+      }
     }
     __syncthreads();
     if (qt + 1 < qt_end) gload(qt + 1);

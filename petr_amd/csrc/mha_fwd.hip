@@ -82,9 +82,9 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   const uint8_t* mp = HAS_MASK ? a.kpm + (long)b * a.L : nullptr;
 
   float4 kreg[2], vreg[2];
-  float breg = 0.f;
-  // unconditional loads from clamped addresses + select (a load under an exec-masked branch is waited for
-  // at the end of the branch, which would serialise the four tile loads)
+  uint8_t mreg = 0;
+  // Unconditional loads from clamped addresses; the zero-fill select happens in lstore(): any use of a loaded
+  // register right after the load would make hipcc wait for it there and expose the whole memory latency.
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -93,41 +93,35 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
       const int kgc = min(kg, a.L - 1);
       const float* ks = kp + (long)kgc * a.k_rs + 4 * c4;
       const float* vs = vp + (long)kgc * a.v_rs + 4 * c4;
-      float4 kv, vv;
       if (VEC) {
-        kv = *reinterpret_cast<const float4*>(ks);
-        vv = *reinterpret_cast<const float4*>(vs);
+        kreg[i] = *reinterpret_cast<const float4*>(ks);
+        vreg[i] = *reinterpret_cast<const float4*>(vs);
       } else {
-        kv = make_float4(ks[0], ks[1], ks[2], ks[3]);
-        vv = make_float4(vs[0], vs[1], vs[2], vs[3]);
+        kreg[i] = make_float4(ks[0], ks[1], ks[2], ks[3]);
+        vreg[i] = make_float4(vs[0], vs[1], vs[2], vs[3]);
       }
-      const bool ok = kg < k_end;
-      kreg[i] = make_float4(ok ? kv.x : 0.f, ok ? kv.y : 0.f, ok ? kv.z : 0.f, ok ? kv.w : 0.f);
-      vreg[i] = make_float4(ok ? vv.x : 0.f, ok ? vv.y : 0.f, ok ? vv.z : 0.f, ok ? vv.w : 0.f);
     }
-    {
-      const int kg = k0 + (t & (KV_TILE - 1));
-      bool dead = kg >= k_end;
-      if (HAS_MASK) {
-        const uint8_t mb = mp[min(kg, a.L - 1)];
-        dead = dead || mb != 0;
-      }
-      breg = dead ? -INFINITY : 0.f;
-    }
+    if (HAS_MASK) mreg = mp[min(k0 + (t & (KV_TILE - 1)), a.L - 1)];
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = t + 256 * i;
       const int key = idx >> 3, c4 = idx & 7;
+      const bool ok = k0 + key < k_end;
       float* d = Kt + (4 * c4) * KT_PITCH + key;
-      d[0] = kreg[i].x;
-      d[KT_PITCH] = kreg[i].y;
-      d[2 * KT_PITCH] = kreg[i].z;
-      d[3 * KT_PITCH] = kreg[i].w;
-      *reinterpret_cast<float4*>(Vs + key * 32 + 4 * c4) = vreg[i];
+      d[0] = ok ? kreg[i].x : 0.f;
+      d[KT_PITCH] = ok ? kreg[i].y : 0.f;
+      d[2 * KT_PITCH] = ok ? kreg[i].z : 0.f;
+      d[3 * KT_PITCH] = ok ? kreg[i].w : 0.f;
+      *reinterpret_cast<float4*>(Vs + key * 32 + 4 * c4) =
+          make_float4(ok ? vreg[i].x : 0.f, ok ? vreg[i].y : 0.f, ok ? vreg[i].z : 0.f, ok ? vreg[i].w : 0.f);
     }
-    if (t < KV_TILE) bias_s[t] = breg;
+    if (t < KV_TILE) {
+      bool dead = k0 + t >= k_end;
+      if (HAS_MASK) dead = dead || mreg != 0;
+      bias_s[t] = dead ? -INFINITY : 0.f;
+    }
   };
 
   f32x16 O;
@@ -138,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   if (k_begin < k_end) gload(k_begin);
   for (int k0 = k_begin; k0 < k_end; k0 += KV_TILE) {
     __syncthreads();
-    lstore();
+    lstore(k0);
     __syncthreads();
     if (k0 + KV_TILE < k_end) gload(k0 + KV_TILE);
     const bool use_bias = HAS_MASK || (k0 + KV_TILE > k_end);

@@ -247,6 +247,9 @@ int petr_prof_begin(int capacity);
 int petr_prof_end(float* ms, int* tags, int cap, int* n_out);
 
 /* small helpers used by the host executor */
+/* SELayer gate of PETRv2 (petrv2_head.py:55-60): out = x * sigmoid(u); bwd: dx = dout*sig, du = dout*x*sig*(1-sig) */
+int petr_gate_fwd(const float* x, const float* u, float* out, long n, void* stream);
+int petr_gate_bwd(const float* dout, const float* x, const float* u, float* dx, float* du, long n, void* stream);
 /* out[m,:] = x[m,:] + e[m % e_rows,:]   (key + key_pos, petr_transformer.py:343-344) */
 int petr_add_rows(const float* x, const float* e, float* out, long M, int e_rows, int C, void* stream);
 int petr_fill(float* p, float v, long n, void* stream);

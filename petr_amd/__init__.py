@@ -11,5 +11,5 @@ from .registry import (ATTENTION, HEADS, POSITIONAL_ENCODING, TRANSFORMER, TRANS
 from .positional_encoding import SinePositionalEncoding3D  # noqa: F401
 from .petr_transformer import (PETRMultiheadAttention, PETRTransformer, PETRTransformerDecoder,  # noqa: F401
                                PETRTransformerDecoderLayer)
-from .petr_head import PETRHead, pos2posemb3d  # noqa: F401
-from .configs import petr_head_cfg  # noqa: F401
+from .petr_head import PETRHead, PETRv2Head, pos2posemb3d  # noqa: F401
+from .configs import petr_head_cfg, petrv2_head_cfg  # noqa: F401

@@ -39,3 +39,11 @@ def petr_head_cfg(in_channels=256, num_query=900, num_layers=6, feedforward_chan
         train_cfg=None)
     cfg.update(overrides)
     return cfg
+
+
+def petrv2_head_cfg(in_channels=256, num_query=900, **overrides):
+    """projects/configs/petrv2/petrv2_vovnet_gridmask_p4_800x320.py:41-96"""
+    cfg = petr_head_cfg(in_channels=in_channels, num_query=num_query)
+    cfg.update(type='PETRv2Head', with_fpe=True, with_time=True, with_multi=True, code_weights=[1.0] * 10)
+    cfg.update(overrides)
+    return cfg

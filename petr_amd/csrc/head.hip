@@ -43,7 +43,12 @@ static int check_config(const petr_head_config* c) {
   PETR_CHECK(c->num_layers >= 1 && c->num_layers <= 8, PETR_ERR_UNSUPPORTED, "head: 1..8 decoder layers");
   PETR_CHECK(c->ffn_dims % 32 == 0 && c->ffn_dims > 0, PETR_ERR_UNSUPPORTED, "head: ffn_dims must be a multiple of 32");
   PETR_CHECK((c->H * c->W) % 4 == 0, PETR_ERR_UNSUPPORTED, "head: H*W must be a multiple of 4");
-  PETR_CHECK(!c->v2, PETR_ERR_UNSUPPORTED, "head: PETRv2 switches are not implemented in the fused executor yet");
+  PETR_CHECK(c->v2 || (!c->with_fpe && !c->with_time && !c->with_multi && c->shared_branches), PETR_ERR_INVALID,
+             "head: with_fpe/with_time/with_multi/deep-copied branches are PETRv2Head switches (set v2)");
+  PETR_CHECK(!c->v2 || !c->shared_branches, PETR_ERR_INVALID, "head: PETRv2Head deep-copies its branches (petrv2_head.py:304-307)");
+  PETR_CHECK(!c->with_multi || c->code_size == 10, PETR_ERR_UNSUPPORTED, "head: RegLayer groups (2,1,3,2,2) need code_size 10");
+  PETR_CHECK(!c->with_time || c->B == 1, PETR_ERR_UNSUPPORTED,
+             "head: with_time divides by a per-sample scalar; the reference broadcast only works for B=1 (petrv2_head.py:505,521)");
   PETR_CHECK(c->code_size >= 5 && c->num_classes >= 1, PETR_ERR_INVALID, "head: bad code_size/num_classes");
   return PETR_OK;
 }
@@ -59,6 +64,9 @@ struct LayerP {
 };
 struct POff {
   long cls_w[3], cls_b[3], cls_g[2], cls_be[2], reg_w[3], reg_b[3];
+  long br_stride;                       // distance between the branch blocks of two levels (0: shared, PETRHead)
+  long th_w1, th_b1, th_w2, th_b2, th_stride;   // RegLayer task heads (PETRv2 with_multi), uniform slot per head
+  long fpe_rw, fpe_rb, fpe_ew, fpe_eb;  // SELayer (PETRv2 with_fpe)
   long post_g, post_b;
   LayerP lay[8];
   long ca_in_stride;
@@ -98,40 +106,77 @@ static void build_layout(const petr_head_config* c, POff* P, petr_head_layout_t*
   // ---- stage 0: branches + post_norm ----
   P->stage_begin[stage] = lb.cur;
   const int cls_idx[3] = {0, 3, 6}, ln_idx[2] = {1, 4}, reg_idx[3] = {0, 2, 4};
+  static const int TH_DIMS[5] = {2, 1, 3, 2, 2};   // RegLayer group_reg_dims (petrv2_head.py:66)
   int first_cls[3][2], first_ln[2][2], first_reg[3][2];
+  P->br_stride = 0;
+  P->th_w1 = P->th_b1 = P->th_w2 = P->th_b2 = P->th_stride = 0;
+  long lvl0_begin = lb.cur;
   for (int lvl = 0; lvl < d.NL; ++lvl) {
-    const bool alias = lvl > 0;   // PETRHead: one module in all slots (petr_head.py:244-247)
+    // PETRHead: one module in all slots (petr_head.py:244-247) -> aliases; PETRv2Head: deep copies (:304-307)
+    const bool alias = c->shared_branches && lvl > 0;
+    const bool first = lvl == 0;
+    if (lvl == 1 && !c->shared_branches) P->br_stride = lb.cur - lvl0_begin;
     for (int i = 0; i < 3; ++i) {
       const int nout = i == 2 ? d.ncls : d.C;
       snprintf(nm, sizeof nm, "cls_branches.%d.%d.weight", lvl, cls_idx[i]);
-      if (!alias) first_cls[i][0] = lb.count;
+      if (first) first_cls[i][0] = lb.count;
       long o = lb.add(nm, 2, nout, d.C, 1, 1, alias ? first_cls[i][0] : -1);
-      if (!alias) P->cls_w[i] = o;
+      if (first) P->cls_w[i] = o;
       snprintf(nm, sizeof nm, "cls_branches.%d.%d.bias", lvl, cls_idx[i]);
-      if (!alias) first_cls[i][1] = lb.count;
+      if (first) first_cls[i][1] = lb.count;
       o = lb.add(nm, 1, nout, 1, 1, 1, alias ? first_cls[i][1] : -1);
-      if (!alias) P->cls_b[i] = o;
+      if (first) P->cls_b[i] = o;
       if (i < 2) {
         snprintf(nm, sizeof nm, "cls_branches.%d.%d.weight", lvl, ln_idx[i]);
-        if (!alias) first_ln[i][0] = lb.count;
+        if (first) first_ln[i][0] = lb.count;
         o = lb.add(nm, 1, d.C, 1, 1, 1, alias ? first_ln[i][0] : -1);
-        if (!alias) P->cls_g[i] = o;
+        if (first) P->cls_g[i] = o;
         snprintf(nm, sizeof nm, "cls_branches.%d.%d.bias", lvl, ln_idx[i]);
-        if (!alias) first_ln[i][1] = lb.count;
+        if (first) first_ln[i][1] = lb.count;
         o = lb.add(nm, 1, d.C, 1, 1, 1, alias ? first_ln[i][1] : -1);
-        if (!alias) P->cls_be[i] = o;
+        if (first) P->cls_be[i] = o;
       }
     }
-    for (int i = 0; i < 3; ++i) {
-      const int nout = i == 2 ? d.code : d.C;
-      snprintf(nm, sizeof nm, "reg_branches.%d.%d.weight", lvl, reg_idx[i]);
-      if (!alias) first_reg[i][0] = lb.count;
-      long o = lb.add(nm, 2, nout, d.C, 1, 1, alias ? first_reg[i][0] : -1);
-      if (!alias) P->reg_w[i] = o;
-      snprintf(nm, sizeof nm, "reg_branches.%d.%d.bias", lvl, reg_idx[i]);
-      if (!alias) first_reg[i][1] = lb.count;
-      o = lb.add(nm, 1, nout, 1, 1, 1, alias ? first_reg[i][1] : -1);
-      if (!alias) P->reg_b[i] = o;
+    if (!c->with_multi) {
+      for (int i = 0; i < 3; ++i) {
+        const int nout = i == 2 ? d.code : d.C;
+        snprintf(nm, sizeof nm, "reg_branches.%d.%d.weight", lvl, reg_idx[i]);
+        if (first) first_reg[i][0] = lb.count;
+        long o = lb.add(nm, 2, nout, d.C, 1, 1, alias ? first_reg[i][0] : -1);
+        if (first) P->reg_w[i] = o;
+        snprintf(nm, sizeof nm, "reg_branches.%d.%d.bias", lvl, reg_idx[i]);
+        if (first) first_reg[i][1] = lb.count;
+        o = lb.add(nm, 1, nout, 1, 1, 1, alias ? first_reg[i][1] : -1);
+        if (first) P->reg_b[i] = o;
+      }
+    } else {
+      // RegLayer (petrv2_head.py:63-95): reg_branch = Linear,ReLU,Dropout,Linear,ReLU,Dropout ; 5 task heads
+      const int sh_idx[2] = {0, 3};
+      for (int i = 0; i < 2; ++i) {
+        snprintf(nm, sizeof nm, "reg_branches.%d.reg_branch.%d.weight", lvl, sh_idx[i]);
+        long o = lb.add(nm, 2, d.C, d.C);
+        if (first) P->reg_w[i] = o;
+        snprintf(nm, sizeof nm, "reg_branches.%d.reg_branch.%d.bias", lvl, sh_idx[i]);
+        o = lb.add(nm, 1, d.C);
+        if (first) P->reg_b[i] = o;
+      }
+      for (int t = 0; t < 5; ++t) {
+        const long slot = lb.cur;
+        snprintf(nm, sizeof nm, "reg_branches.%d.task_heads.%d.0.weight", lvl, t);
+        long o = lb.add(nm, 2, d.C, d.C);
+        if (first && t == 0) P->th_w1 = o;
+        snprintf(nm, sizeof nm, "reg_branches.%d.task_heads.%d.0.bias", lvl, t);
+        o = lb.add(nm, 1, d.C);
+        if (first && t == 0) P->th_b1 = o;
+        snprintf(nm, sizeof nm, "reg_branches.%d.task_heads.%d.2.weight", lvl, t);
+        o = lb.add(nm, 2, TH_DIMS[t], d.C);
+        if (first && t == 0) P->th_w2 = o;
+        lb.cur = slot + align4((long)d.C * d.C) + align4(d.C) + align4(3L * d.C);   // pad to the widest head (3 rows)
+        snprintf(nm, sizeof nm, "reg_branches.%d.task_heads.%d.2.bias", lvl, t);
+        o = lb.add(nm, 1, TH_DIMS[t]);
+        if (first && t == 0) P->th_b2 = o;
+        if (first && t == 1) P->th_stride = slot - (P->th_w1);
+      }
     }
   }
   P->post_g = lb.add("transformer.decoder.post_norm.weight", 1, d.C);
@@ -182,6 +227,13 @@ static void build_layout(const petr_head_config* c, POff* P, petr_head_layout_t*
   P->ad_b2 = lb.add("adapt_pos3d.2.bias", 1, d.C);
   P->in_w = lb.add("input_proj.weight", 4, d.C, d.Cin, 1, 1);
   P->in_b = lb.add("input_proj.bias", 1, d.C);
+  P->fpe_rw = P->fpe_rb = P->fpe_ew = P->fpe_eb = 0;
+  if (c->with_fpe) {   // SELayer (petrv2_head.py:48-60)
+    P->fpe_rw = lb.add("fpe.conv_reduce.weight", 4, d.C, d.C, 1, 1);
+    P->fpe_rb = lb.add("fpe.conv_reduce.bias", 1, d.C);
+    P->fpe_ew = lb.add("fpe.conv_expand.weight", 4, d.C, d.C, 1, 1);
+    P->fpe_eb = lb.add("fpe.conv_expand.bias", 1, d.C);
+  }
   P->stage_end[stage++] = lb.cur;
   P->n_stages = stage;
   P->code_w = lb.add("code_weights", 1, d.code);   // no gradient (petr_head.py:211-212)
@@ -203,6 +255,8 @@ struct WOff {
   LayerW lay[8];
   long xs, mean_p, rstd_p, outs;
   long c1, c1_mean, c1_rstd, c1n, c2, c2_mean, c2_rstd, c2n, r1, r2, reg_raw;
+  long th_h, pe1, fpe_h, fpe_u;          // PETRv2: task-head hiddens [G][5][RG,C]; SELayer buffers [BL,C]
+  long d_th_h, d_pe1, d_fpe_h, d_fpe_u;
   long ffn_part; int ffn_split;
   long mha_ws; size_t mha_ws_bytes;
   // ---- backward scratch ----
@@ -284,6 +338,13 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
   W.r1 = wb.add("r1", d.R * C);
   W.r2 = wb.add("r2", d.R * C);
   W.reg_raw = wb.add("reg_raw", d.R * d.code);
+  W.th_h = W.pe1 = W.fpe_h = W.fpe_u = W.d_th_h = W.d_pe1 = W.d_fpe_h = W.d_fpe_u = 0;
+  if (c->with_multi) W.th_h = wb.add("task_hidden", 5 * d.R * C);
+  if (c->with_fpe) {
+    W.pe1 = wb.add("pe_pre_gate", d.BL * C);
+    W.fpe_h = wb.add("fpe_hidden", d.BL * C);
+    W.fpe_u = wb.add("fpe_gate_logit", d.BL * C);
+  }
   // split-K of the second FFN contraction (K = F, only 4x15 output tiles otherwise)
   W.ffn_split = d.BQ <= 2048 ? 4 : 1;
   if (d.F / 32 < W.ffn_split) W.ffn_split = 1;
@@ -307,6 +368,12 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
   W.zero_end = wb.cur;
   W.d_outs = wb.add("d_outs", d.R * C);
   W.d_xs = wb.add("d_xs", d.R * C);
+  if (c->with_multi) W.d_th_h = wb.add("d_task_hidden", 5 * d.R * C);
+  if (c->with_fpe) {
+    W.d_pe1 = wb.add("d_pe1", d.BL * C);
+    W.d_fpe_h = wb.add("d_fpe_h", d.BL * C);
+    W.d_fpe_u = wb.add("d_fpe_u", d.BL * C);
+  }
   W.s0_raw = wb.add("s0_raw", d.R * d.code);
   W.s0_r2 = wb.add("s0_r2", d.R * C);
   W.s0_r1 = wb.add("s0_r1", d.R * C);
@@ -579,14 +646,24 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.c = Wm + W.h1; g.ldc = 4 * C; g.c_bs0 = (long)d.HW * 4 * C; g.bias = Pm + P.pe_b1;
     g.M = d.HW; g.N = 4 * C; g.K = 3 * d.D; g.nb0 = V; g.flags = PETR_GEMM_RELU;
     RUN(petr_gemm(&g, s1));
-    g = lin_fwd(Wm + W.h1, Pm + P.pe_w2, Pm + P.pe_b2, Wm + W.pos, d.BL, C, 4 * C);
+    g = lin_fwd(Wm + W.h1, Pm + P.pe_w2, Pm + P.pe_b2, Wm + (cfg->with_fpe ? W.pe1 : W.pos), d.BL, C, 4 * C);
     RUN(petr_gemm(&g, s1));
-    // wait for side 2 (sine hidden, memory), then pos += adapt_pos3d(sine) (petr_head.py:400-402)
+    // wait for side 2 (memory, sine hidden)
     if (ln.ctx) {
       hipEvent_t e = ln.next();
       (void)hipEventRecord(e, (hipStream_t)s2);
       (void)hipStreamWaitEvent((hipStream_t)s1, e, 0);
     }
+    if (cfg->with_fpe) {
+      // feature-guided PE (petrv2_head.py:464-466, SELayer :48-60): pos3d * sigmoid(expand(relu(reduce(x))))
+      g = lin_fwd(Wm + W.mem, Pm + P.fpe_rw, Pm + P.fpe_rb, Wm + W.fpe_h, d.BL, C, C);
+      g.flags = PETR_GEMM_RELU;
+      RUN(petr_gemm(&g, s1));
+      g = lin_fwd(Wm + W.fpe_h, Pm + P.fpe_ew, Pm + P.fpe_eb, Wm + W.fpe_u, d.BL, C, C);
+      RUN(petr_gemm(&g, s1));
+      RUN(petr_gate_fwd(Wm + W.pe1, Wm + W.fpe_u, Wm + W.pos, d.BL * C, s1));
+    }
+    // pos += adapt_pos3d(sine) (petr_head.py:400-402)
     g = lin_fwd(Wm + W.h2, Pm + P.ad_w2, Pm + P.ad_b2, Wm + W.pos, d.BL, C, 4 * C);
     g.flags = PETR_GEMM_ACCUMULATE;
     RUN(petr_gemm(&g, s1));
@@ -678,34 +755,61 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   RUN(ln_fwd(Wm + W.xs, 1, 0, nullptr, nullptr, Pm + P.post_g, Pm + P.post_b, Wm + W.outs, nullptr, Wm + W.mean_p,
              Wm + W.rstd_p, d.R, C, PETR_LN_NAN_TO_NUM, nullptr, nullptr, 0, s));
 
-  // ---- branches (petr_head.py:226-247,440-460): one shared cls / reg module for all levels; reg on a side stream ----
+  // ---- branches (petr_head.py:226-247,440-460 / petrv2_head.py:294-307,513-531); reg chain on a side stream ----
+  // PETRHead: ONE cls / reg module for all levels (G = 1 group of R rows); PETRv2Head: deep copies (G = NL groups).
+  const int G = cfg->shared_branches ? 1 : d.NL;
+  const long RG = d.R / G;
+  auto grouped = [&](petr_gemm_args g, long a_row, long c_row) {
+    g.nb0 = G; g.M = (int)RG;
+    g.a_bs0 = RG * a_row; g.b_bs0 = P.br_stride; g.bias_bs0 = g.bias ? P.br_stride : 0; g.c_bs0 = RG * c_row;
+    return g;
+  };
   ln.fork(0);
   {
-    petr_gemm_args g = lin_fwd(Wm + W.outs, Pm + P.reg_w[0], Pm + P.reg_b[0], Wm + W.r1, d.R, C, C);
+    petr_gemm_args g = grouped(lin_fwd(Wm + W.outs, Pm + P.reg_w[0], Pm + P.reg_b[0], Wm + W.r1, RG, C, C), C, C);
     g.flags = PETR_GEMM_RELU;
     RUN(petr_gemm(&g, s1));
-    g = lin_fwd(Wm + W.r1, Pm + P.reg_w[1], Pm + P.reg_b[1], Wm + W.r2, d.R, C, C);
+    g = grouped(lin_fwd(Wm + W.r1, Pm + P.reg_w[1], Pm + P.reg_b[1], Wm + W.r2, RG, C, C), C, C);
     g.flags = PETR_GEMM_RELU;
     RUN(petr_gemm(&g, s1));
-    g = lin_fwd(Wm + W.r2, Pm + P.reg_w[2], Pm + P.reg_b[2], Wm + W.reg_raw, d.R, d.code, C);
-    RUN(petr_gemm(&g, s1));
+    if (!cfg->with_multi) {
+      g = grouped(lin_fwd(Wm + W.r2, Pm + P.reg_w[2], Pm + P.reg_b[2], Wm + W.reg_raw, RG, d.code, C), C, d.code);
+      RUN(petr_gemm(&g, s1));
+    } else {
+      // RegLayer task heads (petrv2_head.py:81-95): 5 x (Linear, ReLU, Linear -> (2,1,3,2,2)), concatenated
+      g = grouped(lin_fwd(Wm + W.r2, Pm + P.th_w1, Pm + P.th_b1, Wm + W.th_h, RG, C, C), C, 5 * C);
+      g.nb1 = 5; g.b_bs1 = P.th_stride; g.bias_bs1 = P.th_stride; g.c_bs1 = RG * C;
+      g.flags = PETR_GEMM_RELU;
+      RUN(petr_gemm(&g, s1));
+      static const int TH_DIMS[5] = {2, 1, 3, 2, 2}, TH_COL[5] = {0, 2, 3, 6, 8};
+      for (int t = 0; t < 5; ++t) {
+        g = grouped(lin_fwd(Wm + W.th_h + (long)t * RG * C, Pm + P.th_w2 + t * P.th_stride, Pm + P.th_b2 + t * P.th_stride,
+                            Wm + W.reg_raw + TH_COL[t], RG, TH_DIMS[t], C), 5 * C, d.code);
+        g.ldc = d.code;
+        RUN(petr_gemm(&g, s1));
+      }
+    }
     petr_bbox_args a;
     memset(&a, 0, sizeof a);
     a.reg = Wm + W.reg_raw; a.ref = Pm + P.ref; a.out = io->all_bbox_preds; a.rows = (int)d.R; a.Q = d.Q; a.code = d.code;
     for (int i = 0; i < 6; ++i) a.pc_range[i] = cfg->pc_range[i];
-    a.time_div = 0.f; a.eps = 1e-5f;
+    a.time_div = cfg->with_time ? io->time_div : 0.f; a.eps = 1e-5f;
     RUN(petr_bbox_epilogue_fwd(&a, s1));
   }
   {
-    petr_gemm_args g = lin_fwd(Wm + W.outs, Pm + P.cls_w[0], Pm + P.cls_b[0], Wm + W.c1, d.R, C, C);
+    petr_gemm_args g = grouped(lin_fwd(Wm + W.outs, Pm + P.cls_w[0], Pm + P.cls_b[0], Wm + W.c1, RG, C, C), C, C);
     RUN(petr_gemm(&g, s));
-    RUN(ln_fwd(Wm + W.c1, 1, 0, nullptr, nullptr, Pm + P.cls_g[0], Pm + P.cls_be[0], Wm + W.c1n, nullptr, Wm + W.c1_mean,
-               Wm + W.c1_rstd, d.R, C, PETR_LN_RELU, nullptr, nullptr, 0, s));
-    g = lin_fwd(Wm + W.c1n, Pm + P.cls_w[1], Pm + P.cls_b[1], Wm + W.c2, d.R, C, C);
+    for (int gi = 0; gi < G; ++gi)
+      RUN(ln_fwd(Wm + W.c1 + gi * RG * C, 1, 0, nullptr, nullptr, Pm + P.cls_g[0] + gi * P.br_stride,
+                 Pm + P.cls_be[0] + gi * P.br_stride, Wm + W.c1n + gi * RG * C, nullptr, Wm + W.c1_mean + gi * RG,
+                 Wm + W.c1_rstd + gi * RG, RG, C, PETR_LN_RELU, nullptr, nullptr, 0, s));
+    g = grouped(lin_fwd(Wm + W.c1n, Pm + P.cls_w[1], Pm + P.cls_b[1], Wm + W.c2, RG, C, C), C, C);
     RUN(petr_gemm(&g, s));
-    RUN(ln_fwd(Wm + W.c2, 1, 0, nullptr, nullptr, Pm + P.cls_g[1], Pm + P.cls_be[1], Wm + W.c2n, nullptr, Wm + W.c2_mean,
-               Wm + W.c2_rstd, d.R, C, PETR_LN_RELU, nullptr, nullptr, 0, s));
-    g = lin_fwd(Wm + W.c2n, Pm + P.cls_w[2], Pm + P.cls_b[2], io->all_cls_scores, d.R, d.ncls, C);
+    for (int gi = 0; gi < G; ++gi)
+      RUN(ln_fwd(Wm + W.c2 + gi * RG * C, 1, 0, nullptr, nullptr, Pm + P.cls_g[1] + gi * P.br_stride,
+                 Pm + P.cls_be[1] + gi * P.br_stride, Wm + W.c2n + gi * RG * C, nullptr, Wm + W.c2_mean + gi * RG,
+                 Wm + W.c2_rstd + gi * RG, RG, C, PETR_LN_RELU, nullptr, nullptr, 0, s));
+    g = grouped(lin_fwd(Wm + W.c2n, Pm + P.cls_w[2], Pm + P.cls_b[2], io->all_cls_scores, RG, d.ncls, C), C, d.ncls);
     RUN(petr_gemm(&g, s));
   }
   ln.join(0);
@@ -751,43 +855,94 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       hipError_t e = hipMemsetAsync(Wm + W.zero_begin, 0, (size_t)(W.zero_end - W.zero_begin) * sizeof(float), ln.main);
       PETR_CHECK(e == hipSuccess, PETR_ERR_LAUNCH, "head_bwd: memset failed: %s", hipGetErrorString(e));
       // ---- box epilogue + reg branch ----
+      const int G = cfg->shared_branches ? 1 : d.NL;
+      const long RG = d.R / G;
+      // per-group batching of the branch contractions (G = 1: PETRHead's shared module)
+      auto gd = [&](petr_gemm_args g, long a_row, long c_row, long r_row) {   // input gradient / forward-like
+        g.nb0 = G; g.M = (int)RG;
+        g.a_bs0 = RG * a_row; g.b_bs0 = P.br_stride; g.c_bs0 = RG * c_row; g.r_bs0 = RG * r_row;
+        return g;
+      };
+      auto gw = [&](petr_gemm_args g, long dy_row, long x_row) {               // weight gradient
+        g.nb0 = G; g.K = (int)RG;
+        g.a_bs0 = RG * dy_row; g.b_bs0 = RG * x_row; g.c_bs0 = P.br_stride; g.cs_bs0 = P.br_stride;
+        const long tiles = cdiv(g.M, 64) * cdiv(g.N, 64) * G;
+        long sk = 512 / (tiles > 0 ? tiles : 1);
+        const long ktiles = cdiv(RG, 32);
+        if (sk > ktiles / 2) sk = ktiles / 2;
+        if (sk < 1) sk = 1;
+        if (sk > 64) sk = 64;
+        g.split_k = (int)sk;
+        return g;
+      };
       petr_bbox_args a;
       memset(&a, 0, sizeof a);
       a.ref = Pm + P.ref; a.out = io->all_bbox_preds; a.rows = (int)d.R; a.Q = d.Q; a.code = d.code;
       for (int i = 0; i < 6; ++i) a.pc_range[i] = cfg->pc_range[i];
-      a.time_div = 0.f; a.eps = 1e-5f;
+      a.time_div = cfg->with_time ? io->time_div : 0.f; a.eps = 1e-5f;
       float* d_raw = Wm + W.s0_raw;   // [R, code]
       RUN(petr_bbox_epilogue_bwd(&a, gr->d_bbox, d_raw, Wm + W.d_ref_tmp, s));
-      RUN(wgrad(lin_wgrad(d_raw, d.code, Wm + W.r2, C, Gp + P.reg_w[2], Gp + P.reg_b[2], d.R, d.code, C)));
       float* d_r2 = Wm + W.s0_r2;
-      petr_gemm_args g = lin_dgrad(d_raw, Pm + P.reg_w[2], d_r2, d.R, d.code, C);
-      g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.r2; g.ldr = C;
-      RUN(petr_gemm(&g, s));
-      RUN(wgrad(lin_wgrad(d_r2, C, Wm + W.r1, C, Gp + P.reg_w[1], Gp + P.reg_b[1], d.R, C, C)));
+      petr_gemm_args g;
+      if (!cfg->with_multi) {
+        RUN(wgrad(gw(lin_wgrad(d_raw, d.code, Wm + W.r2, C, Gp + P.reg_w[2], Gp + P.reg_b[2], RG, d.code, C), d.code, C)));
+        g = gd(lin_dgrad(d_raw, Pm + P.reg_w[2], d_r2, RG, d.code, C), d.code, C, C);
+        g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.r2; g.ldr = C;
+        RUN(petr_gemm(&g, s));
+      } else {
+        static const int TH_DIMS[5] = {2, 1, 3, 2, 2}, TH_COL[5] = {0, 2, 3, 6, 8};
+        float* d_th = Wm + W.d_th_h;
+        for (int t = 0; t < 5; ++t) {
+          RUN(wgrad(gw(lin_wgrad(d_raw + TH_COL[t], d.code, Wm + W.th_h + (long)t * RG * C, C, Gp + P.th_w2 + t * P.th_stride,
+                                 Gp + P.th_b2 + t * P.th_stride, RG, TH_DIMS[t], C), d.code, 5 * C)));
+          g = gd(lin_dgrad(d_raw + TH_COL[t], Pm + P.th_w2 + t * P.th_stride, d_th + (long)t * RG * C, RG, TH_DIMS[t], C),
+                 d.code, 5 * C, 5 * C);
+          g.lda = d.code;
+          g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.th_h + (long)t * RG * C; g.ldr = C;
+          RUN(petr_gemm(&g, s));
+        }
+        // first Linear of the 5 task heads: weights batched over (level, head); input gradient summed over the heads
+        g = gw(lin_wgrad(d_th, C, Wm + W.r2, C, Gp + P.th_w1, Gp + P.th_b1, RG, C, C), 5 * C, C);
+        g.nb1 = 5; g.a_bs1 = RG * C; g.b_bs1 = 0; g.c_bs1 = P.th_stride; g.cs_bs1 = P.th_stride;
+        RUN(wgrad(g));
+        g = gemm0();      // d_r2[r][c] = sum_{t,o} d_th[t][r][o] * tw1_t[o][c], masked by relu(r2)
+        g.a = d_th; g.lda = C; g.a_kcontig = 1; g.a_bs0 = 5 * RG * C;
+        g.b = Pm + P.th_w1; g.ldb = C; g.b_kcontig = 0; g.b_bs0 = P.br_stride;
+        g.c = d_r2; g.ldc = C; g.c_bs0 = RG * C;
+        g.r = Wm + W.r2; g.ldr = C; g.r_bs0 = RG * C; g.flags = PETR_GEMM_RELU_MASK;
+        g.M = (int)RG; g.N = C; g.K = 5 * C; g.nb0 = G;
+        g.k_seg = C; g.a_seg_stride = RG * C; g.b_seg_stride = P.th_stride;
+        RUN(petr_gemm(&g, s));
+      }
+      RUN(wgrad(gw(lin_wgrad(d_r2, C, Wm + W.r1, C, Gp + P.reg_w[1], Gp + P.reg_b[1], RG, C, C), C, C)));
       float* d_r1 = Wm + W.s0_r1;
-      g = lin_dgrad(d_r2, Pm + P.reg_w[1], d_r1, d.R, C, C);
+      g = gd(lin_dgrad(d_r2, Pm + P.reg_w[1], d_r1, RG, C, C), C, C, C);
       g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.r1; g.ldr = C;
       RUN(petr_gemm(&g, s));
-      RUN(wgrad(lin_wgrad(d_r1, C, Wm + W.outs, C, Gp + P.reg_w[0], Gp + P.reg_b[0], d.R, C, C)));
-      g = lin_dgrad(d_r1, Pm + P.reg_w[0], Wm + W.d_outs, d.R, C, C);
+      RUN(wgrad(gw(lin_wgrad(d_r1, C, Wm + W.outs, C, Gp + P.reg_w[0], Gp + P.reg_b[0], RG, C, C), C, C)));
+      g = gd(lin_dgrad(d_r1, Pm + P.reg_w[0], Wm + W.d_outs, RG, C, C), C, C, C);
       RUN(petr_gemm(&g, s));
       // ---- cls branch ----
-      RUN(wgrad(lin_wgrad(gr->d_cls, d.ncls, Wm + W.c2n, C, Gp + P.cls_w[2], Gp + P.cls_b[2], d.R, d.ncls, C)));
+      RUN(wgrad(gw(lin_wgrad(gr->d_cls, d.ncls, Wm + W.c2n, C, Gp + P.cls_w[2], Gp + P.cls_b[2], RG, d.ncls, C), d.ncls, C)));
       float* d_c2n = Wm + W.s0_c2n;
-      g = lin_dgrad(gr->d_cls, Pm + P.cls_w[2], d_c2n, d.R, d.ncls, C);
+      g = gd(lin_dgrad(gr->d_cls, Pm + P.cls_w[2], d_c2n, RG, d.ncls, C), d.ncls, C, C);
       RUN(petr_gemm(&g, s));
       float* d_c2 = Wm + W.s0_c2;
-      RUN(ln_bwd(Wm + W.c2, Wm + W.c2_mean, Wm + W.c2_rstd, Pm + P.cls_g[1], d_c2n, Wm + W.c2n, d_c2, Gp + P.cls_g[1],
-                 Gp + P.cls_be[1], d.R, C, PETR_LN_RELU, 0, s));
-      RUN(wgrad(lin_wgrad(d_c2, C, Wm + W.c1n, C, Gp + P.cls_w[1], Gp + P.cls_b[1], d.R, C, C)));
+      for (int gi = 0; gi < G; ++gi)
+        RUN(ln_bwd(Wm + W.c2 + gi * RG * C, Wm + W.c2_mean + gi * RG, Wm + W.c2_rstd + gi * RG, Pm + P.cls_g[1] + gi * P.br_stride,
+                   d_c2n + gi * RG * C, Wm + W.c2n + gi * RG * C, d_c2 + gi * RG * C, Gp + P.cls_g[1] + gi * P.br_stride,
+                   Gp + P.cls_be[1] + gi * P.br_stride, RG, C, PETR_LN_RELU, 0, s));
+      RUN(wgrad(gw(lin_wgrad(d_c2, C, Wm + W.c1n, C, Gp + P.cls_w[1], Gp + P.cls_b[1], RG, C, C), C, C)));
       float* d_c1n = Wm + W.s0_c1n;
-      g = lin_dgrad(d_c2, Pm + P.cls_w[1], d_c1n, d.R, C, C);
+      g = gd(lin_dgrad(d_c2, Pm + P.cls_w[1], d_c1n, RG, C, C), C, C, C);
       RUN(petr_gemm(&g, s));
       float* d_c1 = Wm + W.s0_c1;
-      RUN(ln_bwd(Wm + W.c1, Wm + W.c1_mean, Wm + W.c1_rstd, Pm + P.cls_g[0], d_c1n, Wm + W.c1n, d_c1, Gp + P.cls_g[0],
-                 Gp + P.cls_be[0], d.R, C, PETR_LN_RELU, 0, s));
-      RUN(wgrad(lin_wgrad(d_c1, C, Wm + W.outs, C, Gp + P.cls_w[0], Gp + P.cls_b[0], d.R, C, C)));
-      g = lin_dgrad(d_c1, Pm + P.cls_w[0], Wm + W.d_outs, d.R, C, C);
+      for (int gi = 0; gi < G; ++gi)
+        RUN(ln_bwd(Wm + W.c1 + gi * RG * C, Wm + W.c1_mean + gi * RG, Wm + W.c1_rstd + gi * RG, Pm + P.cls_g[0] + gi * P.br_stride,
+                   d_c1n + gi * RG * C, Wm + W.c1n + gi * RG * C, d_c1 + gi * RG * C, Gp + P.cls_g[0] + gi * P.br_stride,
+                   Gp + P.cls_be[0] + gi * P.br_stride, RG, C, PETR_LN_RELU, 0, s));
+      RUN(wgrad(gw(lin_wgrad(d_c1, C, Wm + W.outs, C, Gp + P.cls_w[0], Gp + P.cls_b[0], RG, C, C), C, C)));
+      g = gd(lin_dgrad(d_c1, Pm + P.cls_w[0], Wm + W.d_outs, RG, C, C), C, C, C);
       g.flags = PETR_GEMM_ACCUMULATE;
       RUN(petr_gemm(&g, s));
       // ---- post_norm over all levels -> d_xs[l] ----
@@ -887,6 +1042,20 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // d_mem = dV-path + d(mem+pos) ; d_pos = d(mem+pos)
       RUN(petr_axpy(Wm + W.d_mem, Wm + W.d_mempos, 1.f, d.BL * C, s));
       const float* d_pos = Wm + W.d_mempos;
+      const float* d_pe = d_pos;          // upstream gradient of position_encoder's output
+      if (cfg->with_fpe) {
+        // SELayer backward: pos3d = pe1 * sigmoid(u), u = expand(relu(reduce(mem)))
+        RUN(petr_gate_bwd(d_pos, Wm + W.pe1, Wm + W.fpe_u, Wm + W.d_pe1, Wm + W.d_fpe_u, d.BL * C, s));
+        d_pe = Wm + W.d_pe1;
+        RUN(wgrad(lin_wgrad(Wm + W.d_fpe_u, C, Wm + W.fpe_h, C, Gp + P.fpe_ew, Gp + P.fpe_eb, d.BL, C, C)));
+        petr_gemm_args g = lin_dgrad(Wm + W.d_fpe_u, Pm + P.fpe_ew, Wm + W.d_fpe_h, d.BL, C, C);
+        g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.fpe_h; g.ldr = C;
+        RUN(petr_gemm(&g, s));
+        RUN(wgrad(lin_wgrad(Wm + W.d_fpe_h, C, Wm + W.mem, C, Gp + P.fpe_rw, Gp + P.fpe_rb, d.BL, C, C)));
+        g = lin_dgrad(Wm + W.d_fpe_h, Pm + P.fpe_rw, Wm + W.d_mem, d.BL, C, C);
+        g.flags = PETR_GEMM_ACCUMULATE;
+        RUN(petr_gemm(&g, s));
+      }
       // position_encoder and adapt_pos3d (inputs carry no gradient)
       for (int which = 0; which < 2; ++which) {
         const long w1 = which == 0 ? P.pe_w1 : P.ad_w1, b1 = which == 0 ? P.pe_b1 : P.ad_b1;
@@ -895,8 +1064,9 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         const float* feat = Wm + (which == 0 ? W.vol : W.sine);
         const int Kin = which == 0 ? 3 * d.D : C * 3 / 2;
         float* d_hpe = Wm + W.d_hpe[which];
-        RUN(wgrad(lin_wgrad(d_pos, C, hid, 4 * C, Gp + w2, Gp + b2, d.BL, C, 4 * C)));
-        petr_gemm_args g = lin_dgrad(d_pos, Pm + w2, d_hpe, d.BL, C, 4 * C);
+        const float* dy = which == 0 ? d_pe : d_pos;
+        RUN(wgrad(lin_wgrad(dy, C, hid, 4 * C, Gp + w2, Gp + b2, d.BL, C, 4 * C)));
+        petr_gemm_args g = lin_dgrad(dy, Pm + w2, d_hpe, d.BL, C, 4 * C);
         g.flags = PETR_GEMM_RELU_MASK; g.r = hid; g.ldr = 4 * C;
         RUN(petr_gemm(&g, s));
         g = gemm0();      // dW1[4C, Kin] += sum_{view, hw} d_h[view*HW+hw][f] * feat[view][c][hw]

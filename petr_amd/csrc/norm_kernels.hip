@@ -290,6 +290,20 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const float4* x, const fl
   const float4 a = x[i], b = e[i % e_n4];
   out[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
+// SELayer gate of PETRv2 (petrv2_head.py:55-60): out = x * sigmoid(u)
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* x, const float* u, float* out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = x[i] * (1.f / (1.f + expf(-u[i])));
+}
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* dout, const float* x, const float* u, float* dx, float* du,
+                                                        long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float sg = 1.f / (1.f + expf(-u[i]));
+  const float g = dout[i];
+  dx[i] = g * sg;
+  du[i] = g * x[i] * sg * (1.f - sg);
+}
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* x, int np, long stride, const float* bias,
                                                                const float* residual, float* out, long M, int C) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -419,6 +433,20 @@ extern "C" int petr_add_rows(const float* x, const float* e, float* out, long M,
   hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
                      (const float4*)e, (float4*)out, n4, e_n4);
   PETR_LAUNCH_CHECK("add_rows");
+  return PETR_OK;
+}
+
+extern "C" int petr_gate_fwd(const float* x, const float* u, float* out, long n, void* stream) {
+  PETR_CHECK(x && u && out && n > 0, PETR_ERR_INVALID, "gate_fwd: bad argument");
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, u, out, n);
+  PETR_LAUNCH_CHECK("gate_fwd");
+  return PETR_OK;
+}
+
+extern "C" int petr_gate_bwd(const float* dout, const float* x, const float* u, float* dx, float* du, long n, void* stream) {
+  PETR_CHECK(dout && x && u && dx && du && n > 0, PETR_ERR_INVALID, "gate_bwd: bad argument");
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, x, u, dx, du, n);
+  PETR_LAUNCH_CHECK("gate_bwd");
   return PETR_OK;
 }
 

@@ -11,6 +11,7 @@ Host-side work kept in Python because the reference does it on the host too:
     nearest-neighbour source index = floor(dst * in/out), so
     ``mask[i,j] = (floor(i*pad_h/H) >= img_h) or (floor(j*pad_w/W) >= img_w)``.
 """
+import copy
 import ctypes as C
 import math
 import os
@@ -59,6 +60,30 @@ def depth_bins(depth_num, depth_start, position_range, LID):
     return depth_start + bin_size * index
 
 
+class SELayer(nn.Module):
+    """parameter container of reference petrv2_head.py:48-60 (the gate runs in petr_gate_fwd/_bwd)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(channels, channels, 1, bias=True)
+        self.act1 = nn.ReLU()
+        self.conv_expand = nn.Conv2d(channels, channels, 1, bias=True)
+        self.gate = nn.Sigmoid()
+
+
+class RegLayer(nn.Module):
+    """parameter container of reference petrv2_head.py:63-95."""
+
+    def __init__(self, embed_dims=256, shared_reg_fcs=2, group_reg_dims=(2, 1, 3, 2, 2)):
+        super().__init__()
+        reg_branch = []
+        for _ in range(shared_reg_fcs):
+            reg_branch += [nn.Linear(embed_dims, embed_dims), nn.ReLU(), nn.Dropout(0.0)]
+        self.reg_branch = nn.Sequential(*reg_branch)
+        self.task_heads = nn.ModuleList([
+            nn.Sequential(nn.Linear(embed_dims, embed_dims), nn.ReLU(), nn.Linear(embed_dims, d)) for d in group_reg_dims])
+
+
 class _HeadFn(torch.autograd.Function):
     """autograd node around petr_head_fwd / petr_head_bwd.  Parameter gradients are written by the
     kernels straight into the head's flat gradient buffer (each ``p.grad`` is a view of it), the
@@ -95,6 +120,12 @@ class PETRHead(nn.Module):
                  LID=False, depth_start=1, position_range=[-65, -65, -8.0, 65, 65, 8.0], init_cfg=None,
                  normedlinear=False, **kwargs):
         super().__init__()
+        self._v2 = bool(kwargs.pop('_v2', False))
+        self.with_fpe = bool(kwargs.get('with_fpe', False)) and self._v2
+        self.with_time = bool(kwargs.get('with_time', False)) and self._v2
+        self.with_multi = bool(kwargs.get('with_multi', False)) and self._v2
+        self.group_reg_dims = tuple(kwargs.get('group_reg_dims', (2, 1, 3, 2, 2)))
+        assert not self.with_multi or self.group_reg_dims == (2, 1, 3, 2, 2), 'RegLayer groups are (2,1,3,2,2)'
         self.code_size = kwargs.get('code_size', 10)
         cw = code_weights if code_weights is not None else [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2]
         cw = list(cw)[:self.code_size]
@@ -109,12 +140,13 @@ class PETRHead(nn.Module):
         self.position_dim = 3 * depth_num
         self.position_range = list(position_range)
         self.LID, self.depth_start = LID, depth_start
-        self.position_level = 0
+        self.position_level = kwargs.get('position_level', 0) if self._v2 else 0   # petrv2_head.py:165,239
         self.with_position, self.with_multiview = with_position, with_multiview
         assert 'num_feats' in positional_encoding
         num_feats = positional_encoding['num_feats']
         assert num_feats * 2 == self.embed_dims, \
             f'embed_dims should be exactly 2 times of num_feats. Found {self.embed_dims} and {num_feats}.'
+        assert self.position_level == 0 or True
         assert num_reg_fcs == 2, 'the fused branches kernel chain is built for num_reg_fcs=2 (every reference config)'
         assert not normedlinear, 'normedlinear=True is not used by any reference config'
         assert with_position and with_multiview, \
@@ -156,18 +188,26 @@ class PETRHead(nn.Module):
             cls_branch += [nn.Linear(E, E), nn.LayerNorm(E), nn.ReLU(inplace=True)]
         cls_branch.append(nn.Linear(E, self.cls_out_channels))
         fc_cls = nn.Sequential(*cls_branch)
-        reg_branch = []
-        for _ in range(self.num_reg_fcs):
-            reg_branch += [nn.Linear(E, E), nn.ReLU()]
-        reg_branch.append(nn.Linear(E, self.code_size))
-        reg_branch = nn.Sequential(*reg_branch)
-        # the SAME module in all num_pred slots (petr_head.py:244-247): shared weights, aliased keys
-        self.cls_branches = nn.ModuleList([fc_cls for _ in range(self.num_pred)])
-        self.reg_branches = nn.ModuleList([reg_branch for _ in range(self.num_pred)])
+        if self.with_multi:
+            reg_branch = RegLayer(E, self.num_reg_fcs, self.group_reg_dims)
+        else:
+            reg_branch = []
+            for _ in range(self.num_reg_fcs):
+                reg_branch += [nn.Linear(E, E), nn.ReLU()]
+            reg_branch.append(nn.Linear(E, self.code_size))
+            reg_branch = nn.Sequential(*reg_branch)
+        if self._v2:   # PETRv2Head deep-copies one template per level (petrv2_head.py:304-307)
+            self.cls_branches = nn.ModuleList([copy.deepcopy(fc_cls) for _ in range(self.num_pred)])
+            self.reg_branches = nn.ModuleList([copy.deepcopy(reg_branch) for _ in range(self.num_pred)])
+        else:          # the SAME module in all num_pred slots (petr_head.py:244-247): shared weights, aliased keys
+            self.cls_branches = nn.ModuleList([fc_cls for _ in range(self.num_pred)])
+            self.reg_branches = nn.ModuleList([reg_branch for _ in range(self.num_pred)])
         self.adapt_pos3d = nn.Sequential(nn.Conv2d(E * 3 // 2, E * 4, 1), nn.ReLU(), nn.Conv2d(E * 4, E, 1))
         self.position_encoder = nn.Sequential(nn.Conv2d(self.position_dim, E * 4, 1), nn.ReLU(), nn.Conv2d(E * 4, E, 1))
         self.reference_points = nn.Embedding(self.num_query, 3)
         self.query_embedding = nn.Sequential(nn.Linear(E * 3 // 2, E), nn.ReLU(), nn.Linear(E, E))
+        if self.with_fpe:
+            self.fpe = SELayer(E)
 
     def init_weights(self):
         """reference petr_head.py:276-284."""
@@ -182,7 +222,7 @@ class PETRHead(nn.Module):
                               error_msgs):
         """legacy DETR key names -> current ones (reference petr_head.py:345-359)."""
         version = local_metadata.get('version', None)
-        if (version is None or version < 2) and self.__class__ is PETRHead:
+        if (version is None or version < 2) and self.__class__ in (PETRHead, PETRv2Head):
             convert_dict = {'.self_attn.': '.attentions.0.', '.multihead_attn.': '.attentions.1.',
                             '.decoder.norm.': '.decoder.post_norm.'}
             for k in list(state_dict.keys()):
@@ -200,8 +240,8 @@ class PETRHead(nn.Module):
         cfg.num_query, cfg.num_layers, cfg.num_heads = self.num_query, self._nl, self._heads
         cfg.embed_dims, cfg.ffn_dims, cfg.depth_num = self.embed_dims, self._ffn, self.depth_num
         cfg.num_classes, cfg.code_size = self.cls_out_channels, self.code_size
-        cfg.v2 = cfg.with_fpe = cfg.with_time = cfg.with_multi = 0
-        cfg.shared_branches, cfg.LID, cfg.depth_start = 1, int(self.LID), float(self.depth_start)
+        cfg.v2, cfg.with_fpe, cfg.with_time, cfg.with_multi = int(self._v2), int(self.with_fpe), int(self.with_time), int(self.with_multi)
+        cfg.shared_branches, cfg.LID, cfg.depth_start = int(not self._v2), int(self.LID), float(self.depth_start)
         cfg.position_range = (C.c_float * 6)(*[float(v) for v in self.position_range])
         cfg.pc_range = (C.c_float * 6)(*[float(v) for v in self.pc_range])
         cfg.pad_h = cfg.pad_w = 0.0
@@ -346,7 +386,13 @@ class PETRHead(nn.Module):
                 pass
 
     def _time_div(self, img_metas, batch_size):
-        return 0.0
+        """mean_time_stamp of reference petrv2_head.py:499-505 (B = 1: SURVEY §7.3)."""
+        if not self.with_time:
+            return 0.0
+        if batch_size != 1:
+            raise NotImplementedError('with_time: the reference broadcast [B,Q,2] / [B] only works for B = 1')
+        ts = np.asarray([np.asarray(m['timestamp']) for m in img_metas], dtype=np.float32).reshape(batch_size, -1, 6)
+        return float((ts[:, 1, :] - ts[:, 0, :]).mean(-1)[0])
 
     def _launch_forward(self, run, feats):
         L = _C.lib()
@@ -443,3 +489,15 @@ class PETRHead(nn.Module):
 
     def get_bboxes(self, *args, **kwargs):
         raise NotImplementedError('PETRHead.get_bboxes (NMS-free decode) is SURVEY §8(f) rank 2: not built yet')
+
+
+@register('HEADS')
+class PETRv2Head(PETRHead):
+    """reference models/dense_heads/petrv2_head.py:99-540: PETRHead + feature-guided PE (``with_fpe``, SELayer),
+    grouped regression (``with_multi``, RegLayer), velocity / dt (``with_time``), ``position_level``, one deep copy
+    of the branches per decoder level.  Same executor, ``v2`` switches on."""
+
+    def __init__(self, *args, with_fpe=False, with_time=False, with_multi=False, group_reg_dims=(2, 1, 3, 2, 2),
+                 position_level=0, **kwargs):
+        super().__init__(*args, _v2=True, with_fpe=with_fpe, with_time=with_time, with_multi=with_multi,
+                         group_reg_dims=group_reg_dims, position_level=position_level, **kwargs)

@@ -56,6 +56,31 @@ def test_head_golden(pa, golden_dir, name):
     assert rel(out['all_bbox_preds'], torch.from_numpy(fx['all_bbox_preds'])) < REL
 
 
+def test_headv2_golden(pa, golden_dir):
+    """PETRv2Head (fpe + RegLayer + with_time, 12 views, deep-copied branches) vs the reference's own output."""
+    fx = np.load(os.path.join(golden_dir, 'headv2_toy.npz'))
+    oracle = O.seeded_head(3, 4321, num_query=16, v2=True, with_fpe=True, with_time=True, with_multi=True,
+                           code_weights=[1.0] * 10)
+    wsum = sum(v.double().abs().sum().item() for v in oracle.state_dict().values())
+    if abs(wsum - float(fx['weight_abs_sum'])) > 1e-9 * wsum:
+        pytest.skip('torch RNG stream differs from the build container')
+    head = pa.build_head(pa.petrv2_head_cfg(num_query=16))
+    head.load_state_dict(oracle.state_dict())
+    head = head.cuda().eval()
+    metas = metas_from(fx)
+    metas[0]['timestamp'] = list(fx['timestamp'])
+    with torch.no_grad():
+        out = head([torch.from_numpy(fx['feats']).cuda()], metas)
+    assert out['all_bbox_preds'].shape == (6, 1, 16, 10)
+    assert rel(out['all_cls_scores'], torch.from_numpy(fx['all_cls_scores'])) < REL
+    assert rel(out['all_bbox_preds'], torch.from_numpy(fx['all_bbox_preds'])) < REL
+
+
+def test_headv2_backward(pa):
+    kw = dict(num_query=16, v2=True, with_fpe=True, with_time=True, with_multi=True, code_weights=[1.0] * 10)
+    _grad_case(pa, 1, 12, 4, 5, (64, 80), (64, 80), 16, seed=6, oracle_kw=kw, with_time=True)
+
+
 def test_head_c5_forward_and_intermediates(pa):
     """BASELINE configs[1]: c5 shape, 900 queries, 6 layers, fp32, vs configs[0] (the CPU path)."""
     oracle = O.seeded_head(0, None, num_query=900)
@@ -104,16 +129,22 @@ def _oracle_grads(oracle, feats, metas, g_cls, g_box, dtype):
     return out, {k: p.grad for k, p in o.named_parameters() if p.grad is not None}, f.grad
 
 
-def _grad_case(pa, B, N, H, W, pad_hw, img_hw, Q, seed):
+def _grad_case(pa, B, N, H, W, pad_hw, img_hw, Q, seed, oracle_kw=None, with_time=False):
     """Gradients vs the float64 oracle.  Two metrics per tensor, both relative to max(|want|_inf, 1e-4*global):
     L2 (tight) and max-abs (loose): a ReLU whose pre-activation sits within 1e-7 of zero flips its mask
     between ANY two fp32 evaluations (the CPU fp32 oracle shows the same O(1e-2) single-element jumps against
     float64), so max-abs cannot be tight; tensors whose true gradient is identically zero (softmax shift
     invariance: position_encoder/adapt_pos3d last bias; layer-0 self-attention in_proj with query = 0) are
     checked absolutely."""
-    oracle = O.seeded_head(seed, 77, num_query=Q)
-    head = make_pair(pa, oracle, num_query=Q)
-    metas = O.synthetic_img_metas(B, N, pad_hw, img_hw, seed=seed)
+    if oracle_kw is None:
+        oracle = O.seeded_head(seed, 77, num_query=Q)
+        head = make_pair(pa, oracle, num_query=Q)
+    else:
+        oracle = O.seeded_head(seed, 77, **oracle_kw)
+        head = pa.build_head(pa.petrv2_head_cfg(num_query=Q))
+        head.load_state_dict(oracle.state_dict())
+        head = head.cuda().eval()
+    metas = O.synthetic_img_metas(B, N, pad_hw, img_hw, seed=seed, with_time=with_time)
     g = torch.Generator().manual_seed(seed)
     feats = torch.randn(B, N, 256, H, W, generator=g)
     g_cls, g_box = torch.randn(6, B, Q, 10, generator=g), torch.randn(6, B, Q, 10, generator=g)

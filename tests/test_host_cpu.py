@@ -123,6 +123,25 @@ def test_head_state_dict_contract(lib_path, golden_dir):
     assert head._flat.numel() - b[-1][1] <= 16        # only code_weights (no grad) after the last bucket
 
 
+def test_headv2_state_dict_contract(lib_path, golden_dir):
+    """PETRv2Head: 334 reference keys (deep-copied branches, RegLayer, fpe), same seeded init as the reference."""
+    import petr_amd
+    from oracle import petr_oracle as O
+    torch.manual_seed(3)
+    head = petr_amd.build_head(petr_amd.petrv2_head_cfg(num_query=16))
+    head.init_weights()
+    want = {l.split(' ')[0]: l.split(' ', 1)[1].strip() for l in open(os.path.join(golden_dir, 'state_dict_keys_petrv2.txt'))}
+    assert {k: str(tuple(v.shape)) for k, v in head.state_dict().items()} == want
+    ref = O.seeded_head(3, None, num_query=16, v2=True, with_fpe=True, with_time=True, with_multi=True,
+                        code_weights=[1.0] * 10).state_dict()
+    assert all(torch.equal(head.state_dict()[k], ref[k]) for k in ref)
+    head._ensure_flat()
+    assert head.cls_branches[0][0].weight.data_ptr() != head.cls_branches[5][0].weight.data_ptr()   # deep copies
+    lo, hi = head._flat.data_ptr(), head._flat.data_ptr() + head._flat.numel() * 4
+    assert all(lo <= p.data_ptr() < hi for p in head.parameters())
+    assert len(head.gradient_buckets()) == 8
+
+
 def test_legacy_key_remap(lib_path):
     """reference petr_head.py:345-359: DETR-era names load into attentions.N / post_norm."""
     import petr_amd

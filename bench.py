@@ -229,9 +229,16 @@ def main():
             us = kernels['mha_fwd_cross']['mean_us']
             flops = 4.0 * B * Q * Ltok * 256            # QK^T + PV of one layer
             ach = flops / (us * 1e-6) / 1e12
+            traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+                if B == 1:
+                    traffic = pmc[args.workload]['mha_fwd_cross']['traffic_bytes']
+            except (OSError, KeyError, ValueError):
+                traffic = None
             roofline = {'kernel': 'mha_fwd_kernel (cross-attention, one decoder layer)', 'bound': 'mfma',
                         'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                        'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                         'flops_per_launch': flops, 'mean_launch_us': us}
         if 'mha_bwd_cross' in kernels:
             us = kernels['mha_bwd_cross']['mean_us']

@@ -1009,9 +1009,9 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       if (l > 0) {
         // d(x_in) = d_z0 (identity) + d_qkv @ W_in, added to the post-norm gradient of level l-1
         float* dst = Wm + W.d_xs + (long)(l - 1) * d.BQ * C;
-        RUN(petr_axpy(dst, d_z0, 1.f, d.BQ * C, s));
         g = lin_dgrad(d_qkv, Pm + lp.sa_in_w, dst, d.BQ, 3 * C, C);
         g.flags = PETR_GEMM_ACCUMULATE;
+        g.r = d_z0; g.ldr = C;                                   // identity path folded into the same epilogue
         RUN(petr_gemm(&g, s));
       }
     } else {

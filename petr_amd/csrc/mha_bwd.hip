@@ -17,8 +17,11 @@
 //                     128-byte-segment float atomics (two segments per wave instruction).
 //   LDS tiles of Q and dO use pitch 33 so that both the row-fragment read (lane = query) and the
 //   column-fragment read (lane = d) are conflict-free ds_read_b32.
+//   delta = rowsum(dO*O) is formed from the O tile that is loaded with Q and dO (no separate pass).
 // Outputs are ACCUMULATED (+=): the caller zero-fills them (the executor clears its gradient
 // workspace once).  dQ uses float atomics, so its low-order bits depend on arrival order.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -29,27 +32,8 @@ constexpr int P33 = 33;
 struct MhaBwdParams {
   petr_mha_bwd_args a;
   int nkb, q_splits, qtiles_per_split;
-  const float* delta;  // [B*H][Q]
   int vec;             // q/do/k/v 16-byte loads legal
 };
-
-__global__ __launch_bounds__(256) void mha_delta_kernel(const petr_mha_bwd_args a, float* delta) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long rows = (long)a.B * a.H * a.Q;
-  if (idx >= rows * 8) return;
-  const long row = idx >> 3;
-  const int d4 = (int)(idx & 7);
-  const int q = (int)(row % a.Q);
-  const int bh = (int)(row / a.Q);
-  const int b = bh / a.H, hd = bh - b * a.H;
-  const float* op = a.o + (long)b * a.o_bs + (long)hd * a.o_hs + (long)q * a.o_rs + 4 * d4;
-  const float* gp = a.d_o + (long)b * a.do_bs + (long)hd * a.do_hs + (long)q * a.do_rs + 4 * d4;
-  float s = op[0] * gp[0] + op[1] * gp[1] + op[2] * gp[2] + op[3] * gp[3];
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 4, 64);
-  if (d4 == 0) delta[row] = s;
-}
 
 template <bool HAS_MASK, bool VEC>
 __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
@@ -119,24 +103,27 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
   const float sc2 = a.scale * LOG2E;
 
   // register prefetch of a query tile: thread -> (row = t>>3, 4 columns at 4*(t&7))
-  float4 qreg, greg;
-  float lreg = 0.f, dreg = 0.f;
+  const float* op = a.o + (long)b * a.o_bs + (long)hd * a.o_hs;
+  float4 qreg, greg, oreg;
+  float lreg = 0.f;
   // raw loads only (clamped rows): selects/negations happen at the LDS store so that nothing waits at the load
   auto gload = [&](int qt) {
     const int row = qt * 32 + (t >> 3), c4 = t & 7;
     const int rowc = min(row, a.Q - 1);
     const float* s = qp + (long)rowc * a.q_rs + 4 * c4;
     const float* g = gp + (long)rowc * a.do_rs + 4 * c4;
+    const float* o = op + (long)rowc * a.o_rs + 4 * c4;
     if (VEC) {
       qreg = *reinterpret_cast<const float4*>(s);
       greg = *reinterpret_cast<const float4*>(g);
+      oreg = *reinterpret_cast<const float4*>(o);
     } else {
       qreg = make_float4(s[0], s[1], s[2], s[3]);
       greg = make_float4(g[0], g[1], g[2], g[3]);
+      oreg = make_float4(o[0], o[1], o[2], o[3]);
     }
     const int rc = min(qt * 32 + (t & 31), a.Q - 1);
     lreg = a.lse[(long)bh * a.Q + rc];
-    dreg = p.delta[(long)bh * a.Q + rc];
   };
 
   if (qt_begin < qt_end) gload(qt_begin);
@@ -148,10 +135,15 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
       d[0] = ok ? qreg.x : 0.f; d[1] = ok ? qreg.y : 0.f; d[2] = ok ? qreg.z : 0.f; d[3] = ok ? qreg.w : 0.f;
       float* e = dOs + row * P33 + 4 * c4;
       e[0] = ok ? greg.x : 0.f; e[1] = ok ? greg.y : 0.f; e[2] = ok ? greg.z : 0.f; e[3] = ok ? greg.w : 0.f;
+      // delta[row] = sum_d dO*O of this (row, head): 8 lanes share a row -> three xor-shuffles, no extra kernel
+      float dl = (greg.x * oreg.x + greg.y * oreg.y) + (greg.z * oreg.z + greg.w * oreg.w);
+      dl += __shfl_xor(dl, 1, 64);
+      dl += __shfl_xor(dl, 2, 64);
+      dl += __shfl_xor(dl, 4, 64);
+      if (c4 == 0) dl_s[row] = ok ? -dl : 0.f;
       if (t < 32) {
         const bool rok = qt * 32 + t < a.Q;
         lse_s[t] = rok ? -lreg * inv_scale : -INFINITY;   // rows beyond Q: -LSE/scale = -inf  =>  p = 0
-        dl_s[t] = rok ? -dreg : 0.f;
       }
     }
     __syncthreads();
@@ -271,14 +263,15 @@ extern "C" int petr_mha_bwd(const petr_mha_bwd_args* ap, void* stream) {
   const petr_mha_bwd_args& a = p.a;
   p.nkb = (int)cdiv(a.L, 128);
   p.q_splits = choose_q_splits(a.B, a.H, a.Q, a.L);
+  if (const char* e = getenv("PETR_MHA_BWD_QSPLITS")) {   // tuning override
+    const int v = atoi(e);
+    if (v >= 1 && v <= (int)cdiv(a.Q, 32)) p.q_splits = v;
+  }
   p.qtiles_per_split = (int)cdiv(cdiv(a.Q, 32), p.q_splits);
-  p.delta = (const float*)a.ws;
   p.vec = aligned16(a.q) && aligned16(a.d_o) && !(a.q_bs & 3) && !(a.q_hs & 3) && !(a.q_rs & 3) && !(a.do_bs & 3) &&
           !(a.do_hs & 3) && !(a.do_rs & 3);
   hipStream_t s = (hipStream_t)stream;
-  const long nrow8 = (long)a.B * a.H * a.Q * 8;
-  hipLaunchKernelGGL(mha_delta_kernel, dim3((unsigned)cdiv(nrow8, 256)), dim3(256), 0, s, a, (float*)a.ws);
-  PETR_LAUNCH_CHECK("mha_delta");
+  // delta = rowsum(dO*O) is recomputed per query tile inside the kernel (O rides along with Q and dO)
   const long total = (long)p.nkb * a.B * a.H * p.q_splits;
   PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_bwd: grid too large");
   const int rec = petr_prof_open_record(PETR_PROF_MHA_BWD + 16 * (a.L > a.Q ? 1 : 0), stream);

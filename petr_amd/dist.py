@@ -19,11 +19,12 @@ class BucketedGradAllReduce:
     ``merge`` consecutive backward stages form one bucket (xGMI is point-to-point: fewer, larger
     collectives amortise the per-collective latency better than many small ones)."""
 
-    def __init__(self, head, group=None, merge=2, average=True):
+    def __init__(self, head, group=None, merge=2, average=True, force=False):
         self.head = head
         self.group = group
         self.average = average
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = force          # issue the collectives even for a single rank (tests the stream/event path)
         stages = head.gradient_buckets()
         self.n_stages = len(stages)
         self.buckets = []           # (last_stage, begin, end)
@@ -40,7 +41,7 @@ class BucketedGradAllReduce:
 
     def _on_stage(self, stage):
         b = self._by_stage.get(stage)
-        if b is None or self.world == 1:
+        if b is None or (self.world == 1 and not self.force):
             return
         flat = self.head._flat_grad[b[1]:b[2]]
         if self._cuda:

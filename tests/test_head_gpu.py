@@ -221,3 +221,42 @@ def test_transformer_module_api(pa):
         got, mem = head.transformer(x.cuda(), mask.cuda(), qe.cuda(), pos.cuda())
     assert got.shape == (6, 2, 16, 256) and mem.shape == x.shape
     assert rel(got, want) < REL
+
+
+def test_bucketed_allreduce_rccl_single_rank(pa):
+    """RCCL path of petr_amd.dist on real hardware: one rank, collectives forced on, issued per backward stage on the
+    side stream behind events; AVG over one rank must leave the gradients of a plain backward unchanged."""
+    import socket
+    import torch.distributed as dist
+    from petr_amd.dist import BucketedGradAllReduce
+    oracle = O.seeded_head(2, 1234, num_query=16)
+    head = make_pair(pa, oracle, num_query=16)
+    metas = O.synthetic_img_metas(1, 2, (128, 192), seed=1)
+    g = torch.Generator().manual_seed(1)
+    feats = torch.randn(1, 2, 256, 4, 6, generator=g).cuda()
+    g_cls, g_box = torch.randn(6, 1, 16, 10, generator=g).cuda(), torch.randn(6, 1, 16, 10, generator=g).cuda()
+
+    def run():
+        head.zero_grad_flat()
+        out = head([feats], metas)
+        torch.autograd.backward([out['all_cls_scores'], out['all_bbox_preds']], [g_cls, g_box])
+
+    run()
+    want = head.flat_gradients().clone()
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        red = BucketedGradAllReduce(head, merge=2, force=True)
+        assert len(red.buckets) == 4
+        run()
+        red.finish()
+        torch.cuda.synchronize()
+        got = head.flat_gradients()
+        assert rel(got, want) < 1e-5        # float atomics in the weight gradients: not bit-identical run to run
+        red.detach()
+    finally:
+        dist.destroy_process_group()

@@ -18,7 +18,6 @@
 
 namespace {
 
-constexpr int BK = 32;
 
 struct OperandView {
   const float* p;
@@ -30,9 +29,10 @@ struct OperandView {
 // Every load is UNCONDITIONAL (addresses clamped into the operand, the value zeroed afterwards by a
 // select): a load inside an exec-masked branch makes hipcc wait vmcnt(0) at the end of the branch, which
 // serialises the whole prefetch ring into one exposed memory latency per float4 (cdna guide §5 trap (c)).
-template <int ROWS, bool KC, bool VEC, bool A2>
+template <int ROWS, int BK, bool KC, bool VEC, bool A2>
 struct Stage {
   static constexpr int NV = ROWS * BK / 4 / 256;
+  static constexpr int KPR = BK / 4;        // float4 per row of a K-contiguous tile
   static constexpr int LD = KC ? ROWS + 1 : ROWS + 4;
   float4 v[NV];            // RAW loaded values: nothing may read them before store(), or hipcc waits at the load
   float4 w[A2 ? NV : 1];
@@ -52,8 +52,8 @@ struct Stage {
       float4 r, r2 = make_float4(0.f, 0.f, 0.f, 0.f);
       bool ok0, ok1, ok2, ok3;
       if (KC) {
-        const int row = row0 + (idx >> 3);
-        const int k = k0 + 4 * (idx & 7);
+        const int row = row0 + idx / KPR;
+        const int k = k0 + 4 * (idx % KPR);
         const int rowc = min(row, o.rows - 1);
         const bool rok = row < o.rows;
         ok0 = rok && k < kend; ok1 = rok && k + 1 < kend; ok2 = rok && k + 2 < kend; ok3 = rok && k + 3 < kend;
@@ -107,7 +107,7 @@ struct Stage {
       if (A2 && (m & 16u)) { x.x += w[i].x; x.y += w[i].y; x.z += w[i].z; x.w += w[i].w; }
       x.x = (m & 1u) ? x.x : 0.f; x.y = (m & 2u) ? x.y : 0.f; x.z = (m & 4u) ? x.z : 0.f; x.w = (m & 8u) ? x.w : 0.f;
       if (KC) {
-        const int row = idx >> 3, kq = idx & 7;
+        const int row = idx / KPR, kq = idx % KPR;
         float* d = lds + (4 * kq) * LD + row;
         d[0] = x.x;
         d[LD] = x.y;
@@ -122,12 +122,12 @@ struct Stage {
   }
 };
 
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, bool VEC, bool A2>
+template <int BM, int BN, int WM, int WN, int BK, bool AKC, bool BKC, bool VEC, bool A2>
 __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const int tiles_m, const int tiles_n) {
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
   constexpr int TM = WM / 32, TN = WN / 32;
-  using SA = Stage<BM, AKC, VEC, A2>;
-  using SB = Stage<BN, BKC, VEC, false>;
+  using SA = Stage<BM, BK, AKC, VEC, A2>;
+  using SB = Stage<BN, BK, BKC, VEC, false>;
   // two LDS images of (A tile, B tile): tile t+1 is written while the MFMAs of tile t read the other image,
   // ONE barrier per k-tile, and the ds_writes/global loads sit in the same basic block as the MFMAs so the
   // compiler interleaves them (a single wave per SIMD otherwise serialises store -> barrier -> read -> MFMA)
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
   // Register prefetch ring, PD tiles deep: these contractions are short chains of k-tiles whose
   // per-tile MFMA time (16 MFMAs) is far below one global-load latency, so ONE tile of look-ahead
   // leaves every iteration waiting ~1-2 us on its loads; PD tiles in flight hide it.
-  constexpr int PD = (BM * BN <= 128 * 64) ? 3 : 2;
+  constexpr int PD = (BM * BN * BK <= 128 * 64 * 32) ? 3 : 2;
   SA sa[PD];
   SB sb[PD];
   // Tiles past kt_end are loaded from clamped addresses with an all-zero validity mask and multiplied as zeros:
@@ -464,7 +464,7 @@ int launch_skinny(const petr_gemm_args& g, hipStream_t s) {
   return PETR_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool VEC>
+template <int BM, int BN, int WM, int WN, int BK, bool VEC>
 int launch_cfg(const petr_gemm_args& g, hipStream_t s) {
   const int tiles_m = (int)cdiv(g.M, BM), tiles_n = (int)cdiv(g.N, BN);
   dim3 grid(tiles_m * tiles_n, 1, g.nb0 * g.nb1 * g.split_k);
@@ -472,8 +472,9 @@ int launch_cfg(const petr_gemm_args& g, hipStream_t s) {
   // dynamic LDS: two images; beyond 64 KB the per-kernel limit is raised once (host-side attribute, not a launch)
 #define PETR_GEMM_LAUNCH(AKC, BKC, A2)                                                                          \
   do {                                                                                                          \
-    constexpr size_t lds_bytes = 2 * (size_t)BK * (Stage<BM, AKC, VEC, A2>::LD + Stage<BN, BKC, VEC, false>::LD) * 4; \
-    auto kern = gemm_kernel<BM, BN, WM, WN, AKC, BKC, VEC, A2>;                                                 \
+    constexpr size_t lds_bytes =                                                                                \
+        2 * (size_t)BK * (Stage<BM, BK, AKC, VEC, A2>::LD + Stage<BN, BK, BKC, VEC, false>::LD) * 4;              \
+    auto kern = gemm_kernel<BM, BN, WM, WN, BK, AKC, BKC, VEC, A2>;                                                 \
     static bool attr_set = false;                                                                               \
     if (lds_bytes > 65536 && !attr_set) {                                                                       \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
@@ -539,11 +540,12 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
     q.split_k = 1;
     return vec ? launch_skinny<true>(q, s) : launch_skinny<false>(q, s);
   }
-  if (!vec) return launch_cfg<64, 64, 32, 32, false>(g, s);   // generic scalar-load path (odd shapes)
+  if (!vec) return launch_cfg<64, 64, 32, 32, 32, false>(g, s);   // generic scalar-load path (odd shapes)
   const long nz = (long)g.nb0 * g.nb1 * g.split_k;
   const long b128 = cdiv(g.M, 128) * cdiv(g.N, 128) * nz;
   const long b12864 = cdiv(g.M, 128) * cdiv(g.N, 64) * nz;
-  if (b128 >= 384 && g.N > 64) return launch_cfg<128, 128, 64, 64, true>(g, s);
-  if (b12864 >= 256 && g.N > 32) return launch_cfg<128, 64, 64, 32, true>(g, s);
-  return launch_cfg<64, 64, 32, 32, true>(g, s);
+  if (b128 >= 384 && g.N > 64) return launch_cfg<128, 128, 64, 64, 32, true>(g, s);
+  if (b12864 >= 256 && g.N > 32) return launch_cfg<128, 64, 64, 32, 32, true>(g, s);
+  // (a BK = 64 variant of this config measured 5 % slower end to end on MI355X: longer prologue, same chain)
+  return launch_cfg<64, 64, 32, 32, 32, true>(g, s);
 }

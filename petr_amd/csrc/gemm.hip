@@ -38,6 +38,46 @@ struct Stage {
   float4 w[A2 ? NV : 1];
   unsigned okm[NV];        // 4 validity bits per float4 (+16: addend active), applied in store()
 
+  // Loop-invariant part of the addressing (per thread, set once per tile row/column block): the PMC profile of
+  // the first version showed 7-11 VALU instructions per MFMA, almost all of it per-tile index/clamp/64-bit address
+  // arithmetic.  Interior tiles now cost one SGPR-base + 32-bit-VGPR-offset load per float4 and no VALU.
+  struct Inv {
+    unsigned offb[NV];     // byte offset of this thread's float4 from the tile origin (rows clamped)
+    unsigned off2b[NV];    // same for the addend operand (row % a2_rows)
+    unsigned rmask[NV];    // row validity bits
+  };
+  __device__ __forceinline__ static void init(Inv& inv, const OperandView& o, int row0, int a2_rows) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = t + 256 * i;
+      if (KC) {
+        const int row = row0 + idx / KPR, kl = 4 * (idx % KPR);
+        const int rowc = min(row, o.rows - 1);
+        inv.offb[i] = (unsigned)(((long)rowc * o.ld + kl) * 4);
+        const int r2 = a2_rows > 0 ? rowc % a2_rows : rowc;
+        inv.off2b[i] = (unsigned)(((long)r2 * o.ld + kl) * 4);
+        inv.rmask[i] = row < o.rows ? 15u : 0u;
+      } else {
+        constexpr int RPK = ROWS / 4;
+        const int kl = idx / RPK, row = row0 + 4 * (idx % RPK);
+        inv.offb[i] = (unsigned)(((long)kl * o.ld + min(row, max(o.rows - 4, 0))) * 4);
+        inv.off2b[i] = 0;
+        inv.rmask[i] = (row < o.rows ? 1u : 0u) | (row + 1 < o.rows ? 2u : 0u) | (row + 2 < o.rows ? 4u : 0u) |
+                       (row + 3 < o.rows ? 8u : 0u);
+      }
+    }
+  }
+  // interior tile: tile_base = operand + segment + k0 (* ld) is wave-uniform (SGPRs), every k of the tile is valid
+  __device__ __forceinline__ void load_fast(const Inv& inv, const float* tile_base, const float* a2_tile_base, bool a2_on) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tile_base) + inv.offb[i]);
+      if (A2) w[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a2_tile_base) + inv.off2b[i]);
+      okm[i] = inv.rmask[i] | (a2_on ? 16u : 0u);
+    }
+  }
+
   __device__ __forceinline__ static float4 ld4(const float* base, long off0, long off1, long off2, long off3) {
     return make_float4(base[off0], base[off1], base[off2], base[off3]);
   }
@@ -186,13 +226,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
   // Tiles past kt_end are loaded from clamped addresses with an all-zero validity mask and multiplied as zeros:
   // the loop body stays branch-free straight-line code ([store t+1][load t+1+PD][MFMA t][barrier] x PD), which is
   // what lets hipcc keep COUNTED vmcnt waits (two stages in flight) instead of draining the ring at every store.
+  typename SA::Inv ia;
+  typename SB::Inv ib;
+  SA::init(ia, A, m0, g.a2_rows);
+  SB::init(ib, B, n0, 0);
   auto stage_load = [&](SA& ra, SB& rb, int kt) {
     const bool live = kt < kt_end;
     const int ktc = live ? kt : kt_end - 1;
     const int seg = ktc / tps;
     const int k0 = live ? (ktc - seg * tps) * BK : kseg;      // k0 >= kseg: every element masked out
-    ra.load(A, (long)seg * g.a_seg_stride, m0, k0, kseg, a2, g.a2_rows, use_a2);
-    rb.load(B, (long)seg * g.b_seg_stride, n0, k0, kseg, nullptr, 0, false);
+    if (VEC && k0 + BK <= kseg) {     // wave-uniform: interior tile
+      const float* ta = A.p + (long)seg * g.a_seg_stride + (AKC ? (long)k0 : (long)k0 * A.ld);
+      const float* tb = B.p + (long)seg * g.b_seg_stride + (BKC ? (long)k0 : (long)k0 * B.ld);
+      const float* t2 = A2 ? a2 + (long)seg * g.a_seg_stride + k0 : nullptr;
+      ra.load_fast(ia, ta, t2, use_a2);
+      rb.load_fast(ib, tb, nullptr, false);
+    } else {
+      ra.load(A, (long)seg * g.a_seg_stride, m0, k0, kseg, a2, g.a2_rows, use_a2);
+      rb.load(B, (long)seg * g.b_seg_stride, n0, k0, kseg, nullptr, 0, false);
+    }
   };
   const int nkt = kt_end - kt_begin;
   const int kt_stop = kt_begin + ((nkt + PD - 1) / PD) * PD;   // padded trip count
@@ -221,17 +273,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
           for (int k = 0; k < BK; ++k) cs += As[k * SA::LD + threadIdx.x];
           colacc += cs;
         }
+        // Fragment reads run AHEAD of the MFMAs that consume them (left alone, hipcc emits read -> lgkmcnt wait ->
+        // MFMA per step and the ~100-cycle LDS latency sits in front of every 64-cycle MFMA of the dependent chain):
+        // LA steps of fragments are requested before the chain starts and each step refills the slot it frees.
+        constexpr int STEPS = BK / 2;
+        constexpr int LA = (TM * TN == 1) ? 8 : (TM * TN == 2 ? 4 : 2);   // look-ahead in k-steps (registers: LA*(TM+TN))
+        float af[LA][TM], bf[LA][TN];
 #pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-          float af[TM], bf[TN];
+        for (int s = 0; s < LA; ++s) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) af[i] = As[(2 * s + h) * SA::LD + wm0 + i * 32 + c];
+          for (int i = 0; i < TM; ++i) af[s][i] = As[(2 * s + h) * SA::LD + wm0 + i * 32 + c];
 #pragma unroll
-          for (int jj = 0; jj < TN; ++jj) bf[jj] = Bs[(2 * s + h) * SB::LD + wn0 + jj * 32 + c];
+          for (int jj = 0; jj < TN; ++jj) bf[s][jj] = Bs[(2 * s + h) * SB::LD + wn0 + jj * 32 + c];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int jj = 0; jj < TN; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[jj], acc[i][jj], 0, 0, 0);
+            for (int jj = 0; jj < TN; ++jj)
+              acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s % LA][i], bf[s % LA][jj], acc[i][jj], 0, 0, 0);
+          if (s + LA < STEPS) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[s % LA][i] = As[(2 * (s + LA) + h) * SA::LD + wm0 + i * 32 + c];
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) bf[s % LA][jj] = Bs[(2 * (s + LA) + h) * SB::LD + wn0 + jj * 32 + c];
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
       }
@@ -527,6 +596,10 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
   const bool vec = operand_vec_ok(g.a, g.lda, g.a_bs0, g.a_bs1, g.a_seg_stride, g.a_kcontig, g.M, kseg) &&
                    (!g.a2 || aligned16(g.a2)) &&
                    operand_vec_ok(g.b, g.ldb, g.b_bs0, g.b_bs1, g.b_seg_stride, g.b_kcontig, g.N, kseg);
+  // the tiled kernel addresses a tile with 32-bit byte offsets from a 64-bit uniform base
+  PETR_CHECK(((long)(g.a_kcontig ? g.M : kseg) * g.lda + (g.a_kcontig ? kseg : g.M)) * 4 < (1L << 32) &&
+                 ((long)(g.b_kcontig ? g.N : kseg) * g.ldb + (g.b_kcontig ? kseg : g.N)) * 4 < (1L << 32),
+             PETR_ERR_UNSUPPORTED, "gemm: one operand batch/segment must span < 4 GiB");
   hipStream_t s = (hipStream_t)stream;
   // Few output tiles AND a long contraction: the latency-optimised kernel (K split inside the workgroup, no
   // LDS staging, no atomics).  It re-reads operands once per tile row/column, so it only pays while the

@@ -260,3 +260,46 @@ def test_bucketed_allreduce_rccl_single_rank(pa):
         red.detach()
     finally:
         dist.destroy_process_group()
+
+
+def test_head_p4_1408_forward(pa):
+    """BASELINE configs[2] shape (6x256x32x88, L = 16 896) in fp32: forward parity at scale."""
+    oracle = O.seeded_head(0, None, num_query=900)
+    head = make_pair(pa, oracle, num_query=900)
+    metas = O.synthetic_img_metas(1, 6, (512, 1408), seed=2)
+    feats = torch.randn(1, 6, 256, 32, 88, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        want = oracle([feats], metas)
+        got = head([feats.cuda()], metas)
+    assert rel(got['all_cls_scores'], want['all_cls_scores']) < REL
+    assert rel(got['all_bbox_preds'], want['all_bbox_preds']) < REL
+
+
+def test_headv2_800x320_forward_backward_runs(pa):
+    """BASELINE configs[4] shape: PETRv2, 12 views x 20x50 (H*W = 1000 is NOT a multiple of 32: exercises the ragged
+    K-segment tiles of the gradient contractions), 900 queries: forward parity + a finite, reproducible backward."""
+    kw = dict(num_query=900, v2=True, with_fpe=True, with_time=True, with_multi=True, code_weights=[1.0] * 10)
+    oracle = O.seeded_head(1, None, **kw)
+    head = pa.build_head(pa.petrv2_head_cfg(num_query=900))
+    head.load_state_dict(oracle.state_dict())
+    head = head.cuda().eval()
+    metas = O.synthetic_img_metas(1, 12, (320, 800), seed=4, with_time=True)
+    g = torch.Generator().manual_seed(4)
+    feats = torch.randn(1, 12, 256, 20, 50, generator=g)
+    g_cls, g_box = torch.randn(6, 1, 900, 10, generator=g), torch.randn(6, 1, 900, 10, generator=g)
+    fo = feats.clone().requires_grad_(True)
+    want = oracle([fo], metas)
+    (want['all_cls_scores'] * g_cls).sum().add((want['all_bbox_preds'] * g_box).sum()).backward()
+    fg = feats.cuda().requires_grad_(True)
+    got = head([fg], metas)
+    torch.autograd.backward([got['all_cls_scores'], got['all_bbox_preds']], [g_cls.cuda(), g_box.cuda()])
+    assert rel(got['all_cls_scores'], want['all_cls_scores']) < REL
+    assert rel(got['all_bbox_preds'], want['all_bbox_preds']) < REL
+    d = (fg.grad.double().cpu() - fo.grad.double())
+    assert d.norm().item() / fo.grad.double().norm().item() < 5e-3
+    wg = dict(oracle.named_parameters())
+    for name in ['input_proj.weight', 'position_encoder.0.weight', 'adapt_pos3d.0.weight', 'fpe.conv_reduce.weight',
+                 'reg_branches.3.task_heads.2.2.weight', 'transformer.decoder.layers.0.attentions.1.attn.in_proj_weight']:
+        p = dict(head.named_parameters())[name]
+        e = (p.grad.double().cpu() - wg[name].grad.double()).norm().item() / wg[name].grad.double().norm().item()
+        assert e < 5e-3, (name, e)

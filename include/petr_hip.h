@@ -195,6 +195,8 @@ typedef struct {
   float scale;
   int n_split;
   void* ws; size_t ws_bytes;
+  int* sched;   /* optional: B*H*ceil(Q/128) ints, ZERO on entry and left zero on exit; enables dynamic K/V-tile
+                 * scheduling between the n_split workers of a query block (NULL: equal static ranges) */
 } petr_mha_fwd_args;
 size_t petr_mha_fwd_workspace_bytes(int B, int H, int Q, int L, int n_split);
 int petr_mha_choose_split(int B, int H, int Q, int L);

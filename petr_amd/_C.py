@@ -75,7 +75,7 @@ class MhaFwdArgs(C.Structure):
         ('o', C.c_void_p), ('o_bs', C.c_long), ('o_hs', C.c_long), ('o_rs', C.c_long),
         ('lse', C.c_void_p), ('kpm', C.c_void_p),
         ('B', C.c_int), ('H', C.c_int), ('Q', C.c_int), ('L', C.c_int), ('scale', C.c_float),
-        ('n_split', C.c_int), ('ws', C.c_void_p), ('ws_bytes', C.c_size_t))
+        ('n_split', C.c_int), ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('sched', C.c_void_p))
 
 
 class MhaBwdArgs(C.Structure):

@@ -259,6 +259,7 @@ struct WOff {
   long d_th_h, d_pe1, d_fpe_h, d_fpe_u;
   long ffn_part; int ffn_split;
   long mha_ws; size_t mha_ws_bytes;
+  long mha_sched_n;
   // ---- backward scratch ----
   long zero_begin, zero_end;     // cleared once per backward (atomic / += targets)
   long d_qc, d_qkv, dk_all, dv_all, d_ref_tmp;
@@ -299,7 +300,10 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
   W.mempos = wb.add("mempos", d.BL * C);
   W.k_all = wb.add("k_all", (long)d.B * d.NL * d.L * C);
   W.v_all = wb.add("v_all", (long)d.B * d.NL * d.L * C);
-  W.x0 = wb.add("x0", d.BQ * C);
+  // the attention tile-ticket counters (petr_mha_fwd_args.sched) sit right behind x0 so that the one fill that
+  // zeroes the decoder input at the top of every forward also (re)zeroes them
+  W.mha_sched_n = (long)d.B * d.NH * ((d.Q + 127) / 128);
+  W.x0 = wb.add("x0", d.BQ * C + W.mha_sched_n);
   for (int l = 0; l < d.NL; ++l) {
     LayerW& lw = W.lay[l];
     lw.xe_in = wb.add("xe_in", d.BQ * C);
@@ -481,7 +485,7 @@ static int ln_bwd(const float* z, const float* mean, const float* rstd, const fl
 }
 
 static int mha_f(const float* q, long q_bs, long q_rs, const float* k, long k_bs, long k_rs, const float* v, float* o,
-                 float* lse, const uint8_t* kpm, const Dims& d, int L, float* ws, size_t ws_bytes, void* s) {
+                 float* lse, const uint8_t* kpm, const Dims& d, int L, float* ws, size_t ws_bytes, int* sched, void* s) {
   petr_mha_fwd_args a;
   memset(&a, 0, sizeof a);
   a.q = q; a.q_bs = q_bs; a.q_hs = 32; a.q_rs = q_rs;
@@ -490,7 +494,7 @@ static int mha_f(const float* q, long q_bs, long q_rs, const float* k, long k_bs
   a.o = o; a.o_bs = (long)d.Q * d.C; a.o_hs = 32; a.o_rs = d.C;
   a.lse = lse; a.kpm = kpm; a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
   a.scale = 1.0f / sqrtf(32.f);
-  a.n_split = 0; a.ws = ws; a.ws_bytes = ws_bytes;
+  a.n_split = 0; a.ws = ws; a.ws_bytes = ws_bytes; a.sched = sched;
   return petr_mha_fwd(&a, s);
 }
 
@@ -700,7 +704,8 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   }
 
   // ---- decoder (petr_transformer.py:95-107,440-446; layer op order A.3) ----
-  RUN(petr_fill(Wm + W.x0, 0.f, d.BQ * C, s));                       // target = zeros (:95)
+  RUN(petr_fill(Wm + W.x0, 0.f, d.BQ * C + W.mha_sched_n, s));       // target = zeros (:95) + attention tickets
+  int* sched = reinterpret_cast<int*>(Wm + W.x0 + d.BQ * C);
   RUN(petr_add_rows(Wm + W.x0, E, Wm + W.lay[0].xe_in, d.BQ, d.Q, C, s));
   const float* x_in = Wm + W.x0;
   float* mws = Wm + W.mha_ws;
@@ -712,7 +717,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.a2 = E; g.a2_rows = d.Q; g.a2_ncols = 2 * C;
     RUN(petr_gemm(&g, s));
     RUN(mha_f(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
-              Wm + lw.ao_s, Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, s));
+              Wm + lw.ao_s, Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, sched, s));
     g = lin_fwd(Wm + lw.ao_s, Pm + lp.sa_out_w, Pm + lp.sa_out_b, Wm + lw.z0, d.BQ, C, C);
     g.r = x_in; g.ldr = C;                                             // identity + out (petr_transformer.py:367)
     RUN(petr_gemm(&g, s));
@@ -726,7 +731,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
       ln.join(1);
     }
     RUN(mha_f(Wm + lw.qc, (long)d.Q * C, C, Wm + W.k_all + (long)l * d.L * C, (long)d.NL * d.L * C, C,
-              Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, s));
+              Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, sched, s));
     g = lin_fwd(Wm + lw.ao_c, Pm + lp.ca_out_w, Pm + lp.ca_out_b, Wm + lw.z1, d.BQ, C, C);
     g.r = Wm + lw.x1; g.ldr = C;
     RUN(petr_gemm(&g, s));

@@ -34,13 +34,40 @@ struct MhaFwdParams {
   float* o_part;   // [n_split][B*H][Q][32]
   float* ml_part;  // [n_split][B*H][Q][2]
   int q_vec, kv_vec;
+  int n_tiles;
+  int* sched;      // [B*H*nqb] tile tickets (dynamic mode), zero on entry, zero again on exit
 };
 
-template <bool HAS_MASK, bool VEC>
-__global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
-  __shared__ __attribute__((aligned(16))) float Kt[32 * KT_PITCH];
-  __shared__ __attribute__((aligned(16))) float Vs[KV_TILE * 32];
+#ifdef PETR_DIAG_CLOCK   // diagnostic build only (scripts/diag_clock.cpp): in-kernel clock of the main loop
+__device__ unsigned long long g_diag[4 * 4 * 4096];   // per wave: cycles, realtime ticks, tiles | active<<32, hw_id | xcc_id<<32
+#endif
+
+// 8 waves: wave = (key half kh, query group qg).  The two waves of a query group take the two 32-key halves of
+// every 64-key tile and keep their own running (m, l, O); they are merged through LDS once, after the loop.
+// Why 8 and not 4: with ONE resident wave per query group a SIMD held 2 waves, and measured in-kernel
+// (scripts/diag_clock.cpp) a wave alone reaches only 66 % of the MFMA issue rate (its softmax and LDS waits are
+// exposed), so the SIMD idled whenever its two waves were in the same phase and in the tail; 4 half-size
+// instruction streams per SIMD keep the matrix pipe fed.
+//
+// Tile scheduling.  The n_split workgroups of one (batch, head, query block) are WORKERS over that group's
+// K/V tiles; each keeps one running (m, l, O) and writes one partial, so any assignment of tiles to workers is
+// valid.  DYN = false: worker s takes the contiguous range [s*per, (s+1)*per).  DYN = true: worker s starts
+// with tile s and then draws tickets from a per-group counter (one atomicAdd per tile, fetched one tile ahead
+// of its use).  Measured reason (diag_clock): the SIMD arbiter favours the older of the two workgroups sharing a
+// CU, which then runs at 7.1k cycles/tile while the younger gets 10.3k, so with equal static ranges the younger
+// one finishes the last third of its range alone at 2/3 of the MFMA rate; with tickets the fast worker simply
+// takes more tiles and both drain together (the same mechanism absorbs the ragged last range and the mostly
+// padded last query block).  The worker whose ticket is the group's last resets the counter for the next launch.
+template <bool HAS_MASK, bool VEC, bool DYN>
+__global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
+  constexpr int MERGE_PITCH = 17;
+  __shared__ __attribute__((aligned(16))) float smem[4 * 64 * MERGE_PITCH + 2 * 4 * 32];   // >= K^T + V images
   __shared__ float bias_s[KV_TILE];
+  __shared__ int sched_s[2];
+  float* Kt = smem;                       // [32][KT_PITCH]
+  float* Vs = smem + 32 * KT_PITCH;       // [KV_TILE][32]
+  static_assert((32 * KT_PITCH) % 4 == 0, "V image must stay 16-byte aligned");
+  static_assert(32 * KT_PITCH + KV_TILE * 32 <= 4 * 64 * MERGE_PITCH + 2 * 4 * 32, "merge buffer smaller than tiles");
 
   const petr_mha_fwd_args& a = p.a;
   const int total = p.nqb * a.B * a.H * p.n_split;
@@ -52,13 +79,53 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   const int b = bh / a.H, hd = bh - b * a.H;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int qg = wave & 3, kh = wave >> 2;
   const int h = lane >> 5, c = lane & 31;
-  const int q_row = qb * 128 + wave * 32 + c;
+  const int q_row = qb * 128 + qg * 32 + c;
   const int q_ld = min(q_row, a.Q - 1);
-  const bool wave_active = qb * 128 + wave * 32 < a.Q;
+  const bool wave_active = qb * 128 + qg * 32 < a.Q;
 
-  const int k_begin = split * p.tiles_per_split * KV_TILE;
-  const int k_end = min(a.L, k_begin + p.tiles_per_split * KV_TILE);
+  const int n_tiles = p.n_tiles;
+  const int k_end = a.L;
+  int cur = DYN ? split : split * p.tiles_per_split;                          // host guarantees cur < n_tiles
+  const int my_end = DYN ? n_tiles : min(n_tiles, cur + p.tiles_per_split);
+  int* ticket = DYN ? p.sched + (bh * p.nqb + qb) : nullptr;
+  // tickets: tiles 0..n_split-1 are the workers' first tiles, ticket v names tile n_split + v.  Every worker draws
+  // until its first miss, so a group draws exactly n_tiles tickets and the draw that returns n_tiles-1 is the last.
+  // The ticket value is only looked at one tile later (publish()): using it right after the atomic would make
+  // thread 0's wave sit out the whole L2 round trip in front of its MFMA work.
+  // It is issued as inline asm with EXEC narrowed to lane 0 of wave 0: through atomicAdd() hipcc's atomic optimizer
+  // consumes the result at once (s_waitcnt vmcnt(0) right behind the atomic, in front of the MFMA work).  The
+  // compiler does not count this operation in vmcnt; memory operations return in order, so its own counted waits
+  // only become stricter, and publish() waits for everything before it reads the ticket.
+  const bool wave0 = __builtin_amdgcn_readfirstlane(t >> 6) == 0;
+  int drawn = n_tiles;                    // lane 0 of wave 0: raw ticket for the tile after the next one
+  auto draw = [&](bool on) {
+    const int m = __builtin_amdgcn_readfirstlane(on ? 1 : 0);
+    unsigned long long saved;
+    const int one = 1;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b32 exec_lo, %[m]\n\t"
+        "s_mov_b32 exec_hi, 0\n\t"
+        "global_atomic_add %[r], %[a], %[o], off sc0\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [r] "+v"(drawn), [sv] "=&s"(saved)
+        : [m] "s"(m), [a] "v"(ticket), [o] "v"(one)
+        : "memory");
+  };
+  if (DYN) draw(wave0);
+  auto publish = [&](int slot) {
+    if (wave0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (t == 0) {
+        if (drawn == n_tiles - 1) atomicExch(ticket, 0);
+        // a counter that was not zero on entry (contract violation) can only end the worker early, never index
+        // outside [0, n_tiles)
+        sched_s[slot] = (unsigned)drawn < (unsigned)n_tiles ? p.n_split + drawn : n_tiles;
+      }
+    }
+  };
 
   // ---- Q fragment: lane (c,h) holds Q[q][16h .. 16h+15], pre-scaled by scale*log2(e) ----
   float qf[16];
@@ -81,42 +148,33 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   const float* vp = a.v + (long)b * a.v_bs + (long)hd * a.v_hs;
   const uint8_t* mp = HAS_MASK ? a.kpm + (long)b * a.L : nullptr;
 
-  float4 kreg[2], vreg[2];
+  float4 kreg, vreg;
   uint8_t mreg = 0;
+  const int ld_key = t >> 3, ld_c4 = t & 7;
   // Unconditional loads from clamped addresses; the zero-fill select happens in lstore(): any use of a loaded
   // register right after the load would make hipcc wait for it there and expose the whole memory latency.
   auto gload = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = t + 256 * i;
-      const int kg = k0 + (idx >> 3), c4 = idx & 7;
-      const int kgc = min(kg, a.L - 1);
-      const float* ks = kp + (long)kgc * a.k_rs + 4 * c4;
-      const float* vs = vp + (long)kgc * a.v_rs + 4 * c4;
-      if (VEC) {
-        kreg[i] = *reinterpret_cast<const float4*>(ks);
-        vreg[i] = *reinterpret_cast<const float4*>(vs);
-      } else {
-        kreg[i] = make_float4(ks[0], ks[1], ks[2], ks[3]);
-        vreg[i] = make_float4(vs[0], vs[1], vs[2], vs[3]);
-      }
+    const int kgc = min(k0 + ld_key, a.L - 1);
+    const float* ks = kp + (long)kgc * a.k_rs + 4 * ld_c4;
+    const float* vs = vp + (long)kgc * a.v_rs + 4 * ld_c4;
+    if (VEC) {
+      kreg = *reinterpret_cast<const float4*>(ks);
+      vreg = *reinterpret_cast<const float4*>(vs);
+    } else {
+      kreg = make_float4(ks[0], ks[1], ks[2], ks[3]);
+      vreg = make_float4(vs[0], vs[1], vs[2], vs[3]);
     }
     if (HAS_MASK) mreg = mp[min(k0 + (t & (KV_TILE - 1)), a.L - 1)];
   };
   auto lstore = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = t + 256 * i;
-      const int key = idx >> 3, c4 = idx & 7;
-      const bool ok = k0 + key < k_end;
-      float* d = Kt + (4 * c4) * KT_PITCH + key;
-      d[0] = ok ? kreg[i].x : 0.f;
-      d[KT_PITCH] = ok ? kreg[i].y : 0.f;
-      d[2 * KT_PITCH] = ok ? kreg[i].z : 0.f;
-      d[3 * KT_PITCH] = ok ? kreg[i].w : 0.f;
-      *reinterpret_cast<float4*>(Vs + key * 32 + 4 * c4) =
-          make_float4(ok ? vreg[i].x : 0.f, ok ? vreg[i].y : 0.f, ok ? vreg[i].z : 0.f, ok ? vreg[i].w : 0.f);
-    }
+    const bool ok = k0 + ld_key < k_end;
+    float* d = Kt + (4 * ld_c4) * KT_PITCH + ld_key;
+    d[0] = ok ? kreg.x : 0.f;
+    d[KT_PITCH] = ok ? kreg.y : 0.f;
+    d[2 * KT_PITCH] = ok ? kreg.z : 0.f;
+    d[3 * KT_PITCH] = ok ? kreg.w : 0.f;
+    *reinterpret_cast<float4*>(Vs + ld_key * 32 + 4 * ld_c4) =
+        make_float4(ok ? vreg.x : 0.f, ok ? vreg.y : 0.f, ok ? vreg.z : 0.f, ok ? vreg.w : 0.f);
     if (t < KV_TILE) {
       bool dead = k0 + t >= k_end;
       if (HAS_MASK) dead = dead || mreg != 0;
@@ -129,60 +187,106 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   for (int r = 0; r < 16; ++r) O[r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  if (k_begin < k_end) gload(k_begin);
-  for (int k0 = k_begin; k0 < k_end; k0 += KV_TILE) {
+  gload(cur * KV_TILE);
+#ifdef PETR_DIAG_CLOCK
+  const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
+  int dg_tiles = 0;
+#endif
+  for (int it = 0;; ++it) {
+    const int k0 = cur * KV_TILE;
+    if (DYN) publish(it & 1);
     __syncthreads();
     lstore(k0);
     __syncthreads();
-    if (k0 + KV_TILE < k_end) gload(k0 + KV_TILE);
+    int nxt;
+    if (DYN) nxt = __builtin_amdgcn_readfirstlane(sched_s[it & 1]);
+    else nxt = cur + 1 < my_end ? cur + 1 : n_tiles;
+    if (nxt < n_tiles) gload(nxt * KV_TILE);
+    if (DYN) draw(wave0 && nxt < n_tiles);
+#ifdef PETR_DIAG_CLOCK
+    ++dg_tiles;
+#endif
     const bool use_bias = HAS_MASK || (k0 + KV_TILE > k_end);
-    if (!wave_active) continue;            // wave-uniform: a wave whose 32 queries are all padding only stages K/V
+    // wave-uniform skips: a wave whose 32 queries are all padding, or whose key half lies beyond L,
+    // only stages K/V
+    if (wave_active && k0 + kh * 32 < k_end) {
+    // all 16 K fragments are requested before the first MFMA so that one LDS latency, not sixteen,
+    // sits in front of the dependent MFMA chain (the compiler otherwise emits read->wait->2 MFMA)
+    float kfr[16];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      if (k0 + sub * 32 >= k_end) break;   // uniform: whole sub-tile beyond the slice
-      // all 16 K fragments are requested before the first MFMA so that one LDS latency, not sixteen,
-      // sits in front of the dependent MFMA chain (the compiler otherwise emits read->wait->2 MFMA)
-      float kfr[16];
+    for (int s = 0; s < 16; ++s) kfr[s] = Kt[(16 * h + s) * KT_PITCH + kh * 32 + c];
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 S;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) kfr[s] = Kt[(16 * h + s) * KT_PITCH + sub * 32 + c];
-      __builtin_amdgcn_sched_barrier(0);
-      f32x16 S;
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    for (int s = 0; s < 16; ++s) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kfr[s], qf[s], S, 0, 0, 0);
+    // V fragments: requested now, consumed after the softmax (their latency hides under its VALU work)
+    float vfr[16];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kfr[s], qf[s], S, 0, 0, 0);
-      // V fragments: requested now, consumed after the softmax (their latency hides under its VALU work)
-      float vfr[16];
+    for (int s = 0; s < 16; ++s) vfr[s] = Vs[(kh * 32 + mfma32_row(s, h)) * 32 + c];
+    if (use_bias) {
 #pragma unroll
-      for (int s = 0; s < 16; ++s) vfr[s] = Vs[(sub * 32 + mfma32_row(s, h)) * 32 + c];
-      if (use_bias) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] += bias_s[sub * 32 + mfma32_row(r, h)];
-      }
-      float mx = S[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
-      mx = xhalf_max(mx);
-      const float m_new = fmaxf(m_run, mx);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-      float rs = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        S[r] = __builtin_amdgcn_exp2f(S[r] - m_use);
-        rs += S[r];
-      }
-      rs = xhalf_sum(rs);
-      l_run = l_run * alpha + rs;
-      m_run = m_new;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) O[r] *= alpha;
-#pragma unroll
-      for (int s = 0; s < 16; ++s) O = __builtin_amdgcn_mfma_f32_32x32x2f32(vfr[s], S[s], O, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) S[r] += bias_s[kh * 32 + mfma32_row(r, h)];
     }
+    float mx = S[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S[r] = __builtin_amdgcn_exp2f(S[r] - m_use);
+      rs += S[r];
+    }
+    rs = xhalf_sum(rs);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[r] *= alpha;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) O = __builtin_amdgcn_mfma_f32_32x32x2f32(vfr[s], S[s], O, 0, 0, 0);
+    }
+    if (nxt >= n_tiles) break;
+    cur = nxt;
   }
 
-  if (q_row >= a.Q) return;
+#ifdef PETR_DIAG_CLOCK
+  if (lane == 0 && blockIdx.x < 4096 && wave < 4) {
+    unsigned long long* dg = g_diag + 4 * (4 * blockIdx.x + wave);
+    dg[0] = __builtin_amdgcn_s_memtime() - dg_t0;
+    dg[1] = __builtin_amdgcn_s_memrealtime() - dg_r0;
+    dg[2] = (unsigned long long)dg_tiles | ((unsigned long long)wave_active << 16) |
+            ((unsigned long long)w << 32);
+    dg[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+  }
+#endif
+
+  // ---- merge the two key halves of each query group (upper wave -> LDS -> lower wave) ----
+  __syncthreads();   // every wave is done with the K/V images
+  float* mo = smem + (qg * 64 + lane) * MERGE_PITCH;
+  float* mml = smem + 4 * 64 * MERGE_PITCH + qg * 64 + 2 * c;   // (m, l) per query, written by the h == 0 half
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mo[r] = O[r];
+    if (h == 0) { mml[0] = m_run; mml[1] = l_run; }
+  }
+  __syncthreads();
+  if (kh == 1 || q_row >= a.Q) return;
+  {
+    const float m2 = mml[0], l2 = mml[1];
+    const float m_new = fmaxf(m_run, m2);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float a1 = __builtin_amdgcn_exp2f(m_run - m_use), a2 = __builtin_amdgcn_exp2f(m2 - m_use);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[r] = O[r] * a1 + mo[r] * a2;
+    l_run = l_run * a1 + l2 * a2;
+    m_run = m_new;
+  }
   if (p.n_split == 1) {
     const float inv = 1.f / l_run;   // fully masked row: 0 * inf = NaN, as torch's softmax of all -inf
     float* op = a.o + (long)b * a.o_bs + (long)hd * a.o_hs + (long)q_row * a.o_rs;
@@ -274,7 +378,13 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
   const int tiles = (int)cdiv(a.L, KV_TILE);
   if (ns > tiles) ns = tiles;
   p.n_split = ns;
+  p.n_tiles = tiles;
   p.tiles_per_split = (int)cdiv(tiles, ns);
+  if ((long)(ns - 1) * p.tiles_per_split >= tiles) {   // no empty static range (a worker always owns >= 1 tile)
+    ns = (int)cdiv(tiles, p.tiles_per_split);
+    p.n_split = ns;
+  }
+  p.sched = ns > 1 ? a.sched : nullptr;
   p.o_part = nullptr;
   p.ml_part = nullptr;
   if (ns > 1) {
@@ -292,12 +402,18 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
   PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_fwd: grid too large");
   const int rec = petr_prof_open_record(PETR_PROF_MHA_FWD + 16 * (a.L > a.Q ? 1 : 0), stream);
   const bool vec = p.q_vec && p.kv_vec;
-  if (a.kpm) {
-    if (vec) hipLaunchKernelGGL((mha_fwd_kernel<true, true>), dim3((unsigned)total), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((mha_fwd_kernel<true, false>), dim3((unsigned)total), dim3(256), 0, s, p);
-  } else {
-    if (vec) hipLaunchKernelGGL((mha_fwd_kernel<false, true>), dim3((unsigned)total), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((mha_fwd_kernel<false, false>), dim3((unsigned)total), dim3(256), 0, s, p);
+  static const int lds_pad = getenv("PETR_MHA_FWD_LDS_PAD") ? atoi(getenv("PETR_MHA_FWD_LDS_PAD")) : 0;
+  auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), lds_pad, s, p); };
+  const int variant = (a.kpm ? 4 : 0) | (vec ? 2 : 0) | (p.sched ? 1 : 0);
+  switch (variant) {
+    case 0: launch(mha_fwd_kernel<false, false, false>); break;
+    case 1: launch(mha_fwd_kernel<false, false, true>); break;
+    case 2: launch(mha_fwd_kernel<false, true, false>); break;
+    case 3: launch(mha_fwd_kernel<false, true, true>); break;
+    case 4: launch(mha_fwd_kernel<true, false, false>); break;
+    case 5: launch(mha_fwd_kernel<true, false, true>); break;
+    case 6: launch(mha_fwd_kernel<true, true, false>); break;
+    default: launch(mha_fwd_kernel<true, true, true>); break;
   }
   petr_prof_close_record(rec, stream);
   PETR_LAUNCH_CHECK("mha_fwd");

@@ -166,8 +166,9 @@ def _bhsd(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
-def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True):
-    """softmax(scale q k^T + mask) v for [B,H,S,32] (strided) views.  Returns (o [B,H,Q,32], lse [B,H,Q])."""
+def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True, dynamic=True):
+    """softmax(scale q k^T + mask) v for [B,H,S,32] (strided) views.  Returns (o [B,H,Q,32], lse [B,H,Q]).
+    ``dynamic``: the L-split workers draw K/V tiles from per-query-block ticket counters (zeroed here)."""
     L = _C.lib()
     B, H, Q, _ = q.shape
     Lk = k.shape[2]
@@ -178,8 +179,9 @@ def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True
     nbytes = L.petr_mha_fwd_workspace_bytes(B, H, Q, Lk, ns)
     ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=q.device)
     kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
+    sched = torch.zeros(B * H * ((Q + 127) // 128), dtype=torch.int32, device=q.device) if dynamic else None
     a = _C.MhaFwdArgs(_ptr(_f32(q)), *_bhsd(q), _ptr(_f32(k)), *_bhsd(k), _ptr(_f32(v)), *_bhsd(v), _ptr(o), *_bhsd(o),
-                      _ptr(lse), _ptr(kpm), B, H, Q, Lk, scale, ns, _ptr(ws), nbytes)
+                      _ptr(lse), _ptr(kpm), B, H, Q, Lk, scale, ns, _ptr(ws), nbytes, _ptr(sched))
     _C.check(L.petr_mha_fwd(C.byref(a), _stream()), 'petr_mha_fwd')
     return o, lse
 

@@ -28,7 +28,10 @@ extern "C" int petr_device_caps(int* num_cu, char* arch, int arch_len) {
 // ---------------------------------------------------------------------------------------------
 // Opt-in kernel timing with HIP events on the launch stream (bench.py's roofline leg).  Disabled by
 // default: the hot path then records nothing.  Events are created in petr_prof_begin (outside any
-// launch path), recorded around tagged launches, resolved in petr_prof_end after a synchronise.
+// launch path) and resolved in petr_prof_end after a synchronise.  A tagged launch either attaches its
+// two events to the dispatch itself (petr_prof_claim + hipExtLaunchKernelGGL: the events then carry the
+// kernel's own begin/end timestamps, the same interval rocprofv3 --kernel-trace reports) or, for a group
+// of launches, records them around the group (open/close: includes the inter-packet gaps).
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct Prof {
@@ -44,6 +47,17 @@ int petr_prof_open_record(int tag, void* stream) {
   const int i = g_prof.n++;
   g_prof.tag[i] = tag;
   hipEventRecord(g_prof.ev[2 * i], (hipStream_t)stream);
+  return i;
+}
+
+int petr_prof_claim(int tag, hipEvent_t* start, hipEvent_t* stop) {
+  *start = nullptr;
+  *stop = nullptr;
+  if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
+  const int i = g_prof.n++;
+  g_prof.tag[i] = tag;
+  *start = g_prof.ev[2 * i];
+  *stop = g_prof.ev[2 * i + 1];
   return i;
 }
 

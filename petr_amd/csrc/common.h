@@ -1,6 +1,7 @@
 // Shared helpers for the libpetr_hip kernels (gfx950 / CDNA4 only: wave64, MFMA).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -16,6 +17,7 @@ void petr_set_error(const char* fmt, ...);
 // opt-in event timing of tagged launches (api.cpp); no-ops unless petr_prof_begin() was called
 enum { PETR_PROF_MHA_FWD = 1, PETR_PROF_MHA_BWD = 2, PETR_PROF_GEMM = 3, PETR_PROF_COORDS3D = 4 };
 int petr_prof_open_record(int tag, void* stream);
+int petr_prof_claim(int tag, hipEvent_t* start, hipEvent_t* stop);   // events to attach to ONE dispatch (null when off)
 void petr_prof_close_record(int rec, void* stream);
 
 // execution context (side streams + event ring), owned by the host through petr_ctx_create/destroy

@@ -705,7 +705,10 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
 
   // ---- decoder (petr_transformer.py:95-107,440-446; layer op order A.3) ----
   RUN(petr_fill(Wm + W.x0, 0.f, d.BQ * C + W.mha_sched_n, s));       // target = zeros (:95) + attention tickets
-  int* sched = reinterpret_cast<int*>(Wm + W.x0 + d.BQ * C);
+  // Dynamic K/V-tile tickets are opt-in (PETR_MHA_DYNAMIC=1): they make the grouping of the partial sums, and so
+  // the low-order bits of the forward, depend on timing; the default static ranges keep the forward bit-reproducible.
+  static const bool mha_dynamic = getenv("PETR_MHA_DYNAMIC") && atoi(getenv("PETR_MHA_DYNAMIC")) != 0;
+  int* sched = mha_dynamic ? reinterpret_cast<int*>(Wm + W.x0 + d.BQ * C) : nullptr;
   RUN(petr_add_rows(Wm + W.x0, E, Wm + W.lay[0].xe_in, d.BQ, d.Q, C, s));
   const float* x_in = Wm + W.x0;
   float* mws = Wm + W.mha_ws;

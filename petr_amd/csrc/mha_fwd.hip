@@ -27,10 +27,12 @@ constexpr int KV_TILE = 64;
 constexpr int KT_PITCH = 65;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
+constexpr float LAZY = 8.f;       // log2 of the slack allowed between a row's true and reference maximum
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct MhaFwdParams {
   petr_mha_fwd_args a;
-  int nqb, n_split, tiles_per_split;
+  int nqb, n_split, n_sub;
   float* o_part;   // [n_split][B*H][Q][32]
   float* ml_part;  // [n_split][B*H][Q][2]
   int q_vec, kv_vec;
@@ -84,10 +86,18 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   const int q_ld = min(q_row, a.Q - 1);
   const bool wave_active = qb * 128 + qg * 32 < a.Q;
 
-  const int n_tiles = p.n_tiles;
-  const int k_end = a.L;
-  int cur = DYN ? split : split * p.tiles_per_split;                          // host guarantees cur < n_tiles
-  const int my_end = DYN ? n_tiles : min(n_tiles, cur + p.tiles_per_split);
+  // Static ranges are cut at 32-key granularity (132 halves over 8 workers = 16/17 each at c5, not 9,9,...,3
+  // tiles): the worker's tiles are 64-key steps from ITS first key and its last tile may be half (the half-tile
+  // machinery is the one the ragged end of L needs anyway).  Dynamic mode numbers the tiles of the whole key axis.
+  int k_base = 0, k_end = a.L, n_tiles = p.n_tiles;
+  if (!DYN) {
+    const int base = p.n_sub / p.n_split, rem = p.n_sub - base * p.n_split;
+    k_base = 32 * (split * base + min(split, rem));
+    k_end = min(a.L, k_base + 32 * (base + (split < rem ? 1 : 0)));
+    n_tiles = (k_end - k_base + KV_TILE - 1) / KV_TILE;      // host guarantees >= 1
+  }
+  int cur = DYN ? split : 0;
+  const int my_end = n_tiles;
   int* ticket = DYN ? p.sched + (bh * p.nqb + qb) : nullptr;
   // tickets: tiles s and n_split+s are worker s' first two tiles (the pipeline is two tiles deep), ticket v names
   // tile 2*n_split + v.  Every worker draws until its first miss, so a group draws exactly p.n_tickets tickets and
@@ -150,12 +160,23 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   float4 kreg, vreg;
   uint8_t mreg = 0;
   const int ld_key = t >> 3, ld_c4 = t & 7;
-  // Unconditional loads from clamped addresses; the zero-fill select happens in lstore(): any use of a loaded
-  // register right after the load would make hipcc wait for it there and expose the whole memory latency.
+  // f32 MFMA issues on the same lanes as the vector ALU (SQ_VALU_MFMA_COEXEC_CYCLES = 0 for this kernel; removing
+  // the softmax / the staging from a diagnostic build shortened it by exactly their share), so every VALU
+  // instruction in this loop is paid in full: tile addresses are a wave-uniform base + a per-lane 32-bit offset
+  // that is computed once, and nothing is selected or zero-filled per element.
+  const int koff = ld_key * (int)a.k_rs + 4 * ld_c4, voff = ld_key * (int)a.v_rs + 4 * ld_c4;
+  // Loads are unconditional, rows beyond L re-read row L-1 (any finite data will do: their scores get a -inf
+  // bias, so their probabilities are exact zeros).  Nothing is done with a loaded register before lstore(): a
+  // use right behind a load would make hipcc wait for it on the spot.
   auto gload = [&](int k0) {
-    const int kgc = min(k0 + ld_key, a.L - 1);
-    const float* ks = kp + (long)kgc * a.k_rs + 4 * ld_c4;
-    const float* vs = vp + (long)kgc * a.v_rs + 4 * ld_c4;
+    int ko = koff, vo = voff;
+    if (k0 + KV_TILE > a.L) {   // wave-uniform: ragged last tile
+      const int kk = min(ld_key, a.L - 1 - k0);
+      ko = kk * (int)a.k_rs + 4 * ld_c4;
+      vo = kk * (int)a.v_rs + 4 * ld_c4;
+    }
+    const float* ks = kp + (long)k0 * a.k_rs + ko;
+    const float* vs = vp + (long)k0 * a.v_rs + vo;
     if (VEC) {
       kreg = *reinterpret_cast<const float4*>(ks);
       vreg = *reinterpret_cast<const float4*>(vs);
@@ -168,15 +189,13 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   auto lstore = [&](int k0, int buf) {
     float* Kt = smem + buf * IMG;
     float* Vs = Kt + 32 * KT_PITCH;
-    const bool ok = k0 + ld_key < k_end;
     float* d = Kt + (4 * ld_c4) * KT_PITCH + ld_key;
-    d[0] = ok ? kreg.x : 0.f;
-    d[KT_PITCH] = ok ? kreg.y : 0.f;
-    d[2 * KT_PITCH] = ok ? kreg.z : 0.f;
-    d[3 * KT_PITCH] = ok ? kreg.w : 0.f;
-    *reinterpret_cast<float4*>(Vs + ld_key * 32 + 4 * ld_c4) =
-        make_float4(ok ? vreg.x : 0.f, ok ? vreg.y : 0.f, ok ? vreg.z : 0.f, ok ? vreg.w : 0.f);
-    if (t < KV_TILE) {
+    d[0] = kreg.x;
+    d[KT_PITCH] = kreg.y;
+    d[2 * KT_PITCH] = kreg.z;
+    d[3 * KT_PITCH] = kreg.w;
+    *reinterpret_cast<float4*>(Vs + ld_key * 32 + 4 * ld_c4) = vreg;
+    if ((HAS_MASK || k0 + KV_TILE > k_end) && t < KV_TILE) {
       bool dead = k0 + t >= k_end;
       if (HAS_MASK) dead = dead || mreg != 0;
       bias_s[buf][t] = dead ? -INFINITY : 0.f;
@@ -192,25 +211,29 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   // from registers into the other image and tile `nn` is on its way from memory into the registers.
   int nxt = DYN ? p.n_split + split : cur + 1;
   if (nxt >= my_end) nxt = n_tiles;
-  gload(cur * KV_TILE);
+  gload(k_base + cur * KV_TILE);
   if (DYN) draw(wave0);
-  lstore(cur * KV_TILE, 0);
-  if (nxt < n_tiles) gload(nxt * KV_TILE);
+  lstore(k_base + cur * KV_TILE, 0);
+  if (nxt < n_tiles) gload(k_base + nxt * KV_TILE);
 #ifdef PETR_DIAG_CLOCK
   const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
   int dg_tiles = 0;
 #endif
   for (int it = 0;; ++it) {
-    const int k0 = cur * KV_TILE;
+    const int k0 = k_base + cur * KV_TILE;
     const int buf = it & 1;
     if (DYN) publish(buf);
+#ifndef PETR_DIAG_NO_BARRIER
     __syncthreads();   // image `buf` is complete; every wave is done reading the other one
+#endif
     int nn = n_tiles;
     if (nxt < n_tiles) {
       if (DYN) nn = __builtin_amdgcn_readfirstlane(sched_s[buf]);
       else nn = nxt + 1 < my_end ? nxt + 1 : n_tiles;
-      lstore(nxt * KV_TILE, buf ^ 1);
-      if (nn < n_tiles) gload(nn * KV_TILE);
+#ifndef PETR_DIAG_NO_STAGE
+      lstore(k_base + nxt * KV_TILE, buf ^ 1);
+      if (nn < n_tiles) gload(k_base + nn * KV_TILE);
+#endif
     }
     if (DYN) draw(wave0 && nn < n_tiles);
     const float* Kt = smem + buf * IMG;
@@ -241,24 +264,43 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[r] += bias_s[buf][kh * 32 + mfma32_row(r, h)];
     }
+#ifndef PETR_DIAG_NO_SOFTMAX
     float mx = S[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
     mx = xhalf_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-    float rs = 0.f;
+    // Lazy reference maximum: m_run only moves when some row's maximum has outgrown it by more than 2^LAZY (then
+    // exp2(S - m_run) <= 2^LAZY, far from overflow).  (m, l, O) stay a consistent triple, so O / l and the LSE are
+    // the same numbers; what is saved is the rescale of O and its exp2 in almost every step.
+    if (__builtin_amdgcn_ballot_w64(mx > m_run + LAZY) != 0) {   // wave-uniform
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
+      const f32x2 al = {alpha, alpha};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      S[r] = __builtin_amdgcn_exp2f(S[r] - m_use);
-      rs += S[r];
+      for (int i = 0; i < 8; ++i) {
+        f32x2 o2 = {O[2 * i], O[2 * i + 1]};
+        o2 *= al;
+        O[2 * i] = o2.x; O[2 * i + 1] = o2.y;
+      }
+      l_run *= alpha;
+      m_run = m_new;
     }
-    rs = xhalf_sum(rs);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
+    {
+      const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+      const f32x2 mm = {m_use, m_use};
+      f32x2 acc = {0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) O[r] *= alpha;
+      for (int i = 0; i < 8; ++i) {   // packed (two floats per instruction) subtract and row sum
+        f32x2 e = {S[2 * i], S[2 * i + 1]};
+        e -= mm;
+        e.x = __builtin_amdgcn_exp2f(e.x);
+        e.y = __builtin_amdgcn_exp2f(e.y);
+        S[2 * i] = e.x; S[2 * i + 1] = e.y;
+        acc += e;
+      }
+      l_run += xhalf_sum(acc.x + acc.y);
+    }
+#endif
 #pragma unroll
     for (int s = 0; s < 16; ++s) O = __builtin_amdgcn_mfma_f32_32x32x2f32(vfr[s], S[s], O, 0, 0, 0);
     }
@@ -392,11 +434,7 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
   if (ns > tiles) ns = tiles;
   p.n_split = ns;
   p.n_tiles = tiles;
-  p.tiles_per_split = (int)cdiv(tiles, ns);
-  if ((long)(ns - 1) * p.tiles_per_split >= tiles) {   // no empty static range (a worker always owns >= 1 tile)
-    ns = (int)cdiv(tiles, p.tiles_per_split);
-    p.n_split = ns;
-  }
+  p.n_sub = (int)cdiv(a.L, 32);   // ns <= tiles <= n_sub: every static range owns at least one 32-key half tile
   p.sched = ns > 1 ? a.sched : nullptr;
   p.n_tickets = tiles - (2 * ns < tiles ? 2 * ns : tiles) + ns;   // successful draws + one miss per worker
   p.o_part = nullptr;
@@ -414,10 +452,13 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)p.nqb * a.B * a.H * ns;
   PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_fwd: grid too large");
-  const int rec = petr_prof_open_record(PETR_PROF_MHA_FWD + 16 * (a.L > a.Q ? 1 : 0), stream);
+  hipEvent_t ev0, ev1;   // null unless bench.py's profiler is on: then they carry this dispatch's begin/end
+  petr_prof_claim(PETR_PROF_MHA_FWD + 16 * (a.L > a.Q ? 1 : 0), &ev0, &ev1);
   const bool vec = p.q_vec && p.kv_vec;
   static const int lds_pad = getenv("PETR_MHA_FWD_LDS_PAD") ? atoi(getenv("PETR_MHA_FWD_LDS_PAD")) : 0;
-  auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), lds_pad, s, p); };
+  auto launch = [&](auto kern) {
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), lds_pad, s, ev0, ev1, 0, p);
+  };
   const int variant = (a.kpm ? 4 : 0) | (vec ? 2 : 0) | (p.sched ? 1 : 0);
   switch (variant) {
     case 0: launch(mha_fwd_kernel<false, false, false>); break;
@@ -429,7 +470,6 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
     case 6: launch(mha_fwd_kernel<true, true, false>); break;
     default: launch(mha_fwd_kernel<true, true, true>); break;
   }
-  petr_prof_close_record(rec, stream);
   PETR_LAUNCH_CHECK("mha_fwd");
   if (ns > 1) {
     const long n = (long)a.B * a.H * a.Q * 8;

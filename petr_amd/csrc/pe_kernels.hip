@@ -131,9 +131,9 @@ extern "C" int petr_coords3d_fwd(const petr_coords3d_args* a, void* stream) {
   if (a->out) {
     if ((HW & 3) == 0 && aligned16(a->out)) {
       dim3 grid((unsigned)cdiv((long)(HW / 4) * a->D, 256), BN);
-      const int rec = petr_prof_open_record(PETR_PROF_COORDS3D, stream);
-      hipLaunchKernelGGL(coords3d_kernel, grid, dim3(256), 0, s, p);
-      petr_prof_close_record(rec, stream);
+      hipEvent_t ev0, ev1;
+      petr_prof_claim(PETR_PROF_COORDS3D, &ev0, &ev1);
+      hipExtLaunchKernelGGL(coords3d_kernel, grid, dim3(256), 0, s, ev0, ev1, 0, p);
     } else {
       dim3 grid((unsigned)cdiv((long)HW * a->D, 256), BN);
       hipLaunchKernelGGL(coords3d_scalar_kernel, grid, dim3(256), 0, s, p);

@@ -166,7 +166,7 @@ def _bhsd(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
-def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True, dynamic=True):
+def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True, dynamic=False):
     """softmax(scale q k^T + mask) v for [B,H,S,32] (strided) views.  Returns (o [B,H,Q,32], lse [B,H,Q]).
     ``dynamic``: the L-split workers draw K/V tiles from per-query-block ticket counters (zeroed here)."""
     L = _C.lib()

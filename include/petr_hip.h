@@ -85,6 +85,21 @@ int petr_posemb3d_bwd(const float* pos, const float* dim_t, const float* dout, f
                       void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Dropout (training mode; reference: attn_drop 0.1 inside nn.MultiheadAttention, the residual
+ * dropout_layer of both attentions models/utils/petr_transformer.py:258-265,367, and mmcv FFN's
+ * ffn_drop after each of its two Linear layers).
+ *     keep(row, col) = hash32(seed, site, row, col) >= p * 2^32 ; kept values are scaled by 1/(1-p).
+ * Counter-based and stateless: a backward call given the same (seed, site) regenerates the forward's
+ * mask, nothing is stored.  `site` separates the dropout layers of one forward (the executor uses
+ * 8*layer + {0 self-attn P, 1 self-attn out, 2 cross-attn P, 3 cross-attn out, 4 FFN hidden, 5 FFN out}).
+ * The masks cannot equal torch's Philox stream; parity tests export them (petr_dropout_mask) and hand
+ * them to the oracle.  p == 0 disables the layer.                                              */
+typedef struct { uint64_t seed; uint32_t site; float p; } petr_dropout;
+/* keep[row*cols + col] = 1 / 0 for the element a kernel addresses as (row, col): attention P uses
+ * row = (b*H + h)*Q + q, col = key; row-major activations use row = m, col = n.               */
+int petr_dropout_mask(const petr_dropout* d, long rows, long cols, uint8_t* keep, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Dense contraction  C[z][m, n] (+)= act( alpha * sum_k A(m,k) * B(n,k) + bias[n] + R[m,n] )
  *     replaces every nn.Conv2d(1x1) / nn.Linear / F.linear on the path:
  *     petr_head.py:220-274 (input_proj, position_encoder, adapt_pos3d, query_embedding, branches),
@@ -114,6 +129,8 @@ int petr_posemb3d_bwd(const float* pos, const float* dim_t, const float* dout, f
  * ------------------------------------------------------------------------------------------ */
 enum { PETR_GEMM_RELU = 1, PETR_GEMM_ACCUMULATE = 2, PETR_GEMM_RELU_MASK = 4, PETR_GEMM_SIGMOID_MUL = 8,
        PETR_GEMM_ATOMIC = 16 };
+/* drop.p > 0 (only without batch dims / split_k): the activated value act(...) is dropped out with
+ * (row, col) = (m, n) before it is stored (mmcv FFN: Linear, ReLU, Dropout).                   */
 typedef struct {
   const float* a; long lda; int a_kcontig; long a_bs0, a_bs1;
   const float* a2; int a2_rows; int a2_ncols;
@@ -127,6 +144,7 @@ typedef struct {
   float* a_colsum; long cs_bs0, cs_bs1;
   int flags;
   float alpha;
+  petr_dropout drop;
 } petr_gemm_args;
 int petr_gemm(const petr_gemm_args* g, void* stream);
 
@@ -153,6 +171,8 @@ typedef struct {
   /* optional second output y2[m,:] = y[m,:] + add2[m % add2_rows,:]  (query + query_pos for the next
    * attention, petr_transformer.py:341-342, emitted while the row is still in registers) */
   float* y2; const float* add2; int add2_rows;
+  /* dropout of the non-residual part: z = drop(sum partials + bias) + residual (p == 0: off)  */
+  petr_dropout drop;
 } petr_layernorm_args;
 int petr_layernorm_fwd(const petr_layernorm_args* a, void* stream);
 /* dz = LN backward given z (pre-norm input), mean, rstd, gamma, dy (and y if PETR_LN_RELU was used:
@@ -168,6 +188,9 @@ typedef struct {
   /* upstream gradient = sum_{p<dy_partials} dy[p*dy_partial_stride + ...] + dy_residual (both optional):
    * lets a split-K input-gradient contraction hand its slabs over without a reduce launch */
   int dy_partials; long dy_partial_stride; const float* dy_residual;
+  /* optional second output dz_drop = dz * keep / (1-p): the gradient of the dropped branch of
+   * z = drop(f) + residual (dz itself is the residual's gradient)                              */
+  float* dz_drop; petr_dropout drop;
 } petr_layernorm_bwd_args;
 size_t petr_layernorm_bwd_workspace_bytes(int M, int C);
 int petr_layernorm_bwd(const petr_layernorm_bwd_args* a, void* stream);
@@ -195,6 +218,7 @@ typedef struct {
   float scale;
   int n_split;
   void* ws; size_t ws_bytes;
+  petr_dropout drop;   /* dropout of the attention probabilities (row = (b*H+h)*Q+q, col = key) */
   int* sched;   /* optional: B*H*ceil(Q/128) ints, ZERO on entry and left zero on exit; enables dynamic K/V-tile
                  * scheduling between the n_split workers of a query block (NULL: equal static ranges) */
 } petr_mha_fwd_args;
@@ -219,6 +243,7 @@ typedef struct {
   int B, H, Q, L;
   float scale;
   void* ws; size_t ws_bytes;
+  petr_dropout drop;   /* must equal the forward's */
 } petr_mha_bwd_args;
 size_t petr_mha_bwd_workspace_bytes(int B, int H, int Q, int L);
 int petr_mha_bwd(const petr_mha_bwd_args* a, void* stream);
@@ -317,6 +342,8 @@ typedef struct {
   float* all_bbox_preds;        /* [num_layers,B,Q,code_size]                              */
   void* ws; size_t ws_bytes;    /* activations + scratch (petr_head_workspace_bytes)       */
   void* ctx;                    /* petr_ctx* (side streams) or NULL: everything on `stream` */
+  float dropout_p;              /* training mode: the decoder's dropout rate (reference 0.1); 0 = eval */
+  uint64_t dropout_seed;        /* fresh per forward; petr_head_bwd must get the forward's value     */
 } petr_head_io;
 size_t petr_head_workspace_bytes(const petr_head_config* cfg);
 int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io, void* stream);

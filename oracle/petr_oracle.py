@@ -187,9 +187,38 @@ class MultiheadAttentionWrapper(nn.Module):
             query = query + query_pos
         if key_pos is not None:
             key = key + key_pos
+        masks = kwargs.get('masks')
+        if masks is not None:
+            # training-mode parity: the two dropouts with SUPPLIED keep masks (exported from the HIP kernels'
+            # counter-based generator) instead of torch's RNG stream
+            keep_p, keep_o, scale = masks
+            out = self._attention_with_mask(query, key, value, key_padding_mask, keep_p, scale)
+            lq, bs, c = out.shape
+            keep_o = keep_o.view(bs, lq, c).permute(1, 0, 2).to(out.dtype)      # kernel rows are b*Q + q
+            return identity + out * keep_o * scale
         out = self.attn(query=query, key=key, value=value, attn_mask=attn_mask,
                         key_padding_mask=key_padding_mask)[0]
         return identity + self.dropout_layer(self.proj_drop(out))
+
+    def _attention_with_mask(self, query, key, value, key_padding_mask, keep_p, scale):
+        """torch.nn.MultiheadAttention.forward written out (in_proj, 1/sqrt(d) scaling, softmax, dropout on the
+        probabilities, out_proj) so that the probability dropout can take a given mask
+        ``keep_p [(b*H+h)*Lq + q, key]``."""
+        a = self.attn
+        lq, bs, e = query.shape
+        lk = key.shape[0]
+        h, hd = self.num_heads, e // self.num_heads
+        w, b = a.in_proj_weight, a.in_proj_bias
+        q = F.linear(query, w[:e], b[:e]).reshape(lq, bs * h, hd).transpose(0, 1) * hd ** -0.5
+        k = F.linear(key, w[e:2 * e], b[e:2 * e]).reshape(lk, bs * h, hd).transpose(0, 1)
+        v = F.linear(value, w[2 * e:], b[2 * e:]).reshape(lk, bs * h, hd).transpose(0, 1)
+        att = q @ k.transpose(1, 2)
+        if key_padding_mask is not None:
+            att = att.view(bs, h, lq, lk).masked_fill(key_padding_mask[:, None, None, :], float('-inf')).view(bs * h, lq, lk)
+        att = torch.softmax(att, dim=-1)
+        att = att * keep_p.view(bs * h, lq, lk).to(att.dtype) * scale
+        out = (att @ v).transpose(0, 1).reshape(lq, bs, e)
+        return F.linear(out, a.out_proj.weight, a.out_proj.bias)
 
 
 class FFN(nn.Module):
@@ -203,10 +232,17 @@ class FFN(nn.Module):
             nn.Linear(feedforward_channels, embed_dims),
             nn.Dropout(ffn_drop))
 
-    def forward(self, x, identity=None):
-        out = self.layers(x)
+    def forward(self, x, identity=None, masks=None):
         if identity is None:
             identity = x
+        if masks is not None:            # supplied keep masks, rows b*Q + q (see MultiheadAttentionWrapper)
+            keep_h, keep_o, scale = masks
+            lq, bs, _ = x.shape
+            hid = torch.relu(self.layers[0][0](x))
+            hid = hid * keep_h.view(bs, lq, -1).permute(1, 0, 2).to(hid.dtype) * scale
+            out = self.layers[1](hid)
+            return identity + out * keep_o.view(bs, lq, -1).permute(1, 0, 2).to(out.dtype) * scale
+        out = self.layers(x)
         return identity + out
 
 
@@ -229,30 +265,36 @@ class DecoderLayer(nn.Module):
         self.pre_norm = False
 
     def forward(self, query, key=None, value=None, query_pos=None, key_pos=None,
-                key_padding_mask=None, query_key_padding_mask=None):
+                key_padding_mask=None, query_key_padding_mask=None, masks=None):
+        """``masks`` (tests only): dict with the six keep masks of this layer, keys 'sp','so','cp','co','fh','fo',
+        and 'scale' = 1/(1-p); None = the modules' own (RNG / eval) dropout."""
         norm_index = attn_index = ffn_index = 0
         identity = query
+        m = masks
         for layer in self.operation_order:
             if layer == 'self_attn':
                 temp_key = temp_value = query
                 query = self.attentions[attn_index](
                     query, temp_key, temp_value, identity if self.pre_norm else None,
                     query_pos=query_pos, key_pos=query_pos, attn_mask=None,
-                    key_padding_mask=query_key_padding_mask)
+                    key_padding_mask=query_key_padding_mask,
+                    masks=None if m is None else (m['sp'], m['so'], m['scale']))
                 attn_index += 1
                 identity = query
             elif layer == 'cross_attn':
                 query = self.attentions[attn_index](
                     query, key, value, identity if self.pre_norm else None,
                     query_pos=query_pos, key_pos=key_pos, attn_mask=None,
-                    key_padding_mask=key_padding_mask)
+                    key_padding_mask=key_padding_mask,
+                    masks=None if m is None else (m['cp'], m['co'], m['scale']))
                 attn_index += 1
                 identity = query
             elif layer == 'norm':
                 query = self.norms[norm_index](query)
                 norm_index += 1
             elif layer == 'ffn':
-                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                query = self.ffns[ffn_index](query, identity if self.pre_norm else None,
+                                             masks=None if m is None else (m['fh'], m['fo'], m['scale']))
                 ffn_index += 1
         return query
 
@@ -265,10 +307,10 @@ class Decoder(nn.Module):
         self.layers = nn.ModuleList([DecoderLayer(**layer_kw) for _ in range(num_layers)])
         self.post_norm = nn.LayerNorm(layer_kw.get('embed_dims', 256))
 
-    def forward(self, query, **kw):
+    def forward(self, query, dropout_masks=None, **kw):
         intermediate = []
-        for layer in self.layers:
-            query = layer(query, **kw)
+        for i, layer in enumerate(self.layers):
+            query = layer(query, masks=None if dropout_masks is None else dropout_masks[i], **kw)
             intermediate.append(self.post_norm(query))
         return torch.stack(intermediate)
 
@@ -288,7 +330,7 @@ class Transformer(nn.Module):
                 if hasattr(m, 'bias') and m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
-    def forward(self, x, mask, query_embed, pos_embed, reg_branch=None):
+    def forward(self, x, mask, query_embed, pos_embed, reg_branch=None, dropout_masks=None):
         bs, n, c, h, w = x.shape
         memory = x.permute(1, 3, 4, 0, 2).reshape(-1, bs, c)
         pos_embed = pos_embed.permute(1, 3, 4, 0, 2).reshape(-1, bs, c)
@@ -296,7 +338,7 @@ class Transformer(nn.Module):
         mask = mask.view(bs, -1)
         target = torch.zeros_like(query_embed)
         out_dec = self.decoder(query=target, key=memory, value=memory, key_pos=pos_embed,
-                               query_pos=query_embed, key_padding_mask=mask)
+                               query_pos=query_embed, key_padding_mask=mask, dropout_masks=dropout_masks)
         out_dec = out_dec.transpose(1, 2)
         memory = memory.reshape(n, h, w, bs, c).permute(3, 0, 4, 1, 2)
         return out_dec, memory
@@ -414,7 +456,8 @@ class PETRHeadOracle(nn.Module):
         pe = self.position_encoder(vol)
         return pe.view(B, N, self.embed_dims, H, W), coords_mask
 
-    def forward(self, mlvl_feats, img_metas, return_intermediates=False):
+    def forward(self, mlvl_feats, img_metas, return_intermediates=False, dropout_masks=None):
+        """``dropout_masks`` (tests only): per decoder layer the six keep masks + scale, see DecoderLayer.forward."""
         x = mlvl_feats[0]
         batch_size, num_cams = x.size(0), x.size(1)
         x = self.input_proj(x.flatten(0, 1))
@@ -431,7 +474,7 @@ class PETRHeadOracle(nn.Module):
         reference_points = self.reference_points.weight
         query_embeds = self.query_embedding(pos2posemb3d(reference_points))
         reference_points = reference_points.unsqueeze(0).repeat(batch_size, 1, 1)
-        outs_dec, _ = self.transformer(x, masks, query_embeds, pos_embed, self.reg_branches)
+        outs_dec, _ = self.transformer(x, masks, query_embeds, pos_embed, self.reg_branches, dropout_masks=dropout_masks)
         outs_dec = torch.nan_to_num(outs_dec)
         if self.v2 and self.with_time:
             # petrv2_head.py:499-505 — parity is defined for B=1

@@ -32,6 +32,18 @@ class Sine3dArgs(C.Structure):
                        ('normalize', C.c_int), ('scale', C.c_float), ('eps', C.c_float), ('offset', C.c_float))
 
 
+class Dropout(C.Structure):          # petr_dropout
+    _fields_ = _fields(('seed', C.c_uint64), ('site', C.c_uint32), ('p', C.c_float))
+
+
+def dropout(spec):
+    """(seed, site, p) or None -> petr_dropout (p = 0: off)."""
+    if spec is None:
+        return Dropout(0, 0, 0.0)
+    seed, site, p = spec
+    return Dropout(int(seed) & 0xFFFFFFFFFFFFFFFF, int(site), float(p))
+
+
 class GemmArgs(C.Structure):
     _fields_ = _fields(
         ('a', C.c_void_p), ('lda', C.c_long), ('a_kcontig', C.c_int), ('a_bs0', C.c_long), ('a_bs1', C.c_long),
@@ -44,7 +56,7 @@ class GemmArgs(C.Structure):
         ('M', C.c_int), ('N', C.c_int), ('K', C.c_int), ('nb0', C.c_int), ('nb1', C.c_int),
         ('split_k', C.c_int), ('c_split_stride', C.c_long), ('k_seg', C.c_int), ('a_seg_stride', C.c_long),
         ('b_seg_stride', C.c_long), ('a_colsum', C.c_void_p), ('cs_bs0', C.c_long), ('cs_bs1', C.c_long),
-        ('flags', C.c_int), ('alpha', C.c_float))
+        ('flags', C.c_int), ('alpha', C.c_float), ('drop', Dropout))
 
 
 GEMM_RELU, GEMM_ACCUMULATE, GEMM_RELU_MASK, GEMM_SIGMOID_MUL, GEMM_ATOMIC = 1, 2, 4, 8, 16
@@ -56,7 +68,7 @@ class LayerNormArgs(C.Structure):
                        ('bias', C.c_void_p), ('residual', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
                        ('y', C.c_void_p), ('z_out', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p),
                        ('M', C.c_int), ('C', C.c_int), ('eps', C.c_float), ('flags', C.c_int),
-                       ('y2', C.c_void_p), ('add2', C.c_void_p), ('add2_rows', C.c_int))
+                       ('y2', C.c_void_p), ('add2', C.c_void_p), ('add2_rows', C.c_int), ('drop', Dropout))
 
 
 class LayerNormBwdArgs(C.Structure):
@@ -64,7 +76,7 @@ class LayerNormBwdArgs(C.Structure):
                        ('dy', C.c_void_p), ('y', C.c_void_p), ('dz', C.c_void_p), ('dgamma', C.c_void_p),
                        ('dbeta', C.c_void_p), ('ws', C.c_void_p), ('M', C.c_int), ('C', C.c_int), ('flags', C.c_int),
                        ('dz_accumulate', C.c_int), ('dy_partials', C.c_int), ('dy_partial_stride', C.c_long),
-                       ('dy_residual', C.c_void_p))
+                       ('dy_residual', C.c_void_p), ('dz_drop', C.c_void_p), ('drop', Dropout))
 
 
 class MhaFwdArgs(C.Structure):
@@ -75,7 +87,7 @@ class MhaFwdArgs(C.Structure):
         ('o', C.c_void_p), ('o_bs', C.c_long), ('o_hs', C.c_long), ('o_rs', C.c_long),
         ('lse', C.c_void_p), ('kpm', C.c_void_p),
         ('B', C.c_int), ('H', C.c_int), ('Q', C.c_int), ('L', C.c_int), ('scale', C.c_float),
-        ('n_split', C.c_int), ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('sched', C.c_void_p))
+        ('n_split', C.c_int), ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('drop', Dropout), ('sched', C.c_void_p))
 
 
 class MhaBwdArgs(C.Structure):
@@ -90,7 +102,7 @@ class MhaBwdArgs(C.Structure):
         ('dk', C.c_void_p), ('dk_bs', C.c_long), ('dk_hs', C.c_long), ('dk_rs', C.c_long),
         ('dv', C.c_void_p), ('dv_bs', C.c_long), ('dv_hs', C.c_long), ('dv_rs', C.c_long),
         ('B', C.c_int), ('H', C.c_int), ('Q', C.c_int), ('L', C.c_int), ('scale', C.c_float),
-        ('ws', C.c_void_p), ('ws_bytes', C.c_size_t))
+        ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('drop', Dropout))
 
 
 class BboxArgs(C.Structure):
@@ -123,7 +135,8 @@ class HeadIO(C.Structure):
     _fields_ = _fields(('params', C.c_void_p), ('feats', C.c_void_p), ('img2lidar', C.c_void_p), ('depth', C.c_void_p),
                        ('dim_t', C.c_void_p), ('mask', C.c_void_p), ('time_div', C.c_float),
                        ('all_cls_scores', C.c_void_p), ('all_bbox_preds', C.c_void_p),
-                       ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('ctx', C.c_void_p))
+                       ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('ctx', C.c_void_p),
+                       ('dropout_p', C.c_float), ('dropout_seed', C.c_uint64))
 
 
 class HeadGrads(C.Structure):
@@ -203,7 +216,7 @@ EXPORTS = [
     'petr_mha_bwd', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows', 'petr_gate_fwd', 'petr_gate_bwd', 'petr_prof_begin', 'petr_prof_end',
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
-    'petr_ctx_create', 'petr_ctx_destroy',
+    'petr_ctx_create', 'petr_ctx_destroy', 'petr_dropout_mask',
 ]
 
 

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/petr_hip.h"
 
@@ -60,6 +61,40 @@ struct Lanes {
     for (int i = 0; i < ctx->n_side; ++i) join(i);
   }
 };
+
+// ---- dropout (petr_hip.h "Dropout"): host-derived keys + the two device hashes every kernel shares ----
+struct DropDev {
+  uint32_t k0, k1, thr;   // thr = p * 2^32 ; thr == 0: disabled
+  float scale;            // 1 / (1 - thr / 2^32)
+};
+inline DropDev make_drop(const petr_dropout& d) {
+  DropDev r = {0u, 0u, 0u, 1.f};
+  if (!(d.p > 0.f)) return r;
+  uint64_t z = d.seed + 0x9E3779B97F4A7C15ull * (uint64_t)(d.site + 1);   // splitmix64 of (seed, site)
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  r.k0 = (uint32_t)z;
+  r.k1 = (uint32_t)(z >> 32);
+  const double t = (double)d.p * 4294967296.0;
+  r.thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+  if (r.thr == 0u) r.thr = 1u;
+  r.scale = (float)(1.0 / (1.0 - (double)r.thr / 4294967296.0));
+  return r;
+}
+__device__ __forceinline__ uint32_t drop_row_key(const DropDev& d, uint32_t row) {
+  uint32_t x = (row ^ d.k0) * 0x9E3779B1u;
+  x ^= x >> 15;
+  x = (x + d.k1) * 0x85EBCA6Bu;
+  x ^= x >> 13;
+  return x;
+}
+__device__ __forceinline__ bool drop_keep(uint32_t row_key, uint32_t col, uint32_t thr) {
+  uint32_t x = (row_key ^ col) * 0x9E3779B1u;
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  return x >= thr;
+}
 
 #define PETR_CHECK(cond, code, ...)     \
   do {                                  \

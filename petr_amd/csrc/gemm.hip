@@ -317,6 +317,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
   const float* bias = (!plain && g.bias) ? g.bias + z0 * g.bias_bs0 + z1 * g.bias_bs1 : nullptr;
   const float* R = (!plain && g.r) ? g.r + z0 * g.r_bs0 + z1 * g.r_bs1 : nullptr;
   const int flags = plain ? 0 : g.flags;
+  DropDev dd;
+  __builtin_memcpy(&dd, &g.drop, sizeof dd);   // petr_gemm() stored the derived keys here
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn0 + j * 32 + c;
@@ -338,6 +340,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
         else if (flags & PETR_GEMM_RELU_MASK) v = rv > 0.f ? v : 0.f;
         else v += rv;
         if (flags & PETR_GEMM_RELU) v = fmaxf(v, 0.f);
+        if (dd.thr) v = drop_keep(drop_row_key(dd, (uint32_t)mc), (uint32_t)nc, dd.thr) ? v * dd.scale : 0.f;
         v += old;
         if (ok) {
           if (atomic) atomicAdd(dst, v);
@@ -482,6 +485,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const petr_gemm_args g
   const float* R = g.r ? g.r + z0 * g.r_bs0 + z1 * g.r_bs1 : nullptr;
   const int flags = g.flags;
   const bool accumulate = (flags & (PETR_GEMM_ACCUMULATE | PETR_GEMM_ATOMIC)) != 0;
+  DropDev dd;
+  __builtin_memcpy(&dd, &g.drop, sizeof dd);
   const int n = n0 + c;
   const int nc = min(n, g.N - 1);
   const float bv = bias ? bias[nc] : 0.f;
@@ -498,6 +503,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const petr_gemm_args g
     else if (flags & PETR_GEMM_RELU_MASK) v = rv > 0.f ? v : 0.f;
     else v += rv;
     if (flags & PETR_GEMM_RELU) v = fmaxf(v, 0.f);
+    if (dd.thr) v = drop_keep(drop_row_key(dd, (uint32_t)mc), (uint32_t)nc, dd.thr) ? v * dd.scale : 0.f;
     v += old;
     if (m < g.M && n < g.N) *dst = v;
   }
@@ -583,6 +589,16 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
   if (g.nb1 <= 0) g.nb1 = 1;
   if (g.split_k <= 0) g.split_k = 1;
   if (g.alpha == 0.f) g.alpha = 1.f;
+  {
+    // the kernels read g.drop as a DropDev (same 16 bytes): derived keys instead of (seed, site, p)
+    static_assert(sizeof(petr_dropout) == sizeof(DropDev), "petr_dropout / DropDev must have the same size");
+    PETR_CHECK(gp->drop.p >= 0.f && gp->drop.p < 1.f, PETR_ERR_INVALID, "gemm: dropout p=%g outside [0,1)", (double)gp->drop.p);
+    PETR_CHECK(!(gp->drop.p > 0.f) || (g.split_k == 1 && g.nb0 == 1 && g.nb1 == 1 &&
+                                       !(g.flags & (PETR_GEMM_ATOMIC | PETR_GEMM_ACCUMULATE))),
+               PETR_ERR_UNSUPPORTED, "gemm: dropout needs a plain single-batch store");
+    const DropDev dd = make_drop(gp->drop);
+    memcpy(&g.drop, &dd, sizeof dd);
+  }
   PETR_CHECK(!(g.a2 && !g.a_kcontig), PETR_ERR_UNSUPPORTED, "gemm: a2 addend needs a K-contiguous A");
   PETR_CHECK(!((g.flags & (PETR_GEMM_RELU_MASK | PETR_GEMM_SIGMOID_MUL)) && !g.r), PETR_ERR_INVALID,
              "gemm: mask/mul flag without r operand");

@@ -267,7 +267,7 @@ struct WOff {
   // private gradient scratch (never reused inside one backward, so weight-gradient contractions can run on
   // side streams long after the critical path has moved on)
   long s0_raw, s0_r2, s0_r1, s0_c2n, s0_c2, s0_c1n, s0_c1;
-  struct LayerG { long d_z2, d_h, d_x2, d_z1, d_ao, d_x1, d_z0, d_ao_s; } lg[8];
+  struct LayerG { long d_z2, d_h, d_x2, d_z1, d_ao, d_x1, d_z0, d_ao_s, d_zd[3]; } lg[8];
   long total;
 };
 
@@ -395,6 +395,7 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
     g.d_x1 = wb.add("g_d_x1", d.BQ * C);
     g.d_z0 = wb.add("g_d_z0", d.BQ * C);
     g.d_ao_s = wb.add("g_d_ao_s", d.BQ * C);
+    for (int i = 0; i < 3; ++i) g.d_zd[i] = wb.add("g_d_z_dropped", d.BQ * C);   // training mode only
   }
   W.d_mempos = wb.add("d_mempos", d.BL * C);
   W.d_mem = wb.add("d_mem", d.BL * C);
@@ -456,6 +457,9 @@ static petr_gemm_args lin_wgrad(const float* dy, long ldy, const float* x, long 
   return g;
 }
 
+// 1/(1-p) exactly as the kernels apply it (make_drop rounds p to a 32-bit threshold first)
+static float hidden_drop_scale(const petr_dropout& d) { return make_drop(d).scale; }
+
 #define RUN(expr)                 \
   do {                            \
     const int rc__ = (expr);      \
@@ -464,9 +468,10 @@ static petr_gemm_args lin_wgrad(const float* dy, long ldy, const float* x, long 
 
 static int ln_fwd(const float* x, int np, long pstride, const float* bias, const float* res, const float* g,
                   const float* b, float* y, float* z_out, float* mean, float* rstd, long M, int C, int flags, float* y2,
-                  const float* add2, int add2_rows, void* s) {
+                  const float* add2, int add2_rows, void* s, const petr_dropout* drop = nullptr) {
   petr_layernorm_args a;
   memset(&a, 0, sizeof a);
+  if (drop) a.drop = *drop;
   a.x = x; a.n_partials = np; a.partial_stride = pstride; a.bias = bias; a.residual = res; a.gamma = g; a.beta = b;
   a.y = y; a.z_out = z_out; a.mean = mean; a.rstd = rstd; a.M = (int)M; a.C = C; a.eps = 1e-5f; a.flags = flags;
   a.y2 = y2; a.add2 = add2; a.add2_rows = add2_rows;
@@ -475,9 +480,11 @@ static int ln_fwd(const float* x, int np, long pstride, const float* bias, const
 
 static int ln_bwd(const float* z, const float* mean, const float* rstd, const float* g, const float* dy, const float* y,
                   float* dz, float* dg, float* db, long M, int C, int flags, int accumulate, void* s, int dy_partials = 1,
-                  long dy_pstride = 0, const float* dy_res = nullptr) {
+                  long dy_pstride = 0, const float* dy_res = nullptr, float* dz_drop = nullptr,
+                  const petr_dropout* drop = nullptr) {
   petr_layernorm_bwd_args a;
   memset(&a, 0, sizeof a);
+  if (drop && dz_drop) { a.drop = *drop; a.dz_drop = dz_drop; }
   a.dy_partials = dy_partials; a.dy_partial_stride = dy_pstride; a.dy_residual = dy_res;
   a.z = z; a.mean = mean; a.rstd = rstd; a.gamma = g; a.dy = dy; a.y = y; a.dz = dz; a.dgamma = dg; a.dbeta = db;
   a.ws = nullptr; a.M = (int)M; a.C = C; a.flags = flags; a.dz_accumulate = accumulate;
@@ -485,9 +492,11 @@ static int ln_bwd(const float* z, const float* mean, const float* rstd, const fl
 }
 
 static int mha_f(const float* q, long q_bs, long q_rs, const float* k, long k_bs, long k_rs, const float* v, float* o,
-                 float* lse, const uint8_t* kpm, const Dims& d, int L, float* ws, size_t ws_bytes, int* sched, void* s) {
+                 float* lse, const uint8_t* kpm, const Dims& d, int L, float* ws, size_t ws_bytes, int* sched, void* s,
+                 const petr_dropout* drop = nullptr) {
   petr_mha_fwd_args a;
   memset(&a, 0, sizeof a);
+  if (drop) a.drop = *drop;
   a.q = q; a.q_bs = q_bs; a.q_hs = 32; a.q_rs = q_rs;
   a.k = k; a.k_bs = k_bs; a.k_hs = 32; a.k_rs = k_rs;
   a.v = v; a.v_bs = k_bs; a.v_hs = 32; a.v_rs = k_rs;
@@ -500,9 +509,10 @@ static int mha_f(const float* q, long q_bs, long q_rs, const float* k, long k_bs
 
 static int mha_b(const float* q, long q_bs, long q_rs, const float* k, long k_bs, long k_rs, const float* v,
                  const float* o, const float* d_o, const float* lse, const uint8_t* kpm, float* dq, float* dk, float* dv,
-                 const Dims& d, int L, float* ws, size_t ws_bytes, void* s) {
+                 const Dims& d, int L, float* ws, size_t ws_bytes, void* s, const petr_dropout* drop = nullptr) {
   petr_mha_bwd_args a;
   memset(&a, 0, sizeof a);
+  if (drop) a.drop = *drop;
   a.q = q; a.q_bs = q_bs; a.q_hs = 32; a.q_rs = q_rs;
   a.k = k; a.k_bs = k_bs; a.k_hs = 32; a.k_rs = k_rs;
   a.v = v; a.v_bs = k_bs; a.v_hs = 32; a.v_rs = k_rs;
@@ -712,20 +722,36 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   RUN(petr_add_rows(Wm + W.x0, E, Wm + W.lay[0].xe_in, d.BQ, d.Q, C, s));
   const float* x_in = Wm + W.x0;
   float* mws = Wm + W.mha_ws;
+  // Training mode (io->dropout_p > 0): the six dropout layers of a decoder layer (petr_hip.h "Dropout"; sites
+  // 8*l + 0..5).  The residual dropouts act on the sub-layer output BEFORE the identity is added
+  // (petr_transformer.py:367), so in this mode the out-projection / second FFN contraction store the bare
+  // sub-layer output and the LayerNorm prologue does drop(out) + identity; z (the LayerNorm input the backward
+  // needs) is written back over the same buffer.
+  const bool training = io->dropout_p > 0.f;
+  PETR_CHECK(io->dropout_p >= 0.f && io->dropout_p < 1.f, PETR_ERR_INVALID, "head_fwd: dropout_p=%g outside [0,1)",
+             (double)io->dropout_p);
+  auto site = [&](int l, int k) {
+    petr_dropout dr;
+    dr.seed = io->dropout_seed; dr.site = (uint32_t)(8 * l + k); dr.p = io->dropout_p;
+    return dr;
+  };
   for (int l = 0; l < d.NL; ++l) {
     const LayerP& lp = P.lay[l];
     const LayerW& lw = W.lay[l];
+    const petr_dropout dr_sp = site(l, 0), dr_so = site(l, 1), dr_cp = site(l, 2), dr_co = site(l, 3), dr_fh = site(l, 4),
+                       dr_fo = site(l, 5);
     // self-attention: q = k = x + query_pos, v = x  (multi_atten_decoder_layer.py:223-237)
     petr_gemm_args g = lin_fwd(x_in, Pm + lp.sa_in_w, Pm + lp.sa_in_b, Wm + lw.qkv, d.BQ, 3 * C, C);
     g.a2 = E; g.a2_rows = d.Q; g.a2_ncols = 2 * C;
     RUN(petr_gemm(&g, s));
     RUN(mha_f(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
-              Wm + lw.ao_s, Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, sched, s));
+              Wm + lw.ao_s, Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, sched, s, training ? &dr_sp : nullptr));
     g = lin_fwd(Wm + lw.ao_s, Pm + lp.sa_out_w, Pm + lp.sa_out_b, Wm + lw.z0, d.BQ, C, C);
-    g.r = x_in; g.ldr = C;                                             // identity + out (petr_transformer.py:367)
+    if (!training) { g.r = x_in; g.ldr = C; }                          // identity + out (petr_transformer.py:367)
     RUN(petr_gemm(&g, s));
-    RUN(ln_fwd(Wm + lw.z0, 1, 0, nullptr, nullptr, Pm + lp.n_g[0], Pm + lp.n_b[0], Wm + lw.x1, nullptr, Wm + lw.mean0,
-               Wm + lw.rstd0, d.BQ, C, 0, Wm + lw.xe1, E, d.Q, s));
+    RUN(ln_fwd(Wm + lw.z0, 1, 0, nullptr, training ? x_in : nullptr, Pm + lp.n_g[0], Pm + lp.n_b[0], Wm + lw.x1,
+               training ? Wm + lw.z0 : nullptr, Wm + lw.mean0, Wm + lw.rstd0, d.BQ, C, 0, Wm + lw.xe1, E, d.Q, s,
+               training ? &dr_so : nullptr));
     // cross-attention: q = x1 + query_pos, k = mem + pos, v = mem (petr_transformer.py:341-362)
     g = lin_fwd(Wm + lw.xe1, Pm + lp.ca_in_w, Pm + lp.ca_in_b, Wm + lw.qc, d.BQ, C, C);
     RUN(petr_gemm(&g, s));
@@ -734,28 +760,31 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
       ln.join(1);
     }
     RUN(mha_f(Wm + lw.qc, (long)d.Q * C, C, Wm + W.k_all + (long)l * d.L * C, (long)d.NL * d.L * C, C,
-              Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, sched, s));
+              Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, sched, s,
+              training ? &dr_cp : nullptr));
     g = lin_fwd(Wm + lw.ao_c, Pm + lp.ca_out_w, Pm + lp.ca_out_b, Wm + lw.z1, d.BQ, C, C);
-    g.r = Wm + lw.x1; g.ldr = C;
+    if (!training) { g.r = Wm + lw.x1; g.ldr = C; }
     RUN(petr_gemm(&g, s));
-    RUN(ln_fwd(Wm + lw.z1, 1, 0, nullptr, nullptr, Pm + lp.n_g[1], Pm + lp.n_b[1], Wm + lw.x2, nullptr, Wm + lw.mean1,
-               Wm + lw.rstd1, d.BQ, C, 0, nullptr, nullptr, 0, s));
+    RUN(ln_fwd(Wm + lw.z1, 1, 0, nullptr, training ? Wm + lw.x1 : nullptr, Pm + lp.n_g[1], Pm + lp.n_b[1], Wm + lw.x2,
+               training ? Wm + lw.z1 : nullptr, Wm + lw.mean1, Wm + lw.rstd1, d.BQ, C, 0, nullptr, nullptr, 0, s,
+               training ? &dr_co : nullptr));
     // FFN (mmcv FFN): x + W2 relu(W1 x + b1) + b2 ; second contraction split over K
     g = lin_fwd(Wm + lw.x2, Pm + lp.f1_w, Pm + lp.f1_b, Wm + lw.hff, d.BQ, d.F, C);
     g.flags = PETR_GEMM_RELU;
+    if (training) g.drop = dr_fh;                                       // Linear, ReLU, Dropout (mmcv FFN)
     RUN(petr_gemm(&g, s));
     g = lin_fwd(Wm + lw.hff, Pm + lp.f2_w, nullptr, Wm + W.ffn_part, d.BQ, C, d.F);
     g.split_k = W.ffn_split; g.c_split_stride = d.BQ * C;
     float* xs_l = Wm + W.xs + (long)l * d.BQ * C;
-    if (W.ffn_split == 1) { g.bias = Pm + lp.f2_b; g.r = Wm + lw.x2; g.ldr = C; g.c = Wm + lw.z2; }
+    if (W.ffn_split == 1 && !training) { g.bias = Pm + lp.f2_b; g.r = Wm + lw.x2; g.ldr = C; g.c = Wm + lw.z2; }
     RUN(petr_gemm(&g, s));
     float* xe_next = l + 1 < d.NL ? Wm + W.lay[l + 1].xe_in : nullptr;
-    if (W.ffn_split == 1) {
+    if (W.ffn_split == 1 && !training) {
       RUN(ln_fwd(Wm + lw.z2, 1, 0, nullptr, nullptr, Pm + lp.n_g[2], Pm + lp.n_b[2], xs_l, nullptr, Wm + lw.mean2,
                  Wm + lw.rstd2, d.BQ, C, 0, xe_next, E, d.Q, s));
     } else {
       RUN(ln_fwd(Wm + W.ffn_part, W.ffn_split, d.BQ * C, Pm + lp.f2_b, Wm + lw.x2, Pm + lp.n_g[2], Pm + lp.n_b[2], xs_l,
-                 Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, d.BQ, C, 0, xe_next, E, d.Q, s));
+                 Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, d.BQ, C, 0, xe_next, E, d.Q, s, training ? &dr_fo : nullptr));
     }
     x_in = xs_l;
   }
@@ -963,14 +992,22 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       const WOff::LayerG& lg = W.lg[l];
       const float* x_in = l == 0 ? Wm + W.x0 : Wm + W.xs + (long)(l - 1) * d.BQ * C;
       const float* G = Wm + W.d_xs + (long)l * d.BQ * C;     // d(x3_l): post-norm path (+ layer l+1's input grad)
+      // Training mode: z = drop(f) + identity at each of the three LayerNorms, so the sub-layer branch gets
+      // d_z * keep/(1-p) (second output of the LayerNorm backward) while the identity branch keeps d_z.
+      const bool training = io->dropout_p > 0.f;
+      petr_dropout dr[6];
+      for (int k = 0; k < 6; ++k) { dr[k].seed = io->dropout_seed; dr[k].site = (uint32_t)(8 * l + k); dr[k].p = io->dropout_p; }
       // LN2 / FFN
       float* d_z2 = Wm + lg.d_z2;
+      float* d_f2 = training ? Wm + lg.d_zd[2] : d_z2;          // gradient of the second FFN contraction's output
       RUN(ln_bwd(Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, Pm + lp.n_g[2], G, nullptr, d_z2, Gp + lp.n_g[2], Gp + lp.n_b[2],
-                 d.BQ, C, 0, 0, s));
-      RUN(wgrad(lin_wgrad(d_z2, C, Wm + lw.hff, d.F, Gp + lp.f2_w, Gp + lp.f2_b, d.BQ, C, d.F)));
+                 d.BQ, C, 0, 0, s, 1, 0, nullptr, training ? d_f2 : nullptr, &dr[5]));
+      RUN(wgrad(lin_wgrad(d_f2, C, Wm + lw.hff, d.F, Gp + lp.f2_w, Gp + lp.f2_b, d.BQ, C, d.F)));
       float* d_h = Wm + lg.d_h;                                 // [BQ, F]
-      petr_gemm_args g = lin_dgrad(d_z2, Pm + lp.f2_w, d_h, d.BQ, C, d.F);
+      petr_gemm_args g = lin_dgrad(d_f2, Pm + lp.f2_w, d_h, d.BQ, C, d.F);
+      // stored hidden = relu(.) * keep/(1-p): (hidden > 0) is relu-mask AND keep; the 1/(1-p) rides on alpha
       g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + lw.hff; g.ldr = d.F;
+      if (training) g.alpha = hidden_drop_scale(dr[4]);
       RUN(petr_gemm(&g, s));
       RUN(wgrad(lin_wgrad(d_h, d.F, Wm + lw.x2, C, Gp + lp.f1_w, Gp + lp.f1_b, d.BQ, d.F, C)));
       // d_x2 = d_h @ W1 + d_z2 (identity path): K = F is long and there are only BQ/64 x 4 output tiles, so the
@@ -983,16 +1020,18 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       RUN(petr_gemm(&g, s));
       // LN1 / cross-attention
       float* d_z1 = Wm + lg.d_z1;
+      float* d_f1 = training ? Wm + lg.d_zd[1] : d_z1;          // gradient of the cross-attention out-projection's output
       RUN(ln_bwd(Wm + lw.z1, Wm + lw.mean1, Wm + lw.rstd1, Pm + lp.n_g[1], d_x2, nullptr, d_z1, Gp + lp.n_g[1],
-                 Gp + lp.n_b[1], d.BQ, C, 0, 0, s, sk, d.BQ * C, sk > 1 ? d_z2 : nullptr));
-      RUN(wgrad(lin_wgrad(d_z1, C, Wm + lw.ao_c, C, Gp + lp.ca_out_w, Gp + lp.ca_out_b, d.BQ, C, C)));
+                 Gp + lp.n_b[1], d.BQ, C, 0, 0, s, sk, d.BQ * C, sk > 1 ? d_z2 : nullptr, training ? d_f1 : nullptr, &dr[3]));
+      RUN(wgrad(lin_wgrad(d_f1, C, Wm + lw.ao_c, C, Gp + lp.ca_out_w, Gp + lp.ca_out_b, d.BQ, C, C)));
       float* d_ao = Wm + lg.d_ao;
-      g = lin_dgrad(d_z1, Pm + lp.ca_out_w, d_ao, d.BQ, C, C);
+      g = lin_dgrad(d_f1, Pm + lp.ca_out_w, d_ao, d.BQ, C, C);
       RUN(petr_gemm(&g, s));
       float* d_qc = Wm + W.d_qc + (long)l * d.BQ * C;
       RUN(mha_b(Wm + lw.qc, (long)d.Q * C, C, Wm + W.k_all + (long)l * d.L * C, (long)d.NL * d.L * C, C,
                 Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, d_ao, Wm + lw.lse_c, kpm, d_qc,
-                Wm + W.dk_all + (long)l * d.L * C, Wm + W.dv_all + (long)l * d.L * C, d, (int)d.L, mws, W.mha_ws_bytes, s));
+                Wm + W.dk_all + (long)l * d.L * C, Wm + W.dv_all + (long)l * d.L * C, d, (int)d.L, mws, W.mha_ws_bytes, s,
+                training ? &dr[2] : nullptr));
       // q projection of the cross-attention (rows 0..C of in_proj): weight grads live in the final block
       RUN(wgrad(lin_wgrad(d_qc, C, Wm + lw.xe1, C, Gp + lp.ca_in_w, Gp + lp.ca_in_b, d.BQ, C, C)));
       float* d_x1 = Wm + lg.d_x1;
@@ -1001,15 +1040,17 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       RUN(petr_gemm(&g, s));
       // LN0 / self-attention
       float* d_z0 = Wm + lg.d_z0;
+      float* d_f0 = training ? Wm + lg.d_zd[0] : d_z0;          // gradient of the self-attention out-projection's output
       RUN(ln_bwd(Wm + lw.z0, Wm + lw.mean0, Wm + lw.rstd0, Pm + lp.n_g[0], d_x1, nullptr, d_z0, Gp + lp.n_g[0],
-                 Gp + lp.n_b[0], d.BQ, C, 0, 0, s));
-      RUN(wgrad(lin_wgrad(d_z0, C, Wm + lw.ao_s, C, Gp + lp.sa_out_w, Gp + lp.sa_out_b, d.BQ, C, C)));
+                 Gp + lp.n_b[0], d.BQ, C, 0, 0, s, 1, 0, nullptr, training ? d_f0 : nullptr, &dr[1]));
+      RUN(wgrad(lin_wgrad(d_f0, C, Wm + lw.ao_s, C, Gp + lp.sa_out_w, Gp + lp.sa_out_b, d.BQ, C, C)));
       float* d_ao_s = Wm + lg.d_ao_s;
-      g = lin_dgrad(d_z0, Pm + lp.sa_out_w, d_ao_s, d.BQ, C, C);
+      g = lin_dgrad(d_f0, Pm + lp.sa_out_w, d_ao_s, d.BQ, C, C);
       RUN(petr_gemm(&g, s));
       float* d_qkv = Wm + W.d_qkv + (long)l * d.BQ * 3 * C;
       RUN(mha_b(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
-                Wm + lw.ao_s, d_ao_s, Wm + lw.lse_s, nullptr, d_qkv, d_qkv + C, d_qkv + 2 * C, d, d.Q, mws, W.mha_ws_bytes, s));
+                Wm + lw.ao_s, d_ao_s, Wm + lw.lse_s, nullptr, d_qkv, d_qkv + C, d_qkv + 2 * C, d, d.Q, mws, W.mha_ws_bytes, s,
+                training ? &dr[0] : nullptr));
       // in_proj: q,k rows see x + query_pos, v rows see x
       RUN(wgrad(lin_wgrad(d_qkv, 3 * C, Wm + lw.xe_in, C, Gp + lp.sa_in_w, Gp + lp.sa_in_b, d.BQ, 2 * C, C)));
       RUN(wgrad(lin_wgrad(d_qkv + 2 * C, 3 * C, x_in, C, Gp + lp.sa_in_w + (long)2 * C * C, Gp + lp.sa_in_b + 2 * C, d.BQ, C,

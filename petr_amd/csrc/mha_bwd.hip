@@ -33,9 +33,13 @@ struct MhaBwdParams {
   petr_mha_bwd_args a;
   int nkb, q_splits, qtiles_per_split;
   int vec;             // q/do/k/v 16-byte loads legal
+  DropDev drop;        // the forward's probability dropout (thr == 0: off)
 };
 
-template <bool HAS_MASK, bool VEC>
+// DROP: the forward multiplied the probabilities by keep/(1-p) after the softmax, so with m = keep/(1-p)
+//   dV += dO^T (p*m) ,  dP = m * (dO V^T) ,  ds = p * (dP - delta)   (delta = rowsum(dO*O) of the DROPPED output)
+// and the masks are regenerated from (seed, site, row, key), row = (b*H+h)*Q + q.
+template <bool HAS_MASK, bool VEC, bool DROP>
 __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
   __shared__ __attribute__((aligned(16))) float Qs[32 * P33];
   __shared__ __attribute__((aligned(16))) float dOs[32 * P33];
@@ -43,6 +47,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
   __shared__ __attribute__((aligned(16))) float Ks[128 * 32];
   __shared__ __attribute__((aligned(16))) float red[4][32 * P33];
   __shared__ float lse_s[32], dl_s[32];
+  __shared__ uint32_t rk_s[32];
 
   const petr_mha_bwd_args& a = p.a;
   const int total = p.nkb * a.B * a.H * p.q_splits;
@@ -144,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
       if (t < 32) {
         const bool rok = qt * 32 + t < a.Q;
         lse_s[t] = rok ? -lreg * inv_scale : -INFINITY;   // rows beyond Q: -LSE/scale = -inf  =>  p = 0
+        if (DROP) rk_s[t] = drop_row_key(p.drop, (uint32_t)(bh * a.Q + min(qt * 32 + t, a.Q - 1)));
       }
     }
     __syncthreads();
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
     for (int r = 0; r < 16; ++r) {
       const int qr = mfma32_row(r, h);
       S[r] = lse_s[qr] + key_bias;
-      dP[r] = dl_s[qr];
+      dP[r] = DROP ? 0.f : dl_s[qr];
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -164,7 +170,14 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       S[r] = __builtin_amdgcn_exp2f(S[r] * sc2);   // p
-      dP[r] = S[r] * dP[r];                        // ds (without the softmax scale)
+      if (DROP) {
+        const int qr = mfma32_row(r, h);
+        const float m = drop_keep(rk_s[qr], (uint32_t)key, p.drop.thr) ? p.drop.scale : 0.f;
+        dP[r] = S[r] * (dP[r] * m + dl_s[qr]);     // ds = p * (m * dO.V - delta)
+        S[r] *= m;                                 // dropped probability: B operand of dV
+      } else {
+        dP[r] = S[r] * dP[r];                      // ds (without the softmax scale)
+      }
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -276,13 +289,19 @@ extern "C" int petr_mha_bwd(const petr_mha_bwd_args* ap, void* stream) {
   PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_bwd: grid too large");
   hipEvent_t ev0, ev1;   // null unless bench.py's profiler is on: then they carry this dispatch's begin/end
   petr_prof_claim(PETR_PROF_MHA_BWD + 16 * (a.L > a.Q ? 1 : 0), &ev0, &ev1);
+  PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "mha_bwd: dropout p=%g outside [0,1)", (double)a.drop.p);
+  PETR_CHECK((long)a.B * a.H * a.Q < (1L << 32), PETR_ERR_UNSUPPORTED, "mha_bwd: dropout row index needs B*H*Q < 2^32");
+  p.drop = make_drop(a.drop);
   auto launch = [&](auto kern) { hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), 0, s, ev0, ev1, 0, p); };
-  if (a.kpm) {
-    if (p.vec) launch(mha_bwd_kernel<true, true>);
-    else launch(mha_bwd_kernel<true, false>);
-  } else {
-    if (p.vec) launch(mha_bwd_kernel<false, true>);
-    else launch(mha_bwd_kernel<false, false>);
+  switch ((p.drop.thr ? 4 : 0) | (a.kpm ? 2 : 0) | (p.vec ? 1 : 0)) {
+    case 0: launch(mha_bwd_kernel<false, false, false>); break;
+    case 1: launch(mha_bwd_kernel<false, true, false>); break;
+    case 2: launch(mha_bwd_kernel<true, false, false>); break;
+    case 3: launch(mha_bwd_kernel<true, true, false>); break;
+    case 4: launch(mha_bwd_kernel<false, false, true>); break;
+    case 5: launch(mha_bwd_kernel<false, true, true>); break;
+    case 6: launch(mha_bwd_kernel<true, false, true>); break;
+    default: launch(mha_bwd_kernel<true, true, true>); break;
   }
   PETR_LAUNCH_CHECK("mha_bwd");
   return PETR_OK;

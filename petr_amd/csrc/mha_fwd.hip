@@ -37,6 +37,7 @@ struct MhaFwdParams {
   float* ml_part;  // [n_split][B*H][Q][2]
   int q_vec, kv_vec;
   int n_tiles, n_tickets;
+  DropDev drop;    // dropout of the probabilities (thr == 0: off)
   int* sched;      // [B*H*nqb] tile tickets (dynamic mode), zero on entry, zero again on exit
 };
 
@@ -60,7 +61,7 @@ __device__ unsigned long long g_diag[4 * 4 * 4096];   // per wave: cycles, realt
 // one finishes the last third of its range alone at 2/3 of the MFMA rate; with tickets the fast worker simply
 // takes more tiles and both drain together (the same mechanism absorbs the ragged last range and the mostly
 // padded last query block).  The worker whose ticket is the group's last resets the counter for the next launch.
-template <bool HAS_MASK, bool VEC, bool DYN>
+template <bool HAS_MASK, bool VEC, bool DYN, bool DROP>
 __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   constexpr int MERGE_PITCH = 17;
   constexpr int IMG = 32 * KT_PITCH + KV_TILE * 32;   // one K^T + V image pair, floats
@@ -85,6 +86,10 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   const int q_row = qb * 128 + qg * 32 + c;
   const int q_ld = min(q_row, a.Q - 1);
   const bool wave_active = qb * 128 + qg * 32 < a.Q;
+  // attention-probability dropout (nn.MultiheadAttention's attn_drop): element (row, col) = ((b*H+h)*Q + q, key);
+  // the row sum l keeps the UNdropped probabilities (softmax first, dropout after), the 1/(1-p) is applied once
+  // to the finished output
+  const uint32_t drop_rk = DROP ? drop_row_key(p.drop, (uint32_t)(bh * a.Q + q_ld)) : 0u;
 
   // Static ranges are cut at 32-key granularity (132 halves over 8 workers = 16/17 each at c5, not 9,9,...,3
   // tiles): the worker's tiles are 64-key steps from ITS first key and its last tile may be half (the half-tile
@@ -300,6 +305,11 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
       }
       l_run += xhalf_sum(acc.x + acc.y);
     }
+    if (DROP) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        S[r] = drop_keep(drop_rk, (uint32_t)(k0 + kh * 32 + mfma32_row(r, h)), p.drop.thr) ? S[r] : 0.f;
+    }
 #endif
 #pragma unroll
     for (int s = 0; s < 16; ++s) O = __builtin_amdgcn_mfma_f32_32x32x2f32(vfr[s], S[s], O, 0, 0, 0);
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
     m_run = m_new;
   }
   if (p.n_split == 1) {
-    const float inv = 1.f / l_run;   // fully masked row: 0 * inf = NaN, as torch's softmax of all -inf
+    const float inv = (DROP ? p.drop.scale : 1.f) / l_run;   // fully masked row: 0 * inf = NaN, as torch's softmax of all -inf
     float* op = a.o + (long)b * a.o_bs + (long)hd * a.o_hs + (long)q_row * a.o_rs;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(256) void mha_combine_kernel(const MhaFwdParams p) 
     L += ls * wgt;
     acc.x += o.x * wgt; acc.y += o.y * wgt; acc.z += o.z * wgt; acc.w += o.w * wgt;
   }
-  const float inv = 1.f / L;
+  const float inv = p.drop.scale / L;   // scale == 1 without dropout
   const int q = (int)(row % a.Q);
   const int bh = (int)(row / a.Q);
   const int b = bh / a.H, hd = bh - b * a.H;
@@ -436,6 +446,9 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
   p.n_tiles = tiles;
   p.n_sub = (int)cdiv(a.L, 32);   // ns <= tiles <= n_sub: every static range owns at least one 32-key half tile
   p.sched = ns > 1 ? a.sched : nullptr;
+  PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "mha_fwd: dropout p=%g outside [0,1)", (double)a.drop.p);
+  PETR_CHECK((long)a.B * a.H * a.Q < (1L << 32), PETR_ERR_UNSUPPORTED, "mha_fwd: dropout row index needs B*H*Q < 2^32");
+  p.drop = make_drop(a.drop);
   p.n_tickets = tiles - (2 * ns < tiles ? 2 * ns : tiles) + ns;   // successful draws + one miss per worker
   p.o_part = nullptr;
   p.ml_part = nullptr;
@@ -459,16 +472,24 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
   auto launch = [&](auto kern) {
     hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), lds_pad, s, ev0, ev1, 0, p);
   };
-  const int variant = (a.kpm ? 4 : 0) | (vec ? 2 : 0) | (p.sched ? 1 : 0);
+  const int variant = (p.drop.thr ? 8 : 0) | (a.kpm ? 4 : 0) | (vec ? 2 : 0) | (p.sched ? 1 : 0);
   switch (variant) {
-    case 0: launch(mha_fwd_kernel<false, false, false>); break;
-    case 1: launch(mha_fwd_kernel<false, false, true>); break;
-    case 2: launch(mha_fwd_kernel<false, true, false>); break;
-    case 3: launch(mha_fwd_kernel<false, true, true>); break;
-    case 4: launch(mha_fwd_kernel<true, false, false>); break;
-    case 5: launch(mha_fwd_kernel<true, false, true>); break;
-    case 6: launch(mha_fwd_kernel<true, true, false>); break;
-    default: launch(mha_fwd_kernel<true, true, true>); break;
+    case 0: launch(mha_fwd_kernel<false, false, false, false>); break;
+    case 1: launch(mha_fwd_kernel<false, false, true, false>); break;
+    case 2: launch(mha_fwd_kernel<false, true, false, false>); break;
+    case 3: launch(mha_fwd_kernel<false, true, true, false>); break;
+    case 4: launch(mha_fwd_kernel<true, false, false, false>); break;
+    case 5: launch(mha_fwd_kernel<true, false, true, false>); break;
+    case 6: launch(mha_fwd_kernel<true, true, false, false>); break;
+    case 7: launch(mha_fwd_kernel<true, true, true, false>); break;
+    case 8: launch(mha_fwd_kernel<false, false, false, true>); break;
+    case 9: launch(mha_fwd_kernel<false, false, true, true>); break;
+    case 10: launch(mha_fwd_kernel<false, true, false, true>); break;
+    case 11: launch(mha_fwd_kernel<false, true, true, true>); break;
+    case 12: launch(mha_fwd_kernel<true, false, false, true>); break;
+    case 13: launch(mha_fwd_kernel<true, false, true, true>); break;
+    case 14: launch(mha_fwd_kernel<true, true, false, true>); break;
+    default: launch(mha_fwd_kernel<true, true, true, true>); break;
   }
   PETR_LAUNCH_CHECK("mha_fwd");
   if (ns > 1) {

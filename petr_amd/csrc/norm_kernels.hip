@@ -22,6 +22,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(petr_layernorm_args 
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.M) return;
   const int nv = a.C >> 2;
+  DropDev dd;
+  __builtin_memcpy(&dd, &a.drop, sizeof dd);   // petr_layernorm_fwd() stored the derived keys here
+  const uint32_t rk = dd.thr ? drop_row_key(dd, (uint32_t)row) : 0u;
   float4 v[LN_MAXV];
   float sum = 0.f;
 #pragma unroll
@@ -37,6 +40,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(petr_layernorm_args 
       if (a.bias) {
         const float4 y = reinterpret_cast<const float4*>(a.bias)[i4];
         x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+      }
+      if (dd.thr) {   // dropout of the sub-layer output, before the identity is added
+        x.x = drop_keep(rk, 4 * i4, dd.thr) ? x.x * dd.scale : 0.f;
+        x.y = drop_keep(rk, 4 * i4 + 1, dd.thr) ? x.y * dd.scale : 0.f;
+        x.z = drop_keep(rk, 4 * i4 + 2, dd.thr) ? x.z * dd.scale : 0.f;
+        x.w = drop_keep(rk, 4 * i4 + 3, dd.thr) ? x.w * dd.scale : 0.f;
       }
       if (a.residual) {
         const float4 y = reinterpret_cast<const float4*>(a.residual + (size_t)row * a.C)[i4];
@@ -103,6 +112,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(petr_layernorm_bwd_a
   float4 dg[LN_MAXV], db[LN_MAXV];
 #pragma unroll
   for (int j = 0; j < LN_MAXV; ++j) dg[j] = db[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  DropDev dd;
+  __builtin_memcpy(&dd, &a.drop, sizeof dd);   // petr_layernorm_bwd() stored the derived keys here
   for (int row = blockIdx.x * 4 + wave; row < a.M; row += nblocks * 4) {
     const float mean = a.mean[row], rstd = a.rstd[row];
     float4 xh[LN_MAXV], g[LN_MAXV];
@@ -149,6 +160,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(petr_layernorm_bwd_a
         float4* dst = reinterpret_cast<float4*>(a.dz + (size_t)row * a.C) + i4;
         if (a.dz_accumulate) { const float4 o = *dst; d.x += o.x; d.y += o.y; d.z += o.z; d.w += o.w; }
         *dst = d;
+        if (a.dz_drop) {   // gradient of the dropped branch of z = drop(f) + residual
+          const uint32_t rk = drop_row_key(dd, (uint32_t)row);
+          float4 e;
+          e.x = drop_keep(rk, 4 * i4, dd.thr) ? d.x * dd.scale : 0.f;
+          e.y = drop_keep(rk, 4 * i4 + 1, dd.thr) ? d.y * dd.scale : 0.f;
+          e.z = drop_keep(rk, 4 * i4 + 2, dd.thr) ? d.z * dd.scale : 0.f;
+          e.w = drop_keep(rk, 4 * i4 + 3, dd.thr) ? d.w * dd.scale : 0.f;
+          reinterpret_cast<float4*>(a.dz_drop + (size_t)row * a.C)[i4] = e;
+        }
       }
     }
   }
@@ -324,6 +344,25 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(const float* x, int B
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void dropout_mask_kernel(DropDev d, long rows, long cols, uint8_t* keep) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long row = i / cols, col = i - row * cols;
+  keep[i] = d.thr == 0u || drop_keep(drop_row_key(d, (uint32_t)row), (uint32_t)col, d.thr) ? 1 : 0;
+}
+}  // namespace
+
+extern "C" int petr_dropout_mask(const petr_dropout* d, long rows, long cols, uint8_t* keep, void* stream) {
+  PETR_CHECK(d && keep && rows > 0 && cols > 0 && rows < (1L << 32) && cols < (1L << 32), PETR_ERR_INVALID,
+             "dropout_mask: bad arguments");
+  PETR_CHECK(d->p >= 0.f && d->p < 1.f, PETR_ERR_INVALID, "dropout_mask: p=%g outside [0,1)", (double)d->p);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)cdiv(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream,
+                     make_drop(*d), rows, cols, keep);
+  PETR_LAUNCH_CHECK("dropout_mask");
+  return PETR_OK;
+}
+
 extern "C" int petr_layernorm_fwd(const petr_layernorm_args* a, void* stream) {
   PETR_CHECK(a && a->x && a->gamma && a->beta && a->y, PETR_ERR_INVALID, "layernorm: null pointer");
   PETR_CHECK(a->M > 0 && a->C > 0 && (a->C & 3) == 0 && a->C <= 256 * LN_MAXV, PETR_ERR_UNSUPPORTED,
@@ -335,6 +374,12 @@ extern "C" int petr_layernorm_fwd(const petr_layernorm_args* a, void* stream) {
              PETR_ERR_INVALID, "layernorm: pointers must be 16-byte aligned");
   petr_layernorm_args p = *a;
   if (p.n_partials <= 0) p.n_partials = 1;
+  {
+    static_assert(sizeof(petr_dropout) == sizeof(DropDev), "petr_dropout / DropDev must have the same size");
+    PETR_CHECK(a->drop.p >= 0.f && a->drop.p < 1.f, PETR_ERR_INVALID, "layernorm: dropout p=%g outside [0,1)", (double)a->drop.p);
+    const DropDev dd = make_drop(a->drop);   // the kernel reads p.drop as a DropDev (same 16 bytes)
+    memcpy(&p.drop, &dd, sizeof dd);
+  }
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)cdiv(a->M, 4)), dim3(256), 0, (hipStream_t)stream, p);
   PETR_LAUNCH_CHECK("layernorm_fwd");
   return PETR_OK;
@@ -354,7 +399,14 @@ extern "C" int petr_layernorm_bwd(const petr_layernorm_bwd_args* a, void* stream
   int nblocks = (int)((cdiv(a->M, 4) < LNB_BLOCKS) ? cdiv(a->M, 4) : LNB_BLOCKS);
   if (!a->ws && nblocks > 64) nblocks = 64;   // atomics form: fewer, longer blocks -> fewer atomic adds
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblocks), dim3(256), 0, s, *a, nblocks);
+  petr_layernorm_bwd_args p = *a;
+  {
+    PETR_CHECK(!a->dz_drop || (a->drop.p > 0.f && a->drop.p < 1.f && aligned16(a->dz_drop)), PETR_ERR_INVALID,
+               "layernorm_bwd: dz_drop needs 0 < p < 1 and a 16-byte aligned pointer");
+    const DropDev dd = make_drop(a->drop);
+    memcpy(&p.drop, &dd, sizeof dd);
+  }
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblocks), dim3(256), 0, s, p, nblocks);
   PETR_LAUNCH_CHECK("layernorm_bwd");
   if (a->ws && (a->dgamma || a->dbeta)) {
     hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((unsigned)cdiv(2 * a->C, 256)), dim3(256), 0, s,

@@ -74,7 +74,9 @@ def gemm_raw(**kw):
     g = _C.GemmArgs()
     keep = []
     for k, v in kw.items():
-        if isinstance(v, torch.Tensor):
+        if k == 'drop':
+            v = _C.dropout(v)
+        elif isinstance(v, torch.Tensor):
             keep.append(v)
             v = v.data_ptr()
         setattr(g, k, v)
@@ -82,8 +84,9 @@ def gemm_raw(**kw):
 
 
 def linear(x, w, bias=None, relu=False, residual=None, a2=None, a2_rows=0, a2_ncols=0, out=None, accumulate=False,
-           split_k=1):
-    """y = act((x [+ a2]) @ w.T + bias [+ residual]);  x [M,K] row-major, w [N,K] (nn.Linear layout)."""
+           split_k=1, drop=None):
+    """y = drop(act((x [+ a2]) @ w.T + bias [+ residual]));  x [M,K] row-major, w [N,K] (nn.Linear layout);
+    drop = (seed, site, p) or None."""
     M, K = x.shape
     N = w.shape[0]
     if split_k > 1:
@@ -99,8 +102,19 @@ def linear(x, w, bias=None, relu=False, residual=None, a2=None, a2_rows=0, a2_nc
         kw.update(r=residual, ldr=residual.stride(0))
     if a2 is not None:
         kw.update(a2=a2, a2_rows=a2_rows, a2_ncols=a2_ncols)
+    if drop is not None:
+        kw['drop'] = drop
     gemm_raw(**kw)
     return out
+
+
+def dropout_mask(drop, rows, cols, device='cuda'):
+    """The keep mask (bool [rows, cols]) a kernel applies for drop = (seed, site, p): parity tests hand it to the oracle."""
+    L = _C.lib()
+    keep = torch.empty((rows, cols), dtype=torch.uint8, device=device)
+    d = _C.dropout(drop)
+    _C.check(L.petr_dropout_mask(C.byref(d), C.c_long(rows), C.c_long(cols), _ptr(keep), _stream()), 'petr_dropout_mask')
+    return keep.bool()
 
 
 def conv1x1(x, w, bias=None, relu=False, out=None, accumulate=False):
@@ -128,8 +142,9 @@ def colsum(x, out=None, accumulate=False):
     return out
 
 
-def layernorm(x, gamma, beta, bias=None, residual=None, relu=False, nan_to_num=False, eps=1e-5, save_stats=False):
-    """y = LN(sum_p x[p] + bias + residual); x [M,C] or [P,M,C] (split-K partial slabs)."""
+def layernorm(x, gamma, beta, bias=None, residual=None, relu=False, nan_to_num=False, eps=1e-5, save_stats=False,
+              drop=None):
+    """y = LN(drop(sum_p x[p] + bias) + residual); x [M,C] or [P,M,C] (split-K partial slabs); drop = (seed, site, p)."""
     L = _C.lib()
     if x.dim() == 3:
         P, M, Cc = x.shape
@@ -143,22 +158,25 @@ def layernorm(x, gamma, beta, bias=None, residual=None, relu=False, nan_to_num=F
         rstd = torch.empty_like(mean)
     flags = (_C.LN_RELU if relu else 0) | (_C.LN_NAN_TO_NUM if nan_to_num else 0)
     a = _C.LayerNormArgs(_ptr(_f32(x)), P, M * Cc, _ptr(bias), _ptr(residual), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(z),
-                         _ptr(mean), _ptr(rstd), M, Cc, float(eps), flags)
+                         _ptr(mean), _ptr(rstd), M, Cc, float(eps), flags, None, None, 0, _C.dropout(drop))
     _C.check(L.petr_layernorm_fwd(C.byref(a), _stream()), 'petr_layernorm_fwd')
     return (y, z, mean, rstd) if save_stats else y
 
 
-def layernorm_bwd(z, mean, rstd, gamma, dy, y=None, relu=False):
+def layernorm_bwd(z, mean, rstd, gamma, dy, y=None, relu=False, drop=None):
+    """Returns (dz, dgamma, dbeta) and, with drop = (seed, site, p), also dz * keep / (1 - p)."""
     L = _C.lib()
     M, Cc = z.shape
     dz = torch.empty_like(z)
+    dz_drop = torch.empty_like(z) if drop is not None else None
     dgamma = torch.zeros_like(gamma)
     dbeta = torch.zeros_like(gamma)
     ws = torch.empty(L.petr_layernorm_bwd_workspace_bytes(M, Cc) // 4, dtype=torch.float32, device=z.device)
     a = _C.LayerNormBwdArgs(_ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(_f32(dy).contiguous()), _ptr(y), _ptr(dz),
-                            _ptr(dgamma), _ptr(dbeta), _ptr(ws), M, Cc, _C.LN_RELU if relu else 0, 0)
+                            _ptr(dgamma), _ptr(dbeta), _ptr(ws), M, Cc, _C.LN_RELU if relu else 0, 0, 1, 0, None,
+                            _ptr(dz_drop), _C.dropout(drop))
     _C.check(L.petr_layernorm_bwd(C.byref(a), _stream()), 'petr_layernorm_bwd')
-    return dz, dgamma, dbeta
+    return (dz, dgamma, dbeta) if drop is None else (dz, dgamma, dbeta, dz_drop)
 
 
 def _bhsd(t):
@@ -166,7 +184,7 @@ def _bhsd(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
-def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True, dynamic=False):
+def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True, dynamic=False, drop=None):
     """softmax(scale q k^T + mask) v for [B,H,S,32] (strided) views.  Returns (o [B,H,Q,32], lse [B,H,Q]).
     ``dynamic``: the L-split workers draw K/V tiles from per-query-block ticket counters (zeroed here)."""
     L = _C.lib()
@@ -181,12 +199,12 @@ def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True
     kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
     sched = torch.zeros(B * H * ((Q + 127) // 128), dtype=torch.int32, device=q.device) if dynamic else None
     a = _C.MhaFwdArgs(_ptr(_f32(q)), *_bhsd(q), _ptr(_f32(k)), *_bhsd(k), _ptr(_f32(v)), *_bhsd(v), _ptr(o), *_bhsd(o),
-                      _ptr(lse), _ptr(kpm), B, H, Q, Lk, scale, ns, _ptr(ws), nbytes, _ptr(sched))
+                      _ptr(lse), _ptr(kpm), B, H, Q, Lk, scale, ns, _ptr(ws), nbytes, _C.dropout(drop), _ptr(sched))
     _C.check(L.petr_mha_fwd(C.byref(a), _stream()), 'petr_mha_fwd')
     return o, lse
 
 
-def mha_bwd(q, k, v, o, do, lse, key_padding_mask=None, scale=None):
+def mha_bwd(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=None):
     L = _C.lib()
     B, H, Q, _ = q.shape
     Lk = k.shape[2]
@@ -199,7 +217,7 @@ def mha_bwd(q, k, v, o, do, lse, key_padding_mask=None, scale=None):
     kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
     a = _C.MhaBwdArgs(_ptr(_f32(q)), *_bhsd(q), _ptr(_f32(k)), *_bhsd(k), _ptr(_f32(v)), *_bhsd(v), _ptr(_f32(o)), *_bhsd(o),
                       _ptr(_f32(do)), *_bhsd(do), _ptr(lse), _ptr(kpm), _ptr(dq), *_bhsd(dq), _ptr(dk), *_bhsd(dk),
-                      _ptr(dv), *_bhsd(dv), B, H, Q, Lk, scale, _ptr(ws), nbytes)
+                      _ptr(dv), *_bhsd(dv), B, H, Q, Lk, scale, _ptr(ws), nbytes, _C.dropout(drop))
     _C.check(L.petr_mha_bwd(C.byref(a), _stream()), 'petr_mha_bwd')
     return dq, dk, dv
 

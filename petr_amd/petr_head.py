@@ -413,10 +413,36 @@ class PETRHead(nn.Module):
         io.ws = run.ws.data_ptr()
         io.ws_bytes = run.ws.numel() * 4
         io.ctx = self._context()
+        # training mode: the decoder's six dropout layers per decoder layer run inside the kernels from a
+        # counter-based generator; a fresh seed per forward is drawn from torch's default CPU generator
+        # (torch.manual_seed makes runs repeatable).  eval(): p = 0, the dropout-free kernels.
+        drop_p = float(self._dropout_p()) if self.training else 0.0
+        io.dropout_p, io.dropout_seed = drop_p, 0
+        if drop_p > 0.0:
+            seed = getattr(self, '_dropout_seed_override', None)
+            io.dropout_seed = int(seed) if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+        self._last_dropout = (int(io.dropout_seed), drop_p)
         run.io = io
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         _C.check(L.petr_head_fwd(C.byref(run.cfg), C.byref(io), stream), 'petr_head_fwd')
         return run.cls, run.bbox
+
+    def _dropout_p(self):
+        """The one dropout rate of the decoder (reference configs: attn_drop = dropout_layer = ffn_drop = 0.1).
+        The executor applies a single rate to all six sites of a layer and refuses anything else loudly."""
+        rates = set()
+        for layer in self.transformer.decoder.layers:
+            for att in layer.attentions:
+                rates.add(float(att.attn_drop_p))
+                rates.add(float(att.dropout_layer.p) if isinstance(att.dropout_layer, nn.Dropout) else 0.0)
+                if float(att.proj_drop.p) != 0.0:
+                    raise _C.PetrHipError('proj_drop != 0 is not implemented (no reference config uses it)')
+            for ffn in layer.ffns:
+                rates.add(float(ffn.layers[0][2].p))
+                rates.add(float(ffn.layers[2].p))
+        if len(rates) != 1:
+            raise _C.PetrHipError(f'the fused executor needs one dropout rate for the whole decoder, got {sorted(rates)}')
+        return rates.pop()
 
     def _launch_backward(self, run, d_cls, d_bbox, want_dfeats, stage_hook=None):
         L = _C.lib()

@@ -115,21 +115,35 @@ def test_head_c5_forward_and_intermediates(pa):
     del L
 
 
-def _oracle_grads(oracle, feats, metas, g_cls, g_box, dtype):
+def _dropout_masks(seed, p, B, Q, L, n_layers=6, heads=8, C=256, F=2048):
+    """The keep masks the kernels use in training mode (site = 8*layer + k, include/petr_hip.h "Dropout"), exported
+    with petr_dropout_mask and laid out as oracle.DecoderLayer.forward(masks=...) wants them."""
+    from petr_amd import ops
+    shapes = {'sp': (B * heads * Q, Q), 'so': (B * Q, C), 'cp': (B * heads * Q, L), 'co': (B * Q, C), 'fh': (B * Q, F),
+              'fo': (B * Q, C)}
+    out = []
+    for l in range(n_layers):
+        m = {k: ops.dropout_mask((seed, 8 * l + i, p), *shp).cpu() for i, (k, shp) in enumerate(shapes.items())}
+        m['scale'] = 1.0 / (1.0 - p)
+        out.append(m)
+    return out
+
+
+def _oracle_grads(oracle, feats, metas, g_cls, g_box, dtype, dropout_masks=None):
     """fwd+bwd of the oracle in `dtype` (float64 = yardstick that separates fp32 noise from disagreement)."""
     import copy
     o = copy.deepcopy(oracle).to(dtype)
     f = feats.to(dtype).clone().requires_grad_(True)
     torch.set_default_dtype(dtype)
     try:
-        out = o([f], metas)
+        out = o([f], metas, dropout_masks=dropout_masks)
         (out['all_cls_scores'] * g_cls.to(dtype)).sum().add((out['all_bbox_preds'] * g_box.to(dtype)).sum()).backward()
     finally:
         torch.set_default_dtype(torch.float32)
     return out, {k: p.grad for k, p in o.named_parameters() if p.grad is not None}, f.grad
 
 
-def _grad_case(pa, B, N, H, W, pad_hw, img_hw, Q, seed, oracle_kw=None, with_time=False):
+def _grad_case(pa, B, N, H, W, pad_hw, img_hw, Q, seed, oracle_kw=None, with_time=False, dropout=None):
     """Gradients vs the float64 oracle.  Two metrics per tensor, both relative to max(|want|_inf, 1e-4*global):
     L2 (tight) and max-abs (loose): a ReLU whose pre-activation sits within 1e-7 of zero flips its mask
     between ANY two fp32 evaluations (the CPU fp32 oracle shows the same O(1e-2) single-element jumps against
@@ -148,7 +162,13 @@ def _grad_case(pa, B, N, H, W, pad_hw, img_hw, Q, seed, oracle_kw=None, with_tim
     g = torch.Generator().manual_seed(seed)
     feats = torch.randn(B, N, 256, H, W, generator=g)
     g_cls, g_box = torch.randn(6, B, Q, 10, generator=g), torch.randn(6, B, Q, 10, generator=g)
-    want, wgrads, wfeat = _oracle_grads(oracle, feats, metas, g_cls, g_box, torch.float64)
+    masks = None
+    if dropout is not None:      # training mode: the oracle gets the very masks the kernels will draw
+        drop_seed, p = dropout
+        head.train()
+        head._dropout_seed_override = drop_seed
+        masks = _dropout_masks(drop_seed, p, B, Q, N * H * W)
+    want, wgrads, wfeat = _oracle_grads(oracle, feats, metas, g_cls, g_box, torch.float64, masks)
     fg = feats.cuda().requires_grad_(True)
     got = head([fg], metas)
     torch.autograd.backward([got['all_cls_scores'], got['all_bbox_preds']], [g_cls.cuda(), g_box.cuda()])
@@ -176,6 +196,30 @@ def _grad_case(pa, B, N, H, W, pad_hw, img_hw, Q, seed, oracle_kw=None, with_tim
 
 def test_head_backward_toy_batch2_masked(pa):
     _grad_case(pa, 2, 2, 4, 6, (128, 192), (100, 150), 16, seed=4)
+
+
+def test_head_training_mode_dropout_toy_batch2_masked(pa):
+    """train(): all six dropout layers of every decoder layer (p = 0.1, the reference's rate), forward AND backward,
+    against the fp64 oracle running the same masks."""
+    head, metas, feats, _ = _grad_case(pa, 2, 2, 4, 6, (128, 192), (100, 150), 16, seed=4, dropout=(987654321, 0.1))
+    assert head._last_dropout == (987654321, 0.1)
+    # another seed is another function; eval() is the dropout-free path again
+    with torch.no_grad():
+        a = head([feats.cuda()], metas)['all_cls_scores']
+        head._dropout_seed_override = 5
+        b = head([feats.cuda()], metas)['all_cls_scores']
+        head._dropout_seed_override = None
+        c = head([feats.cuda()], metas)['all_cls_scores']     # fresh seed from torch's generator
+        head.eval()
+        e1 = head([feats.cuda()], metas)['all_cls_scores']
+        e2 = head([feats.cuda()], metas)['all_cls_scores']
+    assert not torch.equal(a, b) and not torch.equal(b, c) and torch.equal(e1, e2)
+    assert head._last_dropout == (0, 0.0)
+
+
+def test_head_training_mode_dropout_900_queries(pa):
+    """c5 query count and FFN width, L = 6*8*11 = 528 keys (every attention kernel path incl. L-splits)."""
+    _grad_case(pa, 1, 6, 8, 11, (256, 352), (256, 352), 900, seed=6, dropout=(31337, 0.1))
 
 
 def test_head_backward_c5(pa):

@@ -245,3 +245,90 @@ def test_bbox_epilogue(ops):
     want.backward(dout.double())
     dreg, dref = ops.bbox_epilogue_bwd(got, dev(ref.detach().float()), dev(dout), Q, pc)
     assert relerr(dreg, reg.grad) < 1e-5 and relerr(dref, ref.grad) < 1e-4
+
+
+# ------------------------------------------------------------------ dropout (training mode)
+# The kernels draw their masks from a counter-based hash of (seed, site, row, col) (include/petr_hip.h "Dropout"),
+# which cannot equal torch's Philox stream: every test exports the mask with petr_dropout_mask and gives the SAME
+# mask to the fp64 torch restatement.  Scale = 1/(1-p) with p rounded to a 32-bit threshold (relative 1e-9).
+def test_dropout_mask_is_a_fair_deterministic_coin(ops):
+    p = 0.1
+    m0 = ops.dropout_mask((1234, 3, p), 900, 4224)
+    m0b = ops.dropout_mask((1234, 3, p), 900, 4224)
+    m1 = ops.dropout_mask((1234, 4, p), 900, 4224)       # another site
+    m2 = ops.dropout_mask((1235, 3, p), 900, 4224)       # another seed
+    assert torch.equal(m0, m0b)
+    n = m0.numel()
+    sigma = math.sqrt(p * (1 - p) / n)
+    for m in (m0, m1, m2):
+        assert abs((1 - m.float().mean().item()) - p) < 5 * sigma
+    # independent masks agree on a fraction p^2 + (1-p)^2 of the elements
+    for a, b in ((m0, m1), (m0, m2)):
+        agree = (a == b).float().mean().item()
+        assert abs(agree - (p * p + (1 - p) * (1 - p))) < 0.002
+    # no structure along rows / columns (every row and column drops about p)
+    assert (1 - m0.float().mean(1)).sub(p).abs().max().item() < 6 * math.sqrt(p * (1 - p) / 4224)
+    assert (1 - m0.float().mean(0)).sub(p).abs().max().item() < 6 * math.sqrt(p * (1 - p) / 900)
+    assert ops.dropout_mask((7, 0, 0.0), 10, 10).all()
+
+
+def test_linear_relu_dropout(ops):
+    g = torch.Generator().manual_seed(11)
+    x, w, b = torch.randn(900, 256, generator=g), torch.randn(2048, 256, generator=g) * 0.1, torch.randn(2048, generator=g)
+    drop = (99, 44, 0.1)
+    keep = ops.dropout_mask(drop, 900, 2048).cpu()
+    want = torch.relu(x.double() @ w.double().t() + b.double()) * keep / (1 - 0.1)
+    got = ops.linear(dev(x), dev(w), dev(b), relu=True, drop=drop)
+    assert relerr(got, want) < 2e-6
+    assert ((got == 0).cpu() | keep).all()
+
+
+def test_layernorm_dropout_fwd_bwd(ops):
+    g = torch.Generator().manual_seed(6)
+    parts = torch.randn(4, 900, 256, generator=g)
+    res, bias = torch.randn(900, 256, generator=g), torch.randn(256, generator=g)
+    gamma, beta = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    drop = (5, 13, 0.1)
+    keep = ops.dropout_mask(drop, 900, 256).cpu().double() / 0.9
+    f = (parts.double().sum(0) + bias.double()).requires_grad_(True)     # sub-layer output
+    r = res.double().requires_grad_(True)                                 # identity
+    zt = f * keep + r
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    want = torch.nn.functional.layer_norm(zt, (256,), gd, bd, 1e-5)
+    y, z, mean, rstd = ops.layernorm(dev(parts), dev(gamma), dev(beta), bias=dev(bias), residual=dev(res), save_stats=True,
+                                     drop=drop)
+    assert relerr(y, want) < 2e-6 and relerr(z, zt) < 1e-6
+    dy = torch.randn(900, 256, generator=g)
+    want.backward(dy.double())
+    dz, dgm, dbt, dzd = ops.layernorm_bwd(z, mean, rstd, dev(gamma), dev(dy), drop=drop)
+    assert relerr(dz, r.grad) < 1e-5 and relerr(dzd, f.grad) < 1e-5
+    assert relerr(dgm, gd.grad) < 1e-5 and relerr(dbt, bd.grad) < 1e-5
+
+
+@pytest.mark.parametrize('B,H,Q,L,split,masked', [(1, 8, 900, 1000, 0, False), (2, 2, 70, 333, 3, True), (1, 8, 130, 4224, 8, False)])
+def test_mha_dropout_fwd_bwd(ops, B, H, Q, L, split, masked):
+    g = torch.Generator().manual_seed(Q * 7 + L)
+    q, k, v = (torch.randn(B, H, n, 32, generator=g).double().requires_grad_(True) for n in (Q, L, L))
+    do = torch.randn(B, H, Q, 32, generator=g)
+    kpm = None
+    if masked:
+        kpm = torch.zeros(B, L, dtype=torch.bool)
+        kpm[:, L - L // 4:] = True
+    p = 0.1
+    drop = (2024, 2, p)
+    keep = ops.dropout_mask(drop, B * H * Q, L).cpu().view(B, H, Q, L)
+    s = torch.einsum('bhqd,bhkd->bhqk', q, k) * 32 ** -0.5
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :], float('-inf'))
+    want = torch.einsum('bhqk,bhkd->bhqd', torch.softmax(s, -1) * keep / (1 - p), v)
+    want.backward(do.double())
+    qf, kf, vf = (dev(t.detach().float()) for t in (q, k, v))
+    o, lse = ops.mha_fwd(qf, kf, vf, dev(kpm) if masked else None, n_split=split, drop=drop)
+    assert relerr(o, want) < 2e-6
+    assert relerr(lse, torch.logsumexp(s, -1)) < 2e-6                     # the LSE is the undropped softmax's
+    dq, dk, dv = ops.mha_bwd(qf, kf, vf, o, dev(do), lse, dev(kpm) if masked else None, drop=drop)
+    assert relerr(dq, q.grad) < 1e-5 and relerr(dk, k.grad) < 1e-5 and relerr(dv, v.grad) < 1e-5
+    # p = 0 is the dropout-free kernel
+    o0, _ = ops.mha_fwd(qf, kf, vf, dev(kpm) if masked else None, n_split=split, drop=(2024, 2, 0.0))
+    o1, _ = ops.mha_fwd(qf, kf, vf, dev(kpm) if masked else None, n_split=split)
+    assert torch.equal(o0, o1)

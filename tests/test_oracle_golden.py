@@ -125,3 +125,19 @@ def test_state_dict_keys(golden_dir):
     assert got == want
     assert 'transformer.decoder.layers.0.ffns.0.layers.0.0.weight' in got
     assert 'cls_branches.5.6.bias' in got and 'transformer.decoder.post_norm.weight' in got
+
+
+def test_oracle_supplied_dropout_masks_reduce_to_eval_mode():
+    """The oracle's training-mode path with SUPPLIED masks (used to check the HIP kernels' dropout) writes
+    torch.nn.MultiheadAttention out by hand; with all-keep masks and scale 1 it must reproduce the module path."""
+    o = O.seeded_head(2, 1234, num_query=16).eval()
+    metas = O.synthetic_img_metas(2, 2, (128, 192), (100, 150), seed=1)
+    f = torch.randn(2, 2, 256, 4, 6, generator=torch.Generator().manual_seed(0))
+    B, Q, L, H, C, F = 2, 16, 48, 8, 256, 2048
+    ones = lambda *s: torch.ones(*s, dtype=torch.bool)   # noqa: E731
+    masks = [{'sp': ones(B * H * Q, Q), 'so': ones(B * Q, C), 'cp': ones(B * H * Q, L), 'co': ones(B * Q, C),
+              'fh': ones(B * Q, F), 'fo': ones(B * Q, C), 'scale': 1.0} for _ in range(6)]
+    with torch.no_grad():
+        a, b = o([f], metas), o([f], metas, dropout_masks=masks)
+    assert (a['all_cls_scores'] - b['all_cls_scores']).abs().max() < 1e-5
+    assert (a['all_bbox_preds'] - b['all_bbox_preds']).abs().max() < 1e-5

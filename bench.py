@@ -69,8 +69,9 @@ def synthetic_metas(batch, n_views, pad_hw, seed):
     return metas
 
 
-def cpu_baseline(workload, batch, num_query, budget_s=25.0):
-    """The oracle (CPU restatement of the reference's PyTorch path) on the host cores: fwd+bwd and fwd-only."""
+def cpu_baseline(workload, batch, num_query, budget_s=25.0, train=True):
+    """The oracle (CPU restatement of the reference's PyTorch path) on the host cores: fwd+bwd (training mode:
+    torch's own dropouts active, like the GPU leg) and fwd-only (eval mode)."""
     from oracle import petr_oracle as O
     n, h, w, ph, pw, _ = WORKLOADS[workload]
     # the box's CPU share, not the host's core count (oversubscribed OpenMP threads crawl)
@@ -90,6 +91,7 @@ def cpu_baseline(workload, batch, num_query, budget_s=25.0):
         out = head([feats], metas)
         torch.autograd.backward([out['all_cls_scores'], out['all_bbox_preds']], [g_cls, g_box])
 
+    head.train(train)
     step()   # warm-up
     log(f'cpu baseline: warm-up done, {torch.get_num_threads()} threads')
     t0 = time.perf_counter()
@@ -98,6 +100,7 @@ def cpu_baseline(workload, batch, num_query, budget_s=25.0):
         step()
         n_steps += 1
     dt = (time.perf_counter() - t0) / n_steps
+    head.eval()
     with torch.no_grad():
         head([feats], metas)
         t1 = time.perf_counter()
@@ -107,7 +110,8 @@ def cpu_baseline(workload, batch, num_query, budget_s=25.0):
             n_f += 1
         dtf = (time.perf_counter() - t1) / n_f
     return {'value': round(batch / dt, 4), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{n_steps} fwd+bwd steps (and {n_f} fwd-only) of the same workload, batch {batch}, fp32, eval mode',
+            'sample': f'{n_steps} fwd+bwd steps in {"training" if train else "eval"} mode (and {n_f} eval-mode forwards) of '
+                      f'the same workload, batch {batch}, fp32',
             'fwd_value': round(batch / dtf, 4), 'ms_per_step': round(dt * 1e3, 2), 'fwd_ms': round(dtf * 1e3, 2)}
 
 
@@ -121,6 +125,8 @@ def main():
     ap.add_argument('--queries', type=int, default=900)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--fwd-only', action='store_true', help='time the forward only (diagnostic; not the metric)')
+    ap.add_argument('--eval-mode', action='store_true',
+                    help='time fwd+bwd with the dropouts off (diagnostic; the metric is the training step, dropout 0.1)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -148,7 +154,8 @@ def main():
     torch.manual_seed(0)                     # identical weights on every rank (reference init rules)
     head = petr_amd.build_head(petr_amd.petr_head_cfg(num_query=Q))
     head.init_weights()
-    head = head.to(dev).eval()               # eval: the reference's dropouts are identities
+    # the metric is the TRAINING step: train() = the reference's dropouts (p = 0.1, six per decoder layer) are active
+    head = head.to(dev).train(not (args.eval_mode or args.fwd_only))
     metas = synthetic_metas(B, n, (ph, pw), seed=rank * 1000)
     g = torch.Generator().manual_seed(1234 + rank)           # rank-offset seed: every rank has its own samples
     feats = torch.randn(B, n, 256, h, w, generator=g).to(dev).requires_grad_(not args.fwd_only)
@@ -192,7 +199,9 @@ def main():
         log(f'timed region done: {elapsed / args.steps * 1e3:.3f} ms/step')
     # ---- forward-only rate (for the ">= 10x the host-CPU forward" target), same steady state ----
     fwd_ms = None
+    was_training = head.training
     if not args.fwd_only:
+        head.eval()                      # inference forward
         with torch.no_grad():
             for _ in range(3):
                 head([feats], metas)
@@ -202,6 +211,7 @@ def main():
                 head([feats], metas)
             torch.cuda.synchronize()
             fwd_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        head.train(was_training)
 
     # ---- roofline leg: HIP events around the tagged kernels inside real steps (rank 0) ----
     roofline = None
@@ -240,6 +250,23 @@ def main():
                         'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                         'flops_per_launch': flops, 'mean_launch_us': us}
+        if roofline is not None and was_training:
+            # the same kernel without the dropout of the probabilities (eval-mode / inference forwards)
+            head.eval()
+            _C.check(L.petr_prof_begin(prof_steps * 64), 'petr_prof_begin')
+            with torch.no_grad():
+                for _ in range(prof_steps):
+                    head([feats], metas)
+            torch.cuda.synchronize()
+            _C.check(L.petr_prof_end(ms, tags, cap, C.byref(cnt)), 'petr_prof_end')
+            head.train(was_training)
+            v = [ms[i] for i in range(cnt.value) if tags[i] == 17]
+            if v:
+                us_e = sum(v) / len(v) * 1e3
+                ach_e = roofline['flops_per_launch'] / (us_e * 1e-6) / 1e12
+                roofline['timed_variant'] = 'training mode: dropout (p = 0.1) of the attention probabilities inside the kernel'
+                roofline['inference_variant'] = {'mean_launch_us': round(us_e, 2), 'achieved': round(ach_e, 2),
+                                                 'frac': round(ach_e / FP32_MFMA_PEAK_TFLOPS, 4)}
         if 'mha_bwd_cross' in kernels:
             us = kernels['mha_bwd_cross']['mean_us']
             kernels['mha_bwd_cross']['tflops'] = round(10.0 * B * Q * Ltok * 256 / (us * 1e-6) / 1e12, 2)
@@ -252,7 +279,7 @@ def main():
         log('kernel timing done')
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.workload, B, Q)
+        cpu = cpu_baseline(args.workload, B, Q, train=was_training)
 
     if rank == 0:
         samples = world * B * args.steps
@@ -264,7 +291,9 @@ def main():
             'config': {'workload': f'{desc}, {Q} queries, 6 decoder layers, fp32 (BASELINE configs[1])'
                        if args.workload == 'c5' else f'{desc}, {Q} queries, 6 decoder layers, fp32',
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}',
-                       'dropout': 'off (eval mode, as the CPU baseline)'},
+                       'dropout': ('0.1 at all six sites of every decoder layer (training mode; the CPU baseline too)'
+                                   if was_training else 'off (eval mode, as the CPU baseline)'),
+                       'fwd_only_leg': 'eval mode (inference forward)'},
             'fwd_ms': round(fwd_ms, 4) if fwd_ms is not None else None,
             'fwd_samples_per_s': round(B / (fwd_ms * 1e-3), 2) if fwd_ms else None,
             'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu,

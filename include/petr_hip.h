@@ -88,7 +88,8 @@ int petr_posemb3d_bwd(const float* pos, const float* dim_t, const float* dout, f
  * Dropout (training mode; reference: attn_drop 0.1 inside nn.MultiheadAttention, the residual
  * dropout_layer of both attentions models/utils/petr_transformer.py:258-265,367, and mmcv FFN's
  * ffn_drop after each of its two Linear layers).
- *     keep(row, col) = hash32(seed, site, row, col) >= p * 2^32 ; kept values are scaled by 1/(1-p).
+ *     keep(row, col) = hash16(seed, site, row, col) >= round(p * 2^16) ; kept values are scaled by the matching
+ *     1/(1-p) (p = 0.1 is realised as 6554/65536 = 0.100006).
  * Counter-based and stateless: a backward call given the same (seed, site) regenerates the forward's
  * mask, nothing is stored.  `site` separates the dropout layers of one forward (the executor uses
  * 8*layer + {0 self-attn P, 1 self-attn out, 2 cross-attn P, 3 cross-attn out, 4 FFN hidden, 5 FFN out}).

@@ -62,10 +62,15 @@ struct Lanes {
   }
 };
 
-// ---- dropout (petr_hip.h "Dropout"): host-derived keys + the two device hashes every kernel shares ----
+// ---- dropout (petr_hip.h "Dropout"): host-derived keys + the device hashes every kernel shares ----
+// One 32-bit hash serves the two columns (2j, 2j+1) of a row: its low / high 16 bits are compared with a 16-bit
+// threshold, so p is realised as round(p * 65536) / 65536 (0.1 -> 0.100006) and kept values are scaled by the
+// matching 1/(1-p).  The hash uses full-rate instructions only (xor, shift, 24-bit multiply-add): on gfx950 the
+// f32 MFMA shares the vector issue port, so every VALU cycle spent here is paid in full, and v_mul_lo_u32 is
+// quarter rate.
 struct DropDev {
-  uint32_t k0, k1, thr;   // thr = p * 2^32 ; thr == 0: disabled
-  float scale;            // 1 / (1 - thr / 2^32)
+  uint32_t k0, k1, thr;   // thr = p * 2^16 ; thr == 0: disabled
+  float scale;            // 1 / (1 - thr / 2^16)
 };
 inline DropDev make_drop(const petr_dropout& d) {
   DropDev r = {0u, 0u, 0u, 1.f};
@@ -76,24 +81,34 @@ inline DropDev make_drop(const petr_dropout& d) {
   z ^= z >> 31;
   r.k0 = (uint32_t)z;
   r.k1 = (uint32_t)(z >> 32);
-  const double t = (double)d.p * 4294967296.0;
-  r.thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+  const double t = (double)d.p * 65536.0 + 0.5;
+  r.thr = t >= 65535.0 ? 65535u : (uint32_t)t;
   if (r.thr == 0u) r.thr = 1u;
-  r.scale = (float)(1.0 / (1.0 - (double)r.thr / 4294967296.0));
+  r.scale = (float)(1.0 / (1.0 - (double)r.thr / 65536.0));
   return r;
 }
+// per row (computed once per row / lane, so 32-bit multiplies are fine here)
 __device__ __forceinline__ uint32_t drop_row_key(const DropDev& d, uint32_t row) {
   uint32_t x = (row ^ d.k0) * 0x9E3779B1u;
   x ^= x >> 15;
   x = (x + d.k1) * 0x85EBCA6Bu;
   x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+// hash of the column pair j = col >> 1 of a row: 7 full-rate VALU instructions (statistics: tests/test_ops_gpu.py)
+__device__ __forceinline__ uint32_t drop_pair_hash(uint32_t row_key, uint32_t pair) {
+  uint32_t x = row_key ^ pair;
+  x = __umul24(x, 0xC2B2AEu) + (row_key >> 7);   // v_mad_u32_u24: low 24 bits of x times a 24-bit odd constant
+  x ^= x >> 13;
+  x = __umul24(x, 0x85EBCBu) + row_key;
+  x ^= x >> 16;
   return x;
 }
 __device__ __forceinline__ bool drop_keep(uint32_t row_key, uint32_t col, uint32_t thr) {
-  uint32_t x = (row_key ^ col) * 0x9E3779B1u;
-  x ^= x >> 16;
-  x *= 0x85EBCA6Bu;
-  return x >= thr;
+  const uint32_t hsh = drop_pair_hash(row_key, col >> 1);
+  return ((col & 1u) ? (hsh >> 16) : (hsh & 0xFFFFu)) >= thr;
 }
 
 #define PETR_CHECK(cond, code, ...)     \

@@ -306,9 +306,13 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
       l_run += xhalf_sum(acc.x + acc.y);
     }
     if (DROP) {
+      // accumulator registers (2i, 2i+1) hold the keys (2j, 2j+1) of one column pair: one hash per two probabilities
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        S[r] = drop_keep(drop_rk, (uint32_t)(k0 + kh * 32 + mfma32_row(r, h)), p.drop.thr) ? S[r] : 0.f;
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t hsh = drop_pair_hash(drop_rk, (uint32_t)(k0 + kh * 32 + mfma32_row(2 * i, h)) >> 1);
+        S[2 * i] = (hsh & 0xFFFFu) >= p.drop.thr ? S[2 * i] : 0.f;
+        S[2 * i + 1] = (hsh >> 16) >= p.drop.thr ? S[2 * i + 1] : 0.f;
+      }
     }
 #endif
 #pragma unroll

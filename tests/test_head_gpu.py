@@ -124,7 +124,7 @@ def _dropout_masks(seed, p, B, Q, L, n_layers=6, heads=8, C=256, F=2048):
     out = []
     for l in range(n_layers):
         m = {k: ops.dropout_mask((seed, 8 * l + i, p), *shp).cpu() for i, (k, shp) in enumerate(shapes.items())}
-        m['scale'] = 1.0 / (1.0 - p)
+        m['scale'] = 1.0 / (1.0 - round(p * 65536) / 65536)    # p is realised on a 16-bit grid
         out.append(m)
     return out
 

@@ -270,6 +270,15 @@ def test_dropout_mask_is_a_fair_deterministic_coin(ops):
     assert (1 - m0.float().mean(1)).sub(p).abs().max().item() < 6 * math.sqrt(p * (1 - p) / 4224)
     assert (1 - m0.float().mean(0)).sub(p).abs().max().item() < 6 * math.sqrt(p * (1 - p) / 900)
     assert ops.dropout_mask((7, 0, 0.0), 10, 10).all()
+    # neighbours are uncorrelated: the two columns that share one hash, adjacent pairs, adjacent rows, and the
+    # (row+1, col+1) diagonal all agree on p^2 + (1-p)^2 of the elements
+    f = m0.float()
+    want = p * p + (1 - p) * (1 - p)
+    for a, b in ((f[:, 0::2], f[:, 1::2]), (f[:, 1:-1:2], f[:, 2::2]), (f[:-1], f[1:]), (f[:-1, :-1], f[1:, 1:]),
+                 (f[:, :-64], f[:, 64:]), (f[:-32], f[32:])):
+        assert abs((a == b).float().mean().item() - want) < 0.002
+    # realised rate: round(p * 2^16) / 2^16
+    assert abs((1 - f.mean().item()) - 6554 / 65536) < 5 * sigma
 
 
 def test_linear_relu_dropout(ops):
@@ -277,7 +286,7 @@ def test_linear_relu_dropout(ops):
     x, w, b = torch.randn(900, 256, generator=g), torch.randn(2048, 256, generator=g) * 0.1, torch.randn(2048, generator=g)
     drop = (99, 44, 0.1)
     keep = ops.dropout_mask(drop, 900, 2048).cpu()
-    want = torch.relu(x.double() @ w.double().t() + b.double()) * keep / (1 - 0.1)
+    want = torch.relu(x.double() @ w.double().t() + b.double()) * keep / (1 - 6554 / 65536)
     got = ops.linear(dev(x), dev(w), dev(b), relu=True, drop=drop)
     assert relerr(got, want) < 2e-6
     assert ((got == 0).cpu() | keep).all()
@@ -289,7 +298,7 @@ def test_layernorm_dropout_fwd_bwd(ops):
     res, bias = torch.randn(900, 256, generator=g), torch.randn(256, generator=g)
     gamma, beta = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
     drop = (5, 13, 0.1)
-    keep = ops.dropout_mask(drop, 900, 256).cpu().double() / 0.9
+    keep = ops.dropout_mask(drop, 900, 256).cpu().double() / (1 - 6554 / 65536)
     f = (parts.double().sum(0) + bias.double()).requires_grad_(True)     # sub-layer output
     r = res.double().requires_grad_(True)                                 # identity
     zt = f * keep + r
@@ -314,8 +323,8 @@ def test_mha_dropout_fwd_bwd(ops, B, H, Q, L, split, masked):
     if masked:
         kpm = torch.zeros(B, L, dtype=torch.bool)
         kpm[:, L - L // 4:] = True
-    p = 0.1
-    drop = (2024, 2, p)
+    p = 6554 / 65536          # how the kernels realise 0.1
+    drop = (2024, 2, 0.1)
     keep = ops.dropout_mask(drop, B * H * Q, L).cpu().view(B, H, Q, L)
     s = torch.einsum('bhqd,bhkd->bhqk', q, k) * 32 ** -0.5
     if kpm is not None:

@@ -289,6 +289,46 @@ int petr_reduce_partials(const float* x, int n_partials, long stride, const floa
 int petr_reduce_batch(const float* x, int B, long rows, int C, float* out, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training loss on the device: PETRHead.loss / loss_single / get_targets /
+ * _get_target_single (models/dense_heads/petr_head.py:470-728) with HungarianAssigner3D.assign
+ * (core/bbox/assigners/hungarian_assigner_3d.py:61-143; the reference goes device -> CPU scipy ->
+ * device once per level and sample), FocalLossCost + BBox3DL1Cost (core/bbox/match_costs/
+ * match_cost.py:6-27), normalize_bbox (core/bbox/util.py:38-58), mmdet FocalLoss / L1Loss.
+ *     cls [NL,B,Q,NC] logits, box [NL,B,Q,CS>=10]; gt_boxes [Gtot,9] = (gravity centre xyz, w, l, h,
+ *     yaw, vx, vy) of all samples back to back (what petr_head.py:697-699 builds), gt_labels [Gtot],
+ *     gt_offsets [B+1] (device ints), Gmax = largest per-sample count (<= Q), num_pos = sum_b min(G_b,Q).
+ *     losses [NL,2] = (loss_cls, loss_bbox) per decoder level (level NL-1 is 'loss_cls'/'loss_bbox',
+ *     level i < NL-1 is 'd{i}.loss_*'); d_cls / d_box (optional) = gradient of the SUM of all 2*NL losses
+ *     (level l's losses depend on level l's predictions only, so a caller with other output weights
+ *     scales the slices); assigned [NL,B,Q] = 0 background / k = ground truth k-1 of the sample.
+ *     sync_cls_avg_factor / multi-process reduce_mean are the caller's (single-process semantics here). */
+typedef struct {
+  const float* cls; const float* box;
+  const float* gt_boxes; const int64_t* gt_labels; const int* gt_offsets;
+  int NL, B, Q, NC, CS, Gtot, Gmax; long num_pos;
+  float cls_weight, bbox_weight, alpha, gamma, bg_cls_weight;   /* c5: 2.0, 0.25, 0.25, 2.0, 0.0 */
+  float code_weights[10];
+  float* losses; float* d_cls; float* d_box; int* assigned;
+  void* ws; size_t ws_bytes;
+} petr_loss_args;
+size_t petr_loss_workspace_bytes(int NL, int B, int Q, int Gtot);
+int petr_loss_fwd_bwd(const petr_loss_args* a, void* stream);
+
+/* Box part of NMSFreeCoder.decode_single + get_bboxes (core/bbox/coders/nms_free_coder.py:62-97,
+ * core/bbox/util.py:60-87, petr_head.py:745): for the n top-k entries `index` (into the flattened
+ * [Q*num_classes] scores, as torch.topk returns them) of ONE sample: boxes [n,9] = denormalised box (z at
+ * the gravity centre, or moved to the bottom centre), labels [n] = index % num_classes, keep [n] = centre
+ * inside post_center_range (and score > score_threshold if > 0).                                  */
+typedef struct {
+  const float* bbox_preds; const int64_t* index; const float* scores;
+  float* boxes; int64_t* labels; uint8_t* keep;
+  int n, num_classes, code;
+  float post_center_range[6]; float score_threshold;
+  int bottom_center;   /* 1: z = gravity centre - h/2 (get_bboxes); 0: gravity centre (NMSFreeCoder.decode) */
+} petr_decode_args;
+int petr_decode_boxes(const petr_decode_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Whole-path executor: PETRHead.forward (petr_head.py:366-468) / PETRv2Head.forward
  * (petrv2_head.py:429-540) and its gradient as ONE call each, all kernels enqueued on `stream`.
  * Parameters live in one flat fp32 buffer; `petr_head_layout` reports offsets (in floats) of every

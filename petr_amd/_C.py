@@ -111,6 +111,24 @@ class BboxArgs(C.Structure):
                        ('pc_range', C.c_float * 6), ('time_div', C.c_float), ('eps', C.c_float))
 
 
+class LossArgs(C.Structure):         # petr_loss_args
+    _fields_ = _fields(('cls', C.c_void_p), ('box', C.c_void_p), ('gt_boxes', C.c_void_p), ('gt_labels', C.c_void_p),
+                       ('gt_offsets', C.c_void_p),
+                       ('NL', C.c_int), ('B', C.c_int), ('Q', C.c_int), ('NC', C.c_int), ('CS', C.c_int),
+                       ('Gtot', C.c_int), ('Gmax', C.c_int), ('num_pos', C.c_long),
+                       ('cls_weight', C.c_float), ('bbox_weight', C.c_float), ('alpha', C.c_float), ('gamma', C.c_float),
+                       ('bg_cls_weight', C.c_float), ('code_weights', C.c_float * 10),
+                       ('losses', C.c_void_p), ('d_cls', C.c_void_p), ('d_box', C.c_void_p), ('assigned', C.c_void_p),
+                       ('ws', C.c_void_p), ('ws_bytes', C.c_size_t))
+
+
+class DecodeArgs(C.Structure):       # petr_decode_args
+    _fields_ = _fields(('bbox_preds', C.c_void_p), ('index', C.c_void_p), ('scores', C.c_void_p), ('boxes', C.c_void_p),
+                       ('labels', C.c_void_p), ('keep', C.c_void_p), ('n', C.c_int), ('num_classes', C.c_int),
+                       ('code', C.c_int), ('post_center_range', C.c_float * 6), ('score_threshold', C.c_float),
+                       ('bottom_center', C.c_int))
+
+
 class HeadConfig(C.Structure):
     _fields_ = _fields(
         ('B', C.c_int), ('N', C.c_int), ('C_in', C.c_int), ('H', C.c_int), ('W', C.c_int),
@@ -203,6 +221,8 @@ def lib():
     L.petr_head_bwd_stage_range.argtypes = [C.POINTER(HeadConfig), C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     L.petr_head_bwd.argtypes = [C.POINTER(HeadConfig), C.POINTER(HeadIO), C.POINTER(HeadGrads), C.c_int, C.c_int,
                                 C.c_void_p]
+    L.petr_loss_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.petr_loss_workspace_bytes.restype = C.c_size_t
     L.petr_head_ws_view.argtypes = [C.POINTER(HeadConfig), C.c_char_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     _lib = L
     return L
@@ -216,7 +236,8 @@ EXPORTS = [
     'petr_mha_bwd', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows', 'petr_gate_fwd', 'petr_gate_bwd', 'petr_prof_begin', 'petr_prof_end',
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
-    'petr_ctx_create', 'petr_ctx_destroy', 'petr_dropout_mask',
+    'petr_ctx_create', 'petr_ctx_destroy', 'petr_dropout_mask', 'petr_loss_workspace_bytes', 'petr_loss_fwd_bwd',
+    'petr_decode_boxes',
 ]
 
 

@@ -1,0 +1,158 @@
+"""Host side of the two steps right behind the hot path: the training loss with Hungarian
+matching and the NMS-free decode, both as ONE C-ABI call into libpetr_hip.so (petr_amd/csrc/loss.hip).
+
+Mirrors (reference projects/mmdet3d_plugin/): ``PETRHead.loss`` / ``get_bboxes``
+(models/dense_heads/petr_head.py:646-751), ``HungarianAssigner3D`` (core/bbox/assigners/hungarian_assigner_3d.py),
+``NMSFreeCoder`` (core/bbox/coders/nms_free_coder.py), ``normalize_bbox`` / ``denormalize_bbox`` (core/bbox/util.py).
+torch is plumbing here (tensors, autograd node, ``topk``); the arithmetic — cost matrix, assignment, focal / L1
+loss, their gradients, box denormalisation — runs in the HIP kernels.
+"""
+import ctypes as C
+
+import torch
+
+from . import _C
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class LossConfig:
+    """Hyper-parameters the reference spreads over loss_cls / loss_bbox / train_cfg.assigner / code_weights
+    (configs/petr/petr_r50dcn_gridmask_c5.py:45-110); the assigner's cost weights must equal the loss weights
+    (asserted by the reference, petr_head.py:149-156)."""
+
+    def __init__(self, num_classes=10, code_weights=(1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2), cls_weight=2.0,
+                 bbox_weight=0.25, alpha=0.25, gamma=2.0, bg_cls_weight=0.0):
+        self.num_classes = num_classes
+        self.code_weights = [float(v) for v in code_weights] + [0.0] * (10 - len(code_weights))
+        self.cls_weight, self.bbox_weight, self.alpha, self.gamma = cls_weight, bbox_weight, alpha, gamma
+        self.bg_cls_weight = bg_cls_weight
+
+
+class _LossFn(torch.autograd.Function):
+    """[NL, 2] losses; the kernels already produced the gradients of their sum, backward only weights the level
+    slices by the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, cls, box, gt_boxes, gt_labels, gt_offsets, counts, cfg):
+        L = _C.lib()
+        NL, B, Q, NC = cls.shape
+        CS = box.shape[-1]
+        cls, box = cls.contiguous().float(), box.contiguous().float()
+        gtot, gmax = int(sum(counts)), int(max(counts) if counts else 0)
+        losses = torch.empty((NL, 2), dtype=torch.float32, device=cls.device)
+        d_cls, d_box = torch.empty_like(cls), torch.empty_like(box)
+        assigned = torch.empty((NL, B, Q), dtype=torch.int32, device=cls.device)
+        nbytes = L.petr_loss_workspace_bytes(NL, B, Q, gtot)
+        ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=cls.device)
+        a = _C.LossArgs()
+        a.cls, a.box = cls.data_ptr(), box.data_ptr()
+        a.gt_boxes = gt_boxes.data_ptr() if gtot else None
+        a.gt_labels = gt_labels.data_ptr() if gtot else None
+        a.gt_offsets = gt_offsets.data_ptr()
+        a.NL, a.B, a.Q, a.NC, a.CS, a.Gtot, a.Gmax = NL, B, Q, NC, CS, gtot, gmax
+        a.num_pos = int(sum(min(c, Q) for c in counts))
+        a.cls_weight, a.bbox_weight, a.alpha, a.gamma = cfg.cls_weight, cfg.bbox_weight, cfg.alpha, cfg.gamma
+        a.bg_cls_weight = cfg.bg_cls_weight
+        a.code_weights = (C.c_float * 10)(*cfg.code_weights[:10])
+        a.losses, a.d_cls, a.d_box, a.assigned = losses.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), assigned.data_ptr()
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 8
+        _C.check(L.petr_loss_fwd_bwd(C.byref(a), _stream()), 'petr_loss_fwd_bwd')
+        ctx.save_for_backward(d_cls, d_box)
+        ctx.mark_non_differentiable(assigned)
+        return losses, assigned
+
+    @staticmethod
+    def backward(ctx, g_losses, _g_assigned):
+        d_cls, d_box = ctx.saved_tensors
+        g = g_losses.to(d_cls.dtype)
+        return d_cls * g[:, 0].view(-1, 1, 1, 1), d_box * g[:, 1].view(-1, 1, 1, 1), None, None, None, None, None
+
+
+def _gt_tensor(boxes, device):
+    """petr_head.py:697-699: ``cat(gravity_center, tensor[:, 3:])`` for box objects; plain [G, 9] tensors pass."""
+    if hasattr(boxes, 'gravity_center') and hasattr(boxes, 'tensor'):
+        boxes = torch.cat((boxes.gravity_center, boxes.tensor[:, 3:]), dim=1)
+    return boxes.to(device=device, dtype=torch.float32)
+
+
+def head_loss(cfg, gt_bboxes_list, gt_labels_list, preds_dicts, return_assignment=False):
+    """``PETRHead.loss`` (petr_head.py:646-728): dict with 'loss_cls', 'loss_bbox' (last level) and
+    'd{i}.loss_cls', 'd{i}.loss_bbox' (earlier levels)."""
+    all_cls, all_box = preds_dicts['all_cls_scores'], preds_dicts['all_bbox_preds']
+    assert preds_dicts.get('enc_cls_scores') is None, 'two-stage (enc_*) outputs are not produced by PETRHead'
+    if not all_cls.is_cuda:
+        raise _C.PetrHipError('PETRHead.loss (petr_amd) runs on the GPU only; there is no CPU fallback')
+    dev = all_cls.device
+    B = all_cls.shape[1]
+    assert len(gt_bboxes_list) == B and len(gt_labels_list) == B
+    boxes = [_gt_tensor(b, dev) for b in gt_bboxes_list]
+    counts = [int(b.shape[0]) for b in boxes]
+    for b in boxes:
+        assert b.dim() == 2 and b.shape[1] == 9, 'ground-truth boxes are [G, 9] (centre, dims, yaw, vx, vy)'
+    gt_boxes = torch.cat(boxes, 0).contiguous() if sum(counts) else torch.zeros((0, 9), device=dev)
+    gt_labels = torch.cat([t.to(dev).long() for t in gt_labels_list], 0).contiguous() if sum(counts) else \
+        torch.zeros((0,), dtype=torch.long, device=dev)
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    gt_offsets = torch.tensor(offs, dtype=torch.int32).to(dev)
+    losses, assigned = _LossFn.apply(all_cls, all_box, gt_boxes, gt_labels, gt_offsets, counts, cfg)
+    out = {}
+    n = all_cls.shape[0]
+    out['loss_cls'], out['loss_bbox'] = losses[n - 1, 0], losses[n - 1, 1]
+    for i in range(n - 1):
+        out[f'd{i}.loss_cls'], out[f'd{i}.loss_bbox'] = losses[i, 0], losses[i, 1]
+    return (out, assigned) if return_assignment else out
+
+
+class NMSFreeCoder:
+    """core/bbox/coders/nms_free_coder.py:16-120."""
+
+    def __init__(self, pc_range, voxel_size=None, post_center_range=None, max_num=100, score_threshold=None,
+                 num_classes=10, **kwargs):
+        self.pc_range, self.voxel_size, self.post_center_range = pc_range, voxel_size, post_center_range
+        self.max_num, self.score_threshold, self.num_classes = max_num, score_threshold, num_classes
+
+    def encode(self):
+        pass
+
+    def decode_single(self, cls_scores, bbox_preds, bottom_center=False):
+        if self.post_center_range is None:
+            raise NotImplementedError('Need to reorganize output as a batch, only support post_center_range is not None for now!')
+        L = _C.lib()
+        scores, idx = cls_scores.sigmoid().view(-1).topk(self.max_num)      # selection: torch (plumbing)
+        n = idx.numel()
+        bbox_preds = bbox_preds.contiguous().float()
+        boxes = torch.empty((n, 9), dtype=torch.float32, device=scores.device)
+        labels = torch.empty((n,), dtype=torch.long, device=scores.device)
+        keep = torch.empty((n,), dtype=torch.uint8, device=scores.device)
+        a = _C.DecodeArgs(_ptr(bbox_preds), _ptr(idx), _ptr(scores.contiguous()), _ptr(boxes), _ptr(labels), _ptr(keep), n,
+                          self.num_classes, bbox_preds.shape[-1], (C.c_float * 6)(*[float(v) for v in self.post_center_range]),
+                          float(self.score_threshold) if self.score_threshold else 0.0, int(bottom_center))
+        _C.check(L.petr_decode_boxes(C.byref(a), _stream()), 'petr_decode_boxes')
+        mask = keep.bool()
+        return {'bboxes': boxes[mask], 'scores': scores[mask], 'labels': labels[mask]}
+
+    def decode(self, preds_dicts, bottom_center=False):
+        cls, box = preds_dicts['all_cls_scores'][-1], preds_dicts['all_bbox_preds'][-1]
+        return [self.decode_single(cls[i], box[i], bottom_center) for i in range(cls.size(0))]
+
+
+def get_bboxes(coder, preds_dicts, img_metas, rescale=False):
+    """``PETRHead.get_bboxes`` (petr_head.py:730-751): [boxes, scores, labels] per sample, boxes wrapped by
+    ``img_metas[i]['box_type_3d']`` when the caller provides it (mmdet3d's LiDARInstance3DBoxes)."""
+    ret = []
+    for i, p in enumerate(coder.decode(preds_dicts, bottom_center=True)):
+        boxes = p['bboxes']
+        wrap = img_metas[i].get('box_type_3d') if img_metas is not None and i < len(img_metas) else None
+        if wrap is not None:
+            boxes = wrap(boxes, boxes.size(-1))
+        ret.append([boxes, p['scores'], p['labels']])
+    return ret

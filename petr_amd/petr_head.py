@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _C, ops
+from . import _C, losses, ops
 from .positional_encoding import sine_dim_t
 from .registry import build_positional_encoding, build_transformer, register
 
@@ -510,11 +510,38 @@ class PETRHead(nn.Module):
         return pe, cmask
 
     # ------------------------------------------------------------------ §8(f) "next" rows
-    def loss(self, *args, **kwargs):
-        raise NotImplementedError('PETRHead.loss (Hungarian matching + focal/L1) is SURVEY §8(f) rank 1: not built yet')
+    def _loss_config(self):
+        lc, lb = self.loss_cfg.get('loss_cls') or {}, self.loss_cfg.get('loss_bbox') or {}
+        assert lc.get('type', 'FocalLoss') == 'FocalLoss' and lc.get('use_sigmoid', True), \
+            'the device loss implements the sigmoid FocalLoss of every reference config'
+        assert lb.get('type', 'L1Loss') == 'L1Loss'
+        cls_w, box_w = float(lc.get('loss_weight', 2.0)), float(lb.get('loss_weight', 0.25))
+        assigner = (self.train_cfg or {}).get('assigner') if isinstance(self.train_cfg, dict) else None
+        if assigner is not None:     # petr_head.py:149-156
+            assert cls_w == assigner['cls_cost']['weight'], \
+                'The classification weight for loss and matcher should be exactly the same.'
+            assert box_w == assigner['reg_cost']['weight'], \
+                'The regression L1 weight for loss and matcher should be exactly the same.'
+        return losses.LossConfig(self.num_classes, self.code_weights.detach().cpu().tolist(), cls_w, box_w,
+                                 float(lc.get('alpha', 0.25)), float(lc.get('gamma', 2.0)), 0.0)
 
-    def get_bboxes(self, *args, **kwargs):
-        raise NotImplementedError('PETRHead.get_bboxes (NMS-free decode) is SURVEY §8(f) rank 2: not built yet')
+    def loss(self, gt_bboxes_list, gt_labels_list, preds_dicts, gt_bboxes_ignore=None):
+        """reference petr_head.py:646-728.  Cost matrix, Hungarian assignment, focal + L1 loss and their gradients for
+        all decoder levels run in one call on the device (petr_loss_fwd_bwd); no host round trip."""
+        assert gt_bboxes_ignore is None, f'{self.__class__.__name__} only supports for gt_bboxes_ignore setting to None.'
+        if self.sync_cls_avg_factor:
+            raise _C.PetrHipError('sync_cls_avg_factor=True is not implemented (no reference config sets it)')
+        return losses.head_loss(self._loss_config(), gt_bboxes_list, gt_labels_list, preds_dicts)
+
+    def get_bboxes(self, preds_dicts, img_metas, rescale=False):
+        """reference petr_head.py:730-751 (NMSFreeCoder.decode + gravity centre -> bottom centre)."""
+        if getattr(self, 'bbox_coder', None) is None:
+            cfg = dict(self.bbox_coder_cfg or dict(pc_range=self.pc_range,
+                                                   post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], max_num=300))
+            cfg.pop('type', None)
+            cfg.setdefault('num_classes', self.num_classes)
+            self.bbox_coder = losses.NMSFreeCoder(**cfg)
+        return losses.get_bboxes(self.bbox_coder, preds_dicts, img_metas, rescale)
 
 
 @register('HEADS')

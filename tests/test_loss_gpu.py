@@ -1,0 +1,127 @@
+"""GPU parity of the steps right behind the hot path: PETRHead.loss (match cost, Hungarian
+assignment, focal + L1 loss, gradients — one device call) and PETRHead.get_bboxes (NMS-free decode), against the
+golden vectors produced by the REFERENCE's own loss / assigner / coder code (oracle/make_golden_loss.py) and against
+the CPU oracle on fresh cases."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import loss_oracle as LO  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope='module')
+def head():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import petr_amd
+    cfg = petr_amd.petr_head_cfg(num_query=40)
+    cfg['train_cfg'] = dict(assigner=dict(type='HungarianAssigner3D', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                                          reg_cost=dict(type='BBox3DL1Cost', weight=0.25),
+                                          iou_cost=dict(type='IoUCost', weight=0.0)))
+    return petr_amd.build_head(cfg).cuda()
+
+
+def rel(got, want):
+    got, want = torch.as_tensor(got).detach().double().cpu(), torch.as_tensor(want).double()
+    return ((got - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
+
+
+def _split(fx):
+    counts = [int(c) for c in fx['gt_counts']]
+    boxes = list(torch.from_numpy(fx['gt_boxes']).split(counts))
+    labels = list(torch.from_numpy(fx['gt_labels']).split(counts))
+    return boxes, labels
+
+
+@pytest.mark.parametrize('name', ['loss_toy', 'loss_q900'])
+def test_loss_golden(head, golden_dir, name):
+    """fixture = outputs of the reference's PETRHead.loss (+ autograd gradients of the summed losses)."""
+    from petr_amd import losses
+    fx = np.load(os.path.join(golden_dir, name + '.npz'))
+    boxes, labels = _split(fx)
+    cls = torch.from_numpy(fx['cls']).cuda().requires_grad_(True)
+    box = torch.from_numpy(fx['box']).cuda().requires_grad_(True)
+    out, assigned = losses.head_loss(head._loss_config(), [b.cuda() for b in boxes], [t.cuda() for t in labels],
+                                     {'all_cls_scores': cls, 'all_bbox_preds': box}, return_assignment=True)
+    want = dict(zip([str(k) for k in fx['loss_keys']], fx['loss_values']))
+    assert set(out) == set(want)
+    assert torch.equal(assigned.cpu().long(), torch.from_numpy(fx['assigned']))     # the same matching, query for query
+    for k, v in want.items():
+        assert abs(out[k].item() - v) < 2e-5 * max(1.0, abs(v)), (k, out[k].item(), v)
+    sum(out.values()).backward()
+    assert rel(cls.grad, fx['d_cls']) < 1e-4 and rel(box.grad, fx['d_box']) < 1e-5
+    # weighted outputs: the level slices of the precomputed gradient are scaled by the incoming gradient
+    cls.grad = box.grad = None
+    out = head.loss([b.cuda() for b in boxes], [t.cuda() for t in labels],
+                    {'all_cls_scores': cls, 'all_bbox_preds': box, 'enc_cls_scores': None, 'enc_bbox_preds': None})
+    (3.0 * out['loss_cls'] + 0.5 * out['d2.loss_bbox']).backward()
+    want_c = torch.zeros_like(cls.grad)
+    want_c[5] = 3.0 * torch.from_numpy(fx['d_cls'])[5].cuda()
+    want_b = torch.zeros_like(box.grad)
+    want_b[2] = 0.5 * torch.from_numpy(fx['d_box'])[2].cuda()
+    assert rel(cls.grad, want_c.cpu()) < 1e-4 and rel(box.grad, want_b.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize('B,Q,n_gt,seed', [(2, 900, [61, 23], 11), (3, 130, [0, 5, 130], 12), (1, 900, [300], 13)])
+def test_loss_vs_oracle(head, B, Q, n_gt, seed):
+    """Fresh cases against the CPU oracle (reference-pinned restatement): empty samples, as many boxes as queries,
+    hundreds of boxes; matching must agree exactly, or — on a near-tie — reach the same optimal cost."""
+    from petr_amd import losses
+    g = torch.Generator().manual_seed(seed)
+    cls = torch.randn(6, B, Q, 10, generator=g) * 2 - 2
+    box = torch.randn(6, B, Q, 10, generator=g)
+    boxes, labels = LO.synthetic_gt(B, n_gt, seed=seed)
+    cfg = LO.LossCfg()
+    cd, bd = cls.double().requires_grad_(True), box.double().requires_grad_(True)
+    want, want_assign = LO.head_loss(cfg, [b.double() for b in boxes], labels, {'all_cls_scores': cd, 'all_bbox_preds': bd})
+    cc, bc = cls.cuda().requires_grad_(True), box.cuda().requires_grad_(True)
+    out, assigned = losses.head_loss(head._loss_config(), [b.cuda() for b in boxes], [t.cuda() for t in labels],
+                                     {'all_cls_scores': cc, 'all_bbox_preds': bc}, return_assignment=True)
+    same = torch.equal(assigned.cpu().long(), want_assign)
+    assert same or (assigned.cpu().long() != want_assign).float().mean().item() < 0.01
+    if same:
+        for k, v in want.items():
+            assert abs(out[k].item() - v.item()) < 2e-5 * max(1.0, abs(v.item())), (k, out[k].item(), v.item())
+        sum(want.values()).backward()
+        sum(out.values()).backward()
+        assert rel(cc.grad, cd.grad) < 1e-4 and rel(bc.grad, bd.grad) < 1e-5
+    assert int((assigned > 0).sum()) == 6 * sum(min(n, Q) for n in n_gt)          # one query per ground-truth box
+
+
+def test_loss_nan_guards(head):
+    """petr_head.py:635-643: rows whose normalised target is not finite are left out; a non-finite level loss becomes 0."""
+    from petr_amd import losses
+    g = torch.Generator().manual_seed(5)
+    cls, box = torch.randn(6, 1, 40, 10, generator=g), torch.randn(6, 1, 40, 10, generator=g)
+    boxes, labels = LO.synthetic_gt(1, [6], seed=5)
+    boxes[0][2, 3] = 0.0                     # zero width: log -> -inf, the row drops out of the L1 loss
+    cls[3, 0, 7, 2] = float('nan')           # NaN logit: level 3's classification loss is NaN -> 0
+    want, _ = LO.head_loss(LO.LossCfg(), boxes, labels, {'all_cls_scores': cls, 'all_bbox_preds': box})
+    cc = cls.cuda().requires_grad_(True)
+    out = losses.head_loss(head._loss_config(), [boxes[0].cuda()], [labels[0].cuda()], {'all_cls_scores': cc, 'all_bbox_preds': box.cuda()})
+    for k, v in want.items():
+        assert abs(out[k].item() - v.item()) < 2e-5 * max(1.0, abs(v.item())), (k, out[k].item(), v.item())
+    assert out['d3.loss_cls'].item() == 0.0
+    sum(out.values()).backward()
+    assert (cc.grad[3] == 0).all() and torch.isfinite(cc.grad).all()
+
+
+def test_get_bboxes_golden(head, golden_dir):
+    """fixture = outputs of the reference's NMSFreeCoder.decode + PETRHead.get_bboxes."""
+    fx = np.load(os.path.join(golden_dir, 'decode_q900.npz'))
+    preds = {'all_cls_scores': torch.from_numpy(fx['cls']).cuda(), 'all_bbox_preds': torch.from_numpy(fx['box']).cuda()}
+    metas = [{'box_type_3d': lambda t, dim: ('wrapped', t, dim)}, {}]
+    res = head.get_bboxes(preds, metas)
+    assert res[0][0][0] == 'wrapped' and res[0][0][2] == 9
+    for i, r in enumerate(res):
+        boxes = r[0][1] if i == 0 else r[0]
+        assert boxes.shape == fx[f'bboxes{i}'].shape
+        assert rel(boxes, fx[f'bboxes{i}']) < 1e-5 and rel(r[1], fx[f'scores{i}']) < 1e-6
+        assert torch.equal(r[2].cpu(), torch.from_numpy(fx[f'labels{i}']))
+    # NMSFreeCoder.decode keeps the gravity centre
+    dec = head.bbox_coder.decode(preds)
+    assert rel(dec[1]['bboxes'][:, 2] - dec[1]['bboxes'][:, 5] * 0.5, fx['bboxes1'][:, 2]) < 1e-5

@@ -141,3 +141,33 @@ def test_oracle_supplied_dropout_masks_reduce_to_eval_mode():
         a, b = o([f], metas), o([f], metas, dropout_masks=masks)
     assert (a['all_cls_scores'] - b['all_cls_scores']).abs().max() < 1e-5
     assert (a['all_bbox_preds'] - b['all_bbox_preds']).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize('name', ['loss_toy', 'loss_q900'])
+def test_loss_oracle_against_reference_fixture(golden_dir, name):
+    """oracle/loss_oracle.py vs the outputs of the reference's own PETRHead.loss / HungarianAssigner3D code."""
+    from oracle import loss_oracle as LO
+    fx = np.load(os.path.join(golden_dir, name + '.npz'))
+    counts = [int(c) for c in fx['gt_counts']]
+    boxes = list(torch.from_numpy(fx['gt_boxes']).split(counts))
+    labels = list(torch.from_numpy(fx['gt_labels']).split(counts))
+    cls = torch.from_numpy(fx['cls']).requires_grad_(True)
+    box = torch.from_numpy(fx['box']).requires_grad_(True)
+    got, assigned = LO.head_loss(LO.LossCfg(), boxes, labels, {'all_cls_scores': cls, 'all_bbox_preds': box})
+    want = dict(zip([str(k) for k in fx['loss_keys']], fx['loss_values']))
+    assert set(got) == set(want) and torch.equal(assigned, torch.from_numpy(fx['assigned']))
+    for k, v in want.items():
+        assert abs(got[k].item() - v) < 1e-6 * max(1.0, abs(v))
+    sum(got.values()).backward()
+    assert (cls.grad - torch.from_numpy(fx['d_cls'])).abs().max() < 1e-7
+    assert (box.grad - torch.from_numpy(fx['d_box'])).abs().max() < 1e-7
+
+
+def test_decode_oracle_against_reference_fixture(golden_dir):
+    from oracle import loss_oracle as LO
+    fx = np.load(os.path.join(golden_dir, 'decode_q900.npz'))
+    got = LO.get_bboxes(LO.LossCfg(), {'all_cls_scores': torch.from_numpy(fx['cls']), 'all_bbox_preds': torch.from_numpy(fx['box'])})
+    for i, r in enumerate(got):
+        assert (r[0] - torch.from_numpy(fx[f'bboxes{i}'])).abs().max() < 1e-6
+        assert (r[1] - torch.from_numpy(fx[f'scores{i}'])).abs().max() < 1e-7
+        assert torch.equal(r[2], torch.from_numpy(fx[f'labels{i}']))

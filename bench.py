@@ -275,6 +275,40 @@ def main():
             kernels['coords3d']['gbs'] = round(B * Ltok * 192 * 4 / (us * 1e-6) / 1e9, 1)   # volume bytes
             kernels['coords3d']['hbm_frac'] = round(kernels['coords3d']['gbs'] / HBM_PEAK_GBS, 4)
 
+    # ---- the full training step of the reference: forward -> PETRHead.loss -> backward ----
+    loss_leg = None
+    if rank == 0 and not args.fwd_only:
+        from oracle import loss_oracle as LO          # synthetic ground truth only (40 boxes per sample)
+        gt_b, gt_l = LO.synthetic_gt(B, 40, seed=7)
+        gt_b, gt_l = [t.to(dev) for t in gt_b], [t.to(dev) for t in gt_l]
+
+        def loss_step():
+            head.zero_grad_flat()
+            feats.grad = None
+            out = head([feats], metas)
+            ld = head.loss(gt_b, gt_l, out)
+            sum(ld.values()).backward()
+
+        for _ in range(5):
+            loss_step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_step()
+        torch.cuda.synchronize()
+        full_ms = (time.perf_counter() - t2) / args.steps * 1e3
+        with torch.no_grad():
+            out = head([feats], metas)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            head.loss(gt_b, gt_l, out)
+        torch.cuda.synchronize()
+        loss_ms = (time.perf_counter() - t3) / args.steps * 1e3
+        loss_leg = {'fwd_loss_bwd_ms_per_step': round(full_ms, 4), 'samples_per_s': round(B / (full_ms * 1e-3), 2),
+                    'loss_call_ms': round(loss_ms, 4),
+                    'what': 'forward -> PETRHead.loss (device cost matrix + Hungarian assignment + focal/L1 + gradients, '
+                            '6 levels, 40 ground-truth boxes per sample) -> backward'}
     if rank == 0:
         log('kernel timing done')
     cpu = None
@@ -296,7 +330,7 @@ def main():
                        'fwd_only_leg': 'eval mode (inference forward)'},
             'fwd_ms': round(fwd_ms, 4) if fwd_ms is not None else None,
             'fwd_samples_per_s': round(B / (fwd_ms * 1e-3), 2) if fwd_ms else None,
-            'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu,
+            'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu, 'with_loss': loss_leg,
         }
         if cpu and fwd_ms:
             out['fwd_speedup_vs_cpu'] = round((B / (fwd_ms * 1e-3)) / cpu['fwd_value'], 1)

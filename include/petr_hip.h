@@ -296,7 +296,7 @@ int petr_reduce_batch(const float* x, int B, long rows, int C, float* out, int a
  * match_cost.py:6-27), normalize_bbox (core/bbox/util.py:38-58), mmdet FocalLoss / L1Loss.
  *     cls [NL,B,Q,NC] logits, box [NL,B,Q,CS>=10]; gt_boxes [Gtot,9] = (gravity centre xyz, w, l, h,
  *     yaw, vx, vy) of all samples back to back (what petr_head.py:697-699 builds), gt_labels [Gtot],
- *     gt_offsets [B+1] (device ints), Gmax = largest per-sample count (<= Q), num_pos = sum_b min(G_b,Q).
+ *     gt_offsets [B+1] ints in HOST memory (B <= 64; read at launch), Gmax = largest per-sample count (<= Q), num_pos = sum_b min(G_b,Q).
  *     losses [NL,2] = (loss_cls, loss_bbox) per decoder level (level NL-1 is 'loss_cls'/'loss_bbox',
  *     level i < NL-1 is 'd{i}.loss_*'); d_cls / d_box (optional) = gradient of the SUM of all 2*NL losses
  *     (level l's losses depend on level l's predictions only, so a caller with other output weights

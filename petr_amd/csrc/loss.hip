@@ -31,8 +31,11 @@ namespace {
 constexpr int LSA_COLS = 16;            // columns per lane: Q <= 64 * 16
 constexpr double LSA_INF = 1e300;
 
+constexpr int LOSS_MAX_B = 64;
+
 struct LossParams {
   petr_loss_args a;
+  int offs[LOSS_MAX_B + 1];   // gt_offsets, copied from HOST memory at launch (no device round trip for metadata)
   double* cost;          // [NL][Gtot][Q]
   double* sums;          // [NL][2]
   float cls_norm, box_norm;   // loss_weight / (avg_factor + eps)
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void loss_cost_kernel(const LossParams p) {
   const int lvl = blockIdx.z;
   if (q >= a.Q) return;
   int b = 0;
-  while (b + 1 < a.B && g >= a.gt_offsets[b + 1]) ++b;
+  while (b + 1 < a.B && g >= p.offs[b + 1]) ++b;
   const float* cls = a.cls + (((long)lvl * a.B + b) * a.Q + q) * a.NC;
   const float* box = a.box + (((long)lvl * a.B + b) * a.Q + q) * a.CS;
   const long label = a.gt_labels[g];
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(64) void loss_lsa_kernel(const LossParams p) {
   extern __shared__ double lds[];           // u[Gmax] | col4row[Gmax] (int) | sr_list[Gmax] (int)
   const petr_loss_args& a = p.a;
   const int b = blockIdx.x, lvl = blockIdx.y, lane = threadIdx.x;
-  const int g0 = a.gt_offsets[b], nr = min(a.gt_offsets[b + 1] - g0, a.Q), nc = a.Q;
+  const int g0 = p.offs[b], nr = min(p.offs[b + 1] - g0, a.Q), nc = a.Q;
   int* assigned = a.assigned + ((long)lvl * a.B + b) * a.Q;
   for (int j = lane; j < nc; j += 64) assigned[j] = 0;
   if (nr <= 0) return;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossParams p) {
     lvl = (int)(idx / ((long)a.B * a.Q));
     const int b = (int)((idx / a.Q) % a.B);
     const int asg = a.assigned[idx];
-    const int g = asg > 0 ? a.gt_offsets[b] + asg - 1 : -1;
+    const int g = asg > 0 ? p.offs[b] + asg - 1 : -1;
     const long label = g >= 0 ? a.gt_labels[g] : a.NC;      // num_classes = background (petr_head.py:507-510)
     const float* cls = a.cls + idx * a.NC;
     float* dc = a.d_cls ? a.d_cls + idx * a.NC : nullptr;
@@ -319,6 +322,7 @@ extern "C" int petr_loss_fwd_bwd(const petr_loss_args* ap, void* stream) {
   PETR_CHECK(ap->Gtot == 0 || (ap->gt_boxes && ap->gt_labels), PETR_ERR_INVALID, "loss: gt pointers missing");
   PETR_CHECK(ap->NL > 0 && ap->B > 0 && ap->Q > 0 && ap->NC > 0 && ap->CS >= 10 && ap->Gtot >= 0 && ap->Gmax >= 0,
              PETR_ERR_INVALID, "loss: bad shape");
+  PETR_CHECK(ap->B <= LOSS_MAX_B, PETR_ERR_UNSUPPORTED, "loss: at most %d samples per call", LOSS_MAX_B);
   PETR_CHECK(ap->Q <= 64 * LSA_COLS, PETR_ERR_UNSUPPORTED, "loss: the assignment kernel holds at most %d queries", 64 * LSA_COLS);
   PETR_CHECK(ap->Gmax <= ap->Q, PETR_ERR_UNSUPPORTED, "loss: more ground-truth boxes (%d) than queries (%d) in one sample",
              ap->Gmax, ap->Q);
@@ -330,6 +334,11 @@ extern "C" int petr_loss_fwd_bwd(const petr_loss_args* ap, void* stream) {
   PETR_CHECK(lds <= 60000, PETR_ERR_UNSUPPORTED, "loss: %d ground-truth boxes in one sample exceed the LDS budget", ap->Gmax);
   LossParams p;
   p.a = *ap;
+  for (int b = 0; b <= ap->B; ++b) p.offs[b] = ap->gt_offsets[b];
+  PETR_CHECK(p.offs[0] == 0 && p.offs[ap->B] == ap->Gtot, PETR_ERR_INVALID, "loss: gt_offsets must run from 0 to Gtot");
+  for (int b = 0; b < ap->B; ++b)
+    PETR_CHECK(p.offs[b + 1] >= p.offs[b] && p.offs[b + 1] - p.offs[b] <= ap->Gmax, PETR_ERR_INVALID,
+               "loss: gt_offsets not monotonic or a sample exceeds Gmax");
   p.cost = (double*)ap->ws;
   p.sums = p.cost + (size_t)ap->NL * (ap->Gtot > 0 ? ap->Gtot : 1) * ap->Q;
   const double eps = 1.1920928955078125e-07;   // torch.finfo(float32).eps (mmdet weight_reduce_loss)

@@ -55,7 +55,8 @@ class _LossFn(torch.autograd.Function):
         a.cls, a.box = cls.data_ptr(), box.data_ptr()
         a.gt_boxes = gt_boxes.data_ptr() if gtot else None
         a.gt_labels = gt_labels.data_ptr() if gtot else None
-        a.gt_offsets = gt_offsets.data_ptr()
+        offs = (C.c_int * (B + 1))(*gt_offsets)
+        a.gt_offsets = C.cast(offs, C.c_void_p)
         a.NL, a.B, a.Q, a.NC, a.CS, a.Gtot, a.Gmax = NL, B, Q, NC, CS, gtot, gmax
         a.num_pos = int(sum(min(c, Q) for c in counts))
         a.cls_weight, a.bbox_weight, a.alpha, a.gamma = cfg.cls_weight, cfg.bbox_weight, cfg.alpha, cfg.gamma
@@ -102,7 +103,7 @@ def head_loss(cfg, gt_bboxes_list, gt_labels_list, preds_dicts, return_assignmen
     offs = [0]
     for c in counts:
         offs.append(offs[-1] + c)
-    gt_offsets = torch.tensor(offs, dtype=torch.int32).to(dev)
+    gt_offsets = offs            # host metadata: goes into the kernel arguments, no H2D copy
     losses, assigned = _LossFn.apply(all_cls, all_box, gt_boxes, gt_labels, gt_offsets, counts, cfg)
     out = {}
     n = all_cls.shape[0]

@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void loss_cost_kernel(const LossParams p) {
   p.cost[((long)lvl * a.Gtot + g) * a.Q + q] = (double)c;
 }
 
-// wave-wide argmin with the tie rule (value, then unassigned first, then lowest column)
+// wave-wide argmin with the tie rule (value, then unassigned first, then lowest column).  Only the VALUE travels
+// through the cross-lane network (six DPP/permute steps of one double); the winner among equal values is found
+// with two ballots, and its index comes back with one readlane.
 struct Best { double v; int un; int j; };
 __device__ __forceinline__ Best better(const Best& x, const Best& y) {
   if (x.v < y.v) return x;
@@ -83,15 +85,19 @@ __device__ __forceinline__ Best better(const Best& x, const Best& y) {
   return x.j <= y.j ? x : y;
 }
 __device__ __forceinline__ Best wave_best(Best b) {
+  double m = b.v;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    Best y;
-    y.v = __shfl_xor(b.v, o, 64);
-    y.un = __shfl_xor(b.un, o, 64);
-    y.j = __shfl_xor(b.j, o, 64);
-    b = better(b, y);
-  }
-  return b;
+  for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o, 64));
+  const bool tie = b.v == m;
+  const unsigned long long un_mask = __ballot(tie && b.un);
+  const bool cand = un_mask ? (tie && b.un) : tie;                     // unassigned columns first
+  // lowest column index among the candidates: columns are lane + 64k, so compare indices, one more reduction of ints
+  int j = cand ? b.j : 0x7fffffff;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) j = min(j, __shfl_xor(j, o, 64));
+  Best r;
+  r.v = m; r.un = un_mask != 0; r.j = j;
+  return r;
 }
 
 __global__ __launch_bounds__(64) void loss_lsa_kernel(const LossParams p) {
@@ -128,11 +134,16 @@ __global__ __launch_bounds__(64) void loss_lsa_kernel(const LossParams p) {
       const double* row = cost + (long)i * nc;
       Best best;
       best.v = LSA_INF; best.un = 0; best.j = 0x7fffffff;
+      // the row's costs first, unconditionally and from clamped addresses: a load inside the divergent branch below
+      // would be waited for on the spot, i.e. sixteen serial L2 round trips per step instead of one
+      double cr[LSA_COLS];
+#pragma unroll
+      for (int k = 0; k < LSA_COLS; ++k) cr[k] = row[min(lane + 64 * k, nc - 1)];
 #pragma unroll
       for (int k = 0; k < LSA_COLS; ++k) {
         const int j = lane + 64 * k;
         if (j < nc && !((sc >> k) & 1u)) {
-          const double r = min_val + row[j] - ui - v[k];
+          const double r = min_val + cr[k] - ui - v[k];
           if (r < sp[k]) { sp[k] = r; path[k] = i; }
           Best c;
           c.v = sp[k]; c.un = row4col[k] < 0; c.j = j;

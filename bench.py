@@ -156,6 +156,7 @@ def main():
     head.init_weights()
     # the metric is the TRAINING step: train() = the reference's dropouts (p = 0.1, six per decoder layer) are active
     head = head.to(dev).train(not (args.eval_mode or args.fwd_only))
+    torch.manual_seed(1000 + rank)           # the per-forward dropout seeds are drawn from this stream: one per rank
     metas = synthetic_metas(B, n, (ph, pw), seed=rank * 1000)
     g = torch.Generator().manual_seed(1234 + rank)           # rank-offset seed: every rank has its own samples
     feats = torch.randn(B, n, 256, h, w, generator=g).to(dev).requires_grad_(not args.fwd_only)

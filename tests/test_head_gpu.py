@@ -222,6 +222,36 @@ def test_head_training_mode_dropout_900_queries(pa):
     _grad_case(pa, 1, 6, 8, 11, (256, 352), (256, 352), 900, seed=6, dropout=(31337, 0.1))
 
 
+def test_headv2_training_mode_dropout(pa):
+    """PETRv2Head (fpe, RegLayer, with_time, 12 views, deep-copied branches) in train(): same decoder dropouts."""
+    kw = dict(num_query=16, v2=True, with_fpe=True, with_time=True, with_multi=True, code_weights=[1.0] * 10)
+    _grad_case(pa, 1, 12, 4, 6, (128, 192), (128, 192), 16, seed=8, oracle_kw=kw, with_time=True, dropout=(424242, 0.1))
+
+
+def test_dynamic_tile_tickets_head_parity(golden_dir):
+    """PETR_MHA_DYNAMIC=1 (opt-in ticket scheduling of the attention K/V tiles) is read once per process: run the
+    golden toy forward in a child process with it set."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        "sys.path.insert(0, os.getcwd())\n"
+        "from oracle import petr_oracle as O\n"
+        "import petr_amd\n"
+        "o = O.seeded_head(2, 1234, num_query=900)\n"
+        "h = petr_amd.build_head(petr_amd.petr_head_cfg(num_query=900)); h.load_state_dict(o.state_dict()); h = h.cuda().eval()\n"
+        "m = O.synthetic_img_metas(1, 6, (256, 352), seed=2)\n"
+        "f = torch.randn(1, 6, 256, 8, 11, generator=torch.Generator().manual_seed(0))\n"
+        "with torch.no_grad():\n"
+        "    w = o([f], m); g = h([f.cuda()], m)\n"
+        "e = max(((g[k].cpu().double() - w[k].double()).abs().max() / w[k].double().abs().max()).item() for k in ('all_cls_scores', 'all_bbox_preds'))\n"
+        "print('REL', e); sys.exit(0 if e < 1e-4 else 1)\n")
+    env = dict(os.environ, PETR_MHA_DYNAMIC='1')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1500:]
+
+
 def test_head_backward_c5(pa):
     head, metas, feats, (g_cls, g_box) = _grad_case(pa, 1, 6, 16, 44, (512, 1408), (512, 1408), 900, seed=5)
     # gradient accumulation semantics: a second backward adds onto .grad

@@ -472,9 +472,8 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
   hipEvent_t ev0, ev1;   // null unless bench.py's profiler is on: then they carry this dispatch's begin/end
   petr_prof_claim(PETR_PROF_MHA_FWD + 16 * (a.L > a.Q ? 1 : 0), &ev0, &ev1);
   const bool vec = p.q_vec && p.kv_vec;
-  static const int lds_pad = getenv("PETR_MHA_FWD_LDS_PAD") ? atoi(getenv("PETR_MHA_FWD_LDS_PAD")) : 0;
   auto launch = [&](auto kern) {
-    hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), lds_pad, s, ev0, ev1, 0, p);
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), 0, s, ev0, ev1, 0, p);
   };
   const int variant = (p.drop.thr ? 8 : 0) | (a.kpm ? 4 : 0) | (vec ? 2 : 0) | (p.sched ? 1 : 0);
   switch (variant) {

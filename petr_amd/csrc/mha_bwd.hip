@@ -131,30 +131,37 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
     lreg = a.lse[(long)bh * a.Q + rc];
   };
 
-  if (qt_begin < qt_end) gload(qt_begin);
-  for (int qt = qt_begin; qt < qt_end; ++qt) {
-    {
-      const int row = t >> 3, c4 = t & 7;
-      const bool ok = qt * 32 + row < a.Q;
-      float* d = Qs + row * P33 + 4 * c4;
-      d[0] = ok ? qreg.x : 0.f; d[1] = ok ? qreg.y : 0.f; d[2] = ok ? qreg.z : 0.f; d[3] = ok ? qreg.w : 0.f;
-      float* e = dOs + row * P33 + 4 * c4;
-      e[0] = ok ? greg.x : 0.f; e[1] = ok ? greg.y : 0.f; e[2] = ok ? greg.z : 0.f; e[3] = ok ? greg.w : 0.f;
-      // delta[row] = sum_d dO*O of this (row, head): 8 lanes share a row -> three xor-shuffles, no extra kernel
-      float dl = (greg.x * oreg.x + greg.y * oreg.y) + (greg.z * oreg.z + greg.w * oreg.w);
-      dl += __shfl_xor(dl, 1, 64);
-      dl += __shfl_xor(dl, 2, 64);
-      dl += __shfl_xor(dl, 4, 64);
-      if (c4 == 0) dl_s[row] = ok ? -dl : 0.f;
-      if (t < 32) {
-        const bool rok = qt * 32 + t < a.Q;
-        lse_s[t] = rok ? -lreg * inv_scale : -INFINITY;   // rows beyond Q: -LSE/scale = -inf  =>  p = 0
-        if (DROP) rk_s[t] = drop_row_key(p.drop, (uint32_t)(bh * a.Q + min(qt * 32 + t, a.Q - 1)));
-      }
+  // registers -> LDS for query tile qt (raw loads were issued one tile earlier)
+  auto stage = [&](int qt) {
+    const int row = t >> 3, c4 = t & 7;
+    const bool ok = qt * 32 + row < a.Q;
+    float* d = Qs + row * P33 + 4 * c4;
+    d[0] = ok ? qreg.x : 0.f; d[1] = ok ? qreg.y : 0.f; d[2] = ok ? qreg.z : 0.f; d[3] = ok ? qreg.w : 0.f;
+    float* e = dOs + row * P33 + 4 * c4;
+    e[0] = ok ? greg.x : 0.f; e[1] = ok ? greg.y : 0.f; e[2] = ok ? greg.z : 0.f; e[3] = ok ? greg.w : 0.f;
+    // delta[row] = sum_d dO*O of this (row, head): 8 lanes share a row -> three xor-shuffles, no extra kernel
+    float dl = (greg.x * oreg.x + greg.y * oreg.y) + (greg.z * oreg.z + greg.w * oreg.w);
+    dl += __shfl_xor(dl, 1, 64);
+    dl += __shfl_xor(dl, 2, 64);
+    dl += __shfl_xor(dl, 4, 64);
+    if (c4 == 0) dl_s[row] = ok ? -dl : 0.f;
+    if (t < 32) {
+      const bool rok = qt * 32 + t < a.Q;
+      lse_s[t] = rok ? -lreg * inv_scale : -INFINITY;   // rows beyond Q: -LSE/scale = -inf  =>  p = 0
+      if (DROP) rk_s[t] = drop_row_key(p.drop, (uint32_t)(bh * a.Q + min(qt * 32 + t, a.Q - 1)));
     }
-    __syncthreads();
-    if (qt + 1 < qt_end) gload(qt + 1);
+  };
 
+  // Two barriers per query tile: the tile for the NEXT iteration is staged between them (its Q/dO images are free
+  // as soon as every wave has finished the four products of the current tile), so the barrier that publishes the
+  // dQ partials also publishes the next tile.
+  if (qt_begin < qt_end) {
+    gload(qt_begin);
+    stage(qt_begin);
+    if (qt_begin + 1 < qt_end) gload(qt_begin + 1);
+  }
+  __syncthreads();
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
     f32x16 S, dP;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -187,7 +194,11 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) dSs[wave][mfma32_row(r, h) * P33 + c] = dP[r];
-    __syncthreads();
+    __syncthreads();   // every wave is done with this tile's Q / dO / lse / delta images
+    if (qt + 1 < qt_end) {
+      stage(qt + 1);
+      if (qt + 2 < qt_end) gload(qt + 2);
+    }
 
     f32x16 dQp;
 #pragma unroll

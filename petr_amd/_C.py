@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libpetr_hip.so')
+# PETR_HIP_LIB: another build of the same ABI (A/B timing of kernel variants on ONE box; devices differ by several %)
+LIB_PATH = os.environ.get('PETR_HIP_LIB') or os.path.join(_HERE, 'lib', 'libpetr_hip.so')
 
 c_float_p = C.POINTER(C.c_float)
 

@@ -112,12 +112,21 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
   float4 qreg, greg, oreg;
   float lreg = 0.f;
   // raw loads only (clamped rows): selects/negations happen at the LDS store so that nothing waits at the load
+  // Tile addresses are a wave-uniform base (scalar arithmetic) + a per-lane 32-bit offset computed once: the f32
+  // MFMA shares the vector issue port, and 32/64-bit integer multiplies are quarter rate.
+  const int ld_row = t >> 3, ld_c4 = t & 7;
+  const int q_off = ld_row * (int)a.q_rs + 4 * ld_c4, g_off = ld_row * (int)a.do_rs + 4 * ld_c4,
+            o_off = ld_row * (int)a.o_rs + 4 * ld_c4;
   auto gload = [&](int qt) {
-    const int row = qt * 32 + (t >> 3), c4 = t & 7;
-    const int rowc = min(row, a.Q - 1);
-    const float* s = qp + (long)rowc * a.q_rs + 4 * c4;
-    const float* g = gp + (long)rowc * a.do_rs + 4 * c4;
-    const float* o = op + (long)rowc * a.o_rs + 4 * c4;
+    int qo = q_off, go = g_off, oo = o_off, lo = t & 31;
+    if (qt * 32 + 32 > a.Q) {   // wave-uniform: ragged last tile, rows beyond Q re-read row Q-1
+      const int rr = min(ld_row, a.Q - 1 - qt * 32);
+      qo = rr * (int)a.q_rs + 4 * ld_c4; go = rr * (int)a.do_rs + 4 * ld_c4; oo = rr * (int)a.o_rs + 4 * ld_c4;
+      lo = min(t & 31, a.Q - 1 - qt * 32);
+    }
+    const float* s = qp + (long)qt * 32 * a.q_rs + qo;
+    const float* g = gp + (long)qt * 32 * a.do_rs + go;
+    const float* o = op + (long)qt * 32 * a.o_rs + oo;
     if (VEC) {
       qreg = *reinterpret_cast<const float4*>(s);
       greg = *reinterpret_cast<const float4*>(g);
@@ -127,9 +136,12 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
       greg = make_float4(g[0], g[1], g[2], g[3]);
       oreg = make_float4(o[0], o[1], o[2], o[3]);
     }
-    const int rc = min(qt * 32 + (t & 31), a.Q - 1);
-    lreg = a.lse[(long)bh * a.Q + rc];
+    lreg = a.lse[(long)bh * a.Q + qt * 32 + lo];
   };
+
+  int dq_off[4];   // element (row, d) = (idx >> 5, idx & 31) of the 32 x 32 dQ tile, idx = t + 256 j
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dq_off[j] = ((t + 256 * j) >> 5) * (int)a.dq_rs + (t & 31);
 
   // registers -> LDS for query tile qt (raw loads were issued one tile earlier)
   auto stage = [&](int qt) {
@@ -211,13 +223,12 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
     for (int r = 0; r < 16; ++r) red[wave][mfma32_row(r, h) * 32 + c] = dQp[r];
     __syncthreads();
     {
-      float* dq = a.dq + (long)b * a.dq_bs + (long)hd * a.dq_hs;
+      float* dq = a.dq + (long)b * a.dq_bs + (long)hd * a.dq_hs + (long)qt * 32 * a.dq_rs;   // wave-uniform tile base
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int idx = t + 256 * j;
-        const int qr = qt * 32 + (idx >> 5), d = idx & 31;
         const float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
-        if (qr < a.Q) atomicAdd(dq + (long)qr * a.dq_rs + d, v * a.scale);
+        if (qt * 32 + (idx >> 5) < a.Q) atomicAdd(dq + dq_off[j], v * a.scale);
       }
     }
   }

@@ -619,12 +619,12 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // Few output tiles AND a long contraction: the latency-optimised kernel (K split inside the workgroup, no
   // LDS staging, no atomics).  It re-reads operands once per tile row/column, so it only pays while the
-  // output is small (<= 256 tiles of 32x32: 900x256, 256x256, 256x10 ...); measured on MI355X it ties the
-  // tiled kernel at K = 256 and is 2x faster at K >= 1024 for K-contiguous operands (float4 fragment loads);
+  // output is small (<= 256 tiles of 32x32: 900x256, 256x256, 256x10 ...); measured on MI355X (same-box A/B of the whole
+  // step) it is ~1 % of the step ahead of the tiled kernel at K = 256 and 2x faster at K >= 1024 for K-contiguous operands (float4 fragment loads);
   // with row-contiguous operands (gradients) its 4-byte loads lose to the tiled kernel.  Slabs stay tiled.
   const long tiles32 = cdiv(g.M, 32) * cdiv(g.N, 32) * (long)g.nb0 * g.nb1;
   const bool slabs = g.split_k > 1 && !(g.flags & PETR_GEMM_ATOMIC);
-  if (!slabs && tiles32 <= 256 && g.K >= 512 && g.a_kcontig && g.b_kcontig && !(g.flags & PETR_GEMM_ATOMIC)) {
+  if (!slabs && tiles32 <= 256 && g.K >= 256 && g.a_kcontig && g.b_kcontig && !(g.flags & PETR_GEMM_ATOMIC)) {
     petr_gemm_args q = g;
     q.split_k = 1;
     return vec ? launch_skinny<true>(q, s) : launch_skinny<false>(q, s);

@@ -634,7 +634,7 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
   const long b128 = cdiv(g.M, 128) * cdiv(g.N, 128) * nz;
   const long b12864 = cdiv(g.M, 128) * cdiv(g.N, 64) * nz;
   if (b128 >= 384 && g.N > 64) return launch_cfg<128, 128, 64, 64, 32, true>(g, s);
-  if (b12864 >= 256 && g.N > 32) return launch_cfg<128, 64, 64, 32, 32, true>(g, s);
+  if (b12864 >= 1024 && g.N > 32) return launch_cfg<128, 64, 64, 32, 32, true>(g, s);
   // (a BK = 64 variant of this config measured 5 % slower end to end on MI355X: longer prologue, same chain)
   return launch_cfg<64, 64, 32, 32, 32, true>(g, s);
 }

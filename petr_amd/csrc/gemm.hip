@@ -630,11 +630,10 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
     return vec ? launch_skinny<true>(q, s) : launch_skinny<false>(q, s);
   }
   if (!vec) return launch_cfg<64, 64, 32, 32, 32, false>(g, s);   // generic scalar-load path (odd shapes)
-  const long nz = (long)g.nb0 * g.nb1 * g.split_k;
-  const long b128 = cdiv(g.M, 128) * cdiv(g.N, 128) * nz;
-  const long b12864 = cdiv(g.M, 128) * cdiv(g.N, 64) * nz;
-  if (b128 >= 384 && g.N > 64) return launch_cfg<128, 128, 64, 64, 32, true>(g, s);
-  if (b12864 >= 1024 && g.N > 32) return launch_cfg<128, 64, 64, 32, 32, true>(g, s);
-  // (a BK = 64 variant of this config measured 5 % slower end to end on MI355X: longer prologue, same chain)
+  // One tile shape for everything: 64 x 64 per workgroup, 32 x 32 per wave.  128 x 64 and 128 x 128 configurations
+  // of this kernel lost to it in every same-box A/B (c5 step 5.56 -> 5.33 ms, p4-1600 step 12.67 -> 11.98 ms,
+  // 16384 x 4096 x 1024: 81 -> 92 TFLOP/s): with the f32 MFMA at the vector rate neither LDS bandwidth nor operand
+  // reuse bounds the loop, so the bigger tiles only cost occupancy (more accumulator registers, fewer waves to hide
+  // LDS / global latency and VALU work behind).
   return launch_cfg<64, 64, 32, 32, 32, true>(g, s);
 }

@@ -219,8 +219,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
 
   // Register prefetch ring, PD tiles deep: these contractions are short chains of k-tiles whose
   // per-tile MFMA time (16 MFMAs) is far below one global-load latency, so ONE tile of look-ahead
-  // leaves every iteration waiting ~1-2 us on its loads; PD tiles in flight hide it.
-  constexpr int PD = (BM * BN * BK <= 128 * 64 * 32) ? 3 : 2;
+  // leaves every iteration waiting ~1-2 us on its loads; PD tiles in flight hide it.  Two, not three: the third
+  // stage costs ~25 VGPRs, i.e. a wave of occupancy, and lost 4 % of the whole step in a same-box A/B (c5 5.32 ->
+  // 5.10 ms, p4-1600 12.0 -> 11.45 ms); PD = 1 ties with 2.
+  constexpr int PD = 2;
   SA sa[PD];
   SB sb[PD];
   // Tiles past kt_end are loaded from clamped addresses with an all-zero validity mask and multiplied as zeros:
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
         // MFMA per step and the ~100-cycle LDS latency sits in front of every 64-cycle MFMA of the dependent chain):
         // LA steps of fragments are requested before the chain starts and each step refills the slot it frees.
         constexpr int STEPS = BK / 2;
-        constexpr int LA = (TM * TN == 1) ? 8 : (TM * TN == 2 ? 4 : 2);   // look-ahead in k-steps (registers: LA*(TM+TN))
+        constexpr int LA = (TM * TN == 1) ? 4 : (TM * TN == 2 ? 4 : 2);   // look-ahead in k-steps (registers: LA*(TM+TN))
         float af[LA][TM], bf[LA][TN];
 #pragma unroll
         for (int s = 0; s < LA; ++s) {

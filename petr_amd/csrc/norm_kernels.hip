@@ -397,7 +397,7 @@ extern "C" int petr_layernorm_bwd(const petr_layernorm_bwd_args* a, void* stream
              "layernorm_bwd: C=%d unsupported", a->C);
   PETR_CHECK(!(a->flags & PETR_LN_RELU) || a->y, PETR_ERR_INVALID, "layernorm_bwd: ReLU flag needs y");
   int nblocks = (int)((cdiv(a->M, 4) < LNB_BLOCKS) ? cdiv(a->M, 4) : LNB_BLOCKS);
-  if (!a->ws && nblocks > 64) nblocks = 64;   // atomics form: fewer, longer blocks -> fewer atomic adds
+  if (!a->ws && nblocks > 128) nblocks = 128;   // atomics form: fewer, longer blocks -> fewer atomic adds (64 / 128 / 256 A/B: 128 best)
   hipStream_t s = (hipStream_t)stream;
   petr_layernorm_bwd_args p = *a;
   {

@@ -341,3 +341,42 @@ def test_mha_dropout_fwd_bwd(ops, B, H, Q, L, split, masked):
     o0, _ = ops.mha_fwd(qf, kf, vf, dev(kpm) if masked else None, n_split=split, drop=(2024, 2, 0.0))
     o1, _ = ops.mha_fwd(qf, kf, vf, dev(kpm) if masked else None, n_split=split)
     assert torch.equal(o0, o1)
+
+
+# ------------------------------------------------------------------ attention: ragged / tiny shapes
+@pytest.mark.parametrize('B,H,Q,L,split', [(1, 1, 1, 1, 0), (2, 3, 31, 31, 0), (1, 2, 33, 65, 2), (3, 1, 129, 129, 0),
+                                            (1, 4, 5, 513, 8), (2, 2, 257, 63, 0), (1, 8, 64, 4224, 11), (1, 1, 200, 97, 2)])
+@pytest.mark.parametrize('masked,drop', [(False, None), (True, (77, 9, 0.3))])
+def test_mha_ragged_shapes(ops, B, H, Q, L, split, masked, drop):
+    """Every combination of ragged query blocks, ragged / single key tiles, idle waves, more splits than tiles,
+    key-padding masks and probability dropout, forward and backward, against fp64 torch."""
+    g = torch.Generator().manual_seed(B * 1000 + Q * 7 + L)
+    q, k, v = (torch.randn(B, H, n, 32, generator=g).double().requires_grad_(True) for n in (Q, L, L))
+    do = torch.randn(B, H, Q, 32, generator=g)
+    kpm = None
+    if masked and L > 1:
+        kpm = torch.zeros(B, L, dtype=torch.bool)
+        kpm[:, L - max(1, L // 3):] = True
+        kpm[0, 0] = True
+    s = torch.einsum('bhqd,bhkd->bhqk', q, k) * 32 ** -0.5
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :], float('-inf'))
+    p = torch.softmax(s, -1)
+    if drop is not None:
+        keep = ops.dropout_mask(drop, B * H * Q, L).cpu().view(B, H, Q, L)
+        p = p * keep / (1 - round(drop[2] * 65536) / 65536)
+    want = torch.einsum('bhqk,bhkd->bhqd', p, v)
+    want.backward(do.double())
+    qf, kf, vf = (dev(t.detach().float()) for t in (q, k, v))
+    kw = dict(drop=drop) if drop is not None else {}
+    o, lse = ops.mha_fwd(qf, kf, vf, dev(kpm) if kpm is not None else None, n_split=split, **kw)
+    assert relerr(o, want) < 5e-6
+    dq, dk, dv = ops.mha_bwd(qf, kf, vf, o, dev(do), lse, dev(kpm) if kpm is not None else None, **kw)
+
+    def err(got, want_):     # a single key makes dq / dk identically zero: relative to the gradient scale, not to 0
+        got, want_ = got.double().cpu(), want_.double()
+        return ((got - want_).abs().max() / max(want_.abs().max().item(), 1e-2)).item()
+    assert err(dq, q.grad) < 2e-5 and err(dk, k.grad) < 2e-5 and err(dv, v.grad) < 2e-5
+    # the ticket scheduler is another assignment of the same tiles
+    o2, _ = ops.mha_fwd(qf, kf, vf, dev(kpm) if kpm is not None else None, n_split=split, dynamic=True, **kw)
+    assert relerr(o2, want) < 5e-6

@@ -69,6 +69,21 @@ def synthetic_metas(batch, n_views, pad_hw, seed):
     return metas
 
 
+def synthetic_gt(batch, n_gt, seed=0, num_classes=10, device='cpu'):
+    """Ground truth of the shape nuScenes gives: per sample [G, 9] gravity-centre boxes (centre, dims, yaw, vx, vy)
+    inside the point-cloud range, and [G] labels."""
+    g = torch.Generator().manual_seed(seed)
+    boxes, labels = [], []
+    for _ in range(batch):
+        c = (torch.rand(n_gt, 3, generator=g) - 0.5) * torch.tensor([90.0, 90.0, 6.0])
+        dims = torch.rand(n_gt, 3, generator=g) * torch.tensor([3.0, 8.0, 2.5]) + 0.4
+        yaw = (torch.rand(n_gt, 1, generator=g) - 0.5) * 6.283
+        vel = torch.randn(n_gt, 2, generator=g)
+        boxes.append(torch.cat([c, dims, yaw, vel], 1).to(device))
+        labels.append(torch.randint(0, num_classes, (n_gt,), generator=g).to(device))
+    return boxes, labels
+
+
 def cpu_baseline(workload, batch, num_query, budget_s=25.0, train=True):
     """The oracle (CPU restatement of the reference's PyTorch path) on the host cores: fwd+bwd (training mode:
     torch's own dropouts active, like the GPU leg) and fwd-only (eval mode)."""
@@ -279,9 +294,7 @@ def main():
     # ---- the full training step of the reference: forward -> PETRHead.loss -> backward ----
     loss_leg = None
     if rank == 0 and not args.fwd_only:
-        from oracle import loss_oracle as LO          # synthetic ground truth only (40 boxes per sample)
-        gt_b, gt_l = LO.synthetic_gt(B, 40, seed=7)
-        gt_b, gt_l = [t.to(dev) for t in gt_b], [t.to(dev) for t in gt_l]
+        gt_b, gt_l = synthetic_gt(B, 40, seed=7, device=dev)     # 40 ground-truth boxes per sample
 
         def loss_step():
             head.zero_grad_flat()

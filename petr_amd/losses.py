@@ -67,12 +67,19 @@ class _LossFn(torch.autograd.Function):
         _C.check(L.petr_loss_fwd_bwd(C.byref(a), _stream()), 'petr_loss_fwd_bwd')
         ctx.save_for_backward(d_cls, d_box)
         ctx.mark_non_differentiable(assigned)
-        return losses, assigned
+        ctx.n_levels = NL
+        # 2*NL separate scalar outputs (what the reference's dict holds): the caller's sum / weighting then costs one
+        # tiny autograd node per entry it touches instead of a select + select_backward (a zero-filled [NL, 2]
+        # tensor each) per entry
+        return (assigned,) + losses.flatten().unbind(0)
 
     @staticmethod
-    def backward(ctx, g_losses, _g_assigned):
+    def backward(ctx, _g_assigned, *g_losses):
         d_cls, d_box = ctx.saved_tensors
-        g = g_losses.to(d_cls.dtype)
+        if all(g is None for g in g_losses):
+            return (None,) * 7
+        zero = d_cls.new_zeros(())
+        g = torch.stack([zero if x is None else x.to(d_cls.dtype) for x in g_losses]).view(ctx.n_levels, 2)
         return d_cls * g[:, 0].view(-1, 1, 1, 1), d_box * g[:, 1].view(-1, 1, 1, 1), None, None, None, None, None
 
 
@@ -104,12 +111,13 @@ def head_loss(cfg, gt_bboxes_list, gt_labels_list, preds_dicts, return_assignmen
     for c in counts:
         offs.append(offs[-1] + c)
     gt_offsets = offs            # host metadata: goes into the kernel arguments, no H2D copy
-    losses, assigned = _LossFn.apply(all_cls, all_box, gt_boxes, gt_labels, gt_offsets, counts, cfg)
+    res = _LossFn.apply(all_cls, all_box, gt_boxes, gt_labels, gt_offsets, counts, cfg)
+    assigned, flat = res[0], res[1:]          # flat[2*l] = loss_cls of level l, flat[2*l+1] = loss_bbox
     out = {}
     n = all_cls.shape[0]
-    out['loss_cls'], out['loss_bbox'] = losses[n - 1, 0], losses[n - 1, 1]
+    out['loss_cls'], out['loss_bbox'] = flat[2 * (n - 1)], flat[2 * (n - 1) + 1]
     for i in range(n - 1):
-        out[f'd{i}.loss_cls'], out[f'd{i}.loss_bbox'] = losses[i, 0], losses[i, 1]
+        out[f'd{i}.loss_cls'], out[f'd{i}.loss_bbox'] = flat[2 * i], flat[2 * i + 1]
     return (out, assigned) if return_assignment else out
 
 

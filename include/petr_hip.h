@@ -358,6 +358,10 @@ typedef struct {
 typedef struct petr_ctx petr_ctx;
 int petr_ctx_create(petr_ctx** out, int n_side_streams);
 int petr_ctx_destroy(petr_ctx* ctx);
+/* `target_stream` waits for everything enqueued so far on `main_stream` AND on every side stream of `ctx`
+ * (ctx may be NULL): how a consumer of partially finished work - the gradient exchange after a backward
+ * stage range that is not the last - orders itself without stalling the compute stream.          */
+int petr_ctx_join_into(petr_ctx* ctx, void* main_stream, void* target_stream);
 
 #define PETR_MAX_PARAMS 512
 typedef struct {
@@ -397,7 +401,10 @@ typedef struct {
 } petr_head_grads;
 /* stage_begin/stage_end select a contiguous range of backward stages so the host can interleave
  * gradient all-reduce buckets; petr_head_bwd_num_stages() stages in total; after stage s completes,
- * the gradients of flat range [petr_head_bwd_stage_range(s)] are final.                      */
+ * the gradients of flat range [petr_head_bwd_stage_range(s)] are final.  With a side-stream context
+ * "completes" means: on `stream` AND on the context's side streams - `stream` itself is joined with
+ * them only by the call that runs the last stage; a consumer of an earlier range uses
+ * petr_ctx_join_into().                                                                        */
 int petr_head_bwd_num_stages(const petr_head_config* cfg);
 int petr_head_bwd_stage_range(const petr_head_config* cfg, int stage, long* begin, long* end);
 int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io, const petr_head_grads* g,

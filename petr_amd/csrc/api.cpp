@@ -121,6 +121,32 @@ extern "C" int petr_ctx_create(petr_ctx** out, int n_side_streams) {
   return PETR_OK;
 }
 
+extern "C" int petr_ctx_join_into(petr_ctx* c, void* main_stream, void* target_stream) {
+  // `target_stream` waits for everything enqueued so far on `main_stream` and on every side stream of `c`
+  hipStream_t tgt = (hipStream_t)target_stream;
+  const Lanes ln{(hipStream_t)main_stream, c};
+  hipEvent_t e;
+  if (c) {
+    e = ln.next();
+  } else {
+    static thread_local hipEvent_t fallback = nullptr;      // no context: one event is enough (record/wait are ordered)
+    if (!fallback) {
+      hipError_t r = hipEventCreateWithFlags(&fallback, hipEventDisableTiming);
+      PETR_CHECK(r == hipSuccess, PETR_ERR_LAUNCH, "ctx_join_into: hipEventCreate: %s", hipGetErrorString(r));
+    }
+    e = fallback;
+  }
+  hipError_t r = hipEventRecord(e, ln.main);
+  if (r == hipSuccess) r = hipStreamWaitEvent(tgt, e, 0);
+  for (int i = 0; c && i < c->n_side && r == hipSuccess; ++i) {
+    hipEvent_t es = ln.next();
+    r = hipEventRecord(es, c->side[i]);
+    if (r == hipSuccess) r = hipStreamWaitEvent(tgt, es, 0);
+  }
+  PETR_CHECK(r == hipSuccess, PETR_ERR_LAUNCH, "ctx_join_into: %s", hipGetErrorString(r));
+  return PETR_OK;
+}
+
 extern "C" int petr_ctx_destroy(petr_ctx* c) {
   if (!c) return PETR_OK;
   for (int i = 0; i < c->n_side; ++i) (void)hipStreamDestroy(c->side[i]);

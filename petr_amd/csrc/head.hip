@@ -1175,6 +1175,10 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       }
     }
   }
-  ln.join_all();     // everything (gradient buckets of the stages just run included) is ordered on the caller's stream
+  // The caller's stream is made to wait for the side streams only when the LAST stage has been enqueued.  After an
+  // earlier stage range the weight gradients of those stages may still be running on the side streams: whoever
+  // consumes them (the gradient exchange) orders itself behind them with petr_ctx_join_into(), and the dependent
+  // chain of input-gradient kernels on the caller's stream goes on without stopping at every stage boundary.
+  if (stage_end == P.n_stages) ln.join_all();
   return PETR_OK;
 }

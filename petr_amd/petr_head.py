@@ -427,6 +427,14 @@ class PETRHead(nn.Module):
         _C.check(L.petr_head_fwd(C.byref(run.cfg), C.byref(io), stream), 'petr_head_fwd')
         return run.cls, run.bbox
 
+    def join_streams_into(self, target_stream):
+        """Make ``target_stream`` (a torch.cuda.Stream) wait for everything this head has enqueued so far on the
+        current stream and on its side streams (petr_ctx_join_into): used by the gradient exchange between backward
+        stages, so that the compute stream never stops at a stage boundary."""
+        cur = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _C.check(_C.lib().petr_ctx_join_into(self._context(), cur, C.c_void_p(target_stream.cuda_stream)),
+                 'petr_ctx_join_into')
+
     def _dropout_p(self):
         """The one dropout rate of the decoder (reference configs: attn_drop = dropout_layer = ffn_drop = 0.1).
         The executor applies a single rate to all six sites of a layer and refuses anything else loudly."""

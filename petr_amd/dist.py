@@ -41,6 +41,7 @@ class BucketedGradAllReduce:
         self._cuda = head.flat_parameters().is_cuda
         self._comm = torch.cuda.Stream() if self._cuda else None
         head._stage_hook = self._on_stage
+        head._stage_hook_stages = sorted(self._by_stage)     # the backward is cut only where a bucket ends
 
     def _on_stage(self, stage):
         b = self._by_stage.get(stage)
@@ -75,6 +76,7 @@ class BucketedGradAllReduce:
 
     def detach(self):
         self.head._stage_hook = None
+        self.head._stage_hook_stages = None
 
 
 def all_reduce_flat(flat_grad, world, group=None, average=True):

@@ -466,9 +466,15 @@ class PETRHead(nn.Module):
         if hook is None:
             _C.check(L.petr_head_bwd(C.byref(run.cfg), C.byref(run.io), C.byref(g), 0, n_stages, stream), 'petr_head_bwd')
         else:   # data-parallel: hand each finished gradient bucket to the all-reducer while backward continues
-            for s in range(n_stages):
-                _C.check(L.petr_head_bwd(C.byref(run.cfg), C.byref(run.io), C.byref(g), s, s + 1, stream), 'petr_head_bwd')
-                hook(s)
+            # one call per bucket (stage ranges end where the hook wants to be called), not per stage
+            ends = getattr(self, '_stage_hook_stages', None) or list(range(n_stages))
+            ends = sorted(set(int(e) for e in ends if 0 <= int(e) < n_stages) | {n_stages - 1})
+            begin = 0
+            for e in ends:
+                _C.check(L.petr_head_bwd(C.byref(run.cfg), C.byref(run.io), C.byref(g), begin, e + 1, stream), 'petr_head_bwd')
+                for st in range(begin, e + 1):
+                    hook(st)
+                begin = e + 1
         self._free_ws[run.key].append(run.ws)
         return d_feats
 

@@ -33,6 +33,8 @@ WORKLOADS = {
     'c5': (6, 16, 44, 512, 1408, 'petr_r50dcn_gridmask_c5 head-only: 6x(256x16x44) features'),
     'p4_1408': (6, 32, 88, 512, 1408, 'petr_r50dcn_gridmask_p4 1408x512: 6x(256x32x88) features'),
     'p4_1600': (6, 40, 100, 640, 1600, 'petr_vovnet_p4 1600x640: 6x(256x40x100) features'),
+    # PETRv2Head (fpe + RegLayer + with_time), two frames = 12 views
+    'v2_800': (12, 20, 50, 320, 800, 'petrv2_vovnet_p4 800x320, two frames: 12x(256x20x50) features, PETRv2Head'),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 HBM_PEAK_GBS = 8000.0
@@ -64,8 +66,11 @@ def synthetic_metas(batch, n_views, pad_hw, seed):
             rt[:3, :3] = R
             rt[:3, 3] = -R @ t
             mats.append(K @ rt)
+        half = n_views // 2
         metas.append({'pad_shape': [(pad_hw[0], pad_hw[1], 3)] * n_views, 'img_shape': [(pad_hw[0], pad_hw[1], 3)] * n_views,
-                      'lidar2img': mats})
+                      'lidar2img': mats,
+                      # PETRv2 (with_time): current frame at t = 0, the previous sweep ~0.5 s earlier
+                      'timestamp': [0.0] * half + [0.5 + 0.01 * i for i in range(n_views - half)]})
     return metas
 
 
@@ -95,8 +100,10 @@ def cpu_baseline(workload, batch, num_query, budget_s=25.0, train=True):
     except AttributeError:
         cores = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(cores, 16)))
-    head = O.seeded_head(0, None, num_query=num_query)
-    metas = O.synthetic_img_metas(batch, n, (ph, pw), seed=0)
+    v2 = workload.startswith('v2')
+    kw = dict(v2=True, with_fpe=True, with_time=True, with_multi=True, code_weights=[1.0] * 10) if v2 else {}
+    head = O.seeded_head(0, None, num_query=num_query, **kw)
+    metas = O.synthetic_img_metas(batch, n, (ph, pw), seed=0, with_time=v2)
     g = torch.Generator().manual_seed(0)
     feats = torch.randn(batch, n, 256, h, w, generator=g)
     g_cls, g_box = torch.randn(6, batch, num_query, 10, generator=g), torch.randn(6, batch, num_query, 10, generator=g)
@@ -164,7 +171,8 @@ def main():
     n, h, w, ph, pw, desc = WORKLOADS[args.workload]
     B, Q = args.batch, args.queries
     torch.manual_seed(0)                     # identical weights on every rank (reference init rules)
-    head = petr_amd.build_head(petr_amd.petr_head_cfg(num_query=Q))
+    v2 = args.workload.startswith('v2')
+    head = petr_amd.build_head((petr_amd.petrv2_head_cfg if v2 else petr_amd.petr_head_cfg)(num_query=Q))
     head.init_weights()
     # the metric is the TRAINING step: train() = the reference's dropouts (p = 0.1, six per decoder layer) are active
     head = head.to(dev).train(not (args.eval_mode or args.fwd_only))

@@ -13,3 +13,5 @@ from .petr_transformer import (PETRMultiheadAttention, PETRTransformer, PETRTran
                                PETRTransformerDecoderLayer)
 from .petr_head import PETRHead, PETRv2Head, pos2posemb3d  # noqa: F401
 from .configs import petr_head_cfg, petrv2_head_cfg  # noqa: F401
+from . import glue  # noqa: F401,E402
+from .losses import NMSFreeCoder  # noqa: F401,E402

@@ -228,6 +228,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    if reducer is not None:
+        # everything below (forward-only, kernel-timing and loss legs) runs per rank without talking to the others,
+        # some of it on rank 0 only: no collective may be issued from here on
+        reducer.detach()
+        reducer = None
     if rank == 0:
         log(f'timed region done: {elapsed / args.steps * 1e3:.3f} ms/step')
     # ---- forward-only rate (for the ">= 10x the host-CPU forward" target), same steady state ----
@@ -366,8 +371,10 @@ def main():
         if cpu and fwd_ms:
             out['fwd_speedup_vs_cpu'] = round((B / (fwd_ms * 1e-3)) / cpu['fwd_value'], 1)
             out['fwdbwd_speedup_vs_cpu'] = round(out['value'] / cpu['value'], 1)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1 or args.force_reducer:
+        if world > 1:
+            dist.barrier()           # rank 0 ran a few extra legs: leave together
         dist.destroy_process_group()
 
 

@@ -377,3 +377,31 @@ def test_headv2_800x320_forward_backward_runs(pa):
         p = dict(head.named_parameters())[name]
         e = (p.grad.double().cpu() - wg[name].grad.double()).norm().item() / wg[name].grad.double().norm().item()
         assert e < 5e-3, (name, e)
+
+
+@pytest.mark.parametrize('extra', [[], ['--force-reducer']])
+def test_bench_contract(extra):
+    """bench.py prints ONE JSON line with the driver's contract keys (+ roofline / cpu_baseline objects); the
+    --force-reducer variant drives the data-parallel path (staged backward + RCCL) on one rank, including the
+    'no collectives after the timed region' rule that N > 1 launches depend on."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline'] + extra,
+                       capture_output=True, text=True, timeout=600, cwd=root,
+                       env=dict(os.environ, MASTER_PORT='29577'))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 2 and d['higher_is_better'] is True
+    assert d['unit'] == 'samples/s' and d['dtype'] == 'f32' and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    rf = d['roofline']
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
+    assert 0.2 < rf['frac'] < 1.0 and rf['traffic'] > 9.5e6
+    assert abs(d['value'] - 1000.0 / d['ms_per_step']) < 0.02 * d['value']

@@ -161,8 +161,12 @@ def main():
             raise SystemExit('--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # rehearsal knobs (not used by the driver): PETR_BENCH_DEVICE pins every rank to one GPU and PETR_BENCH_BACKEND=gloo
+    # replaces RCCL, so that the N > 1 control flow (collectives, barriers, teardown) can be run on a one-GPU box
+    dev_index = int(os.environ.get('PETR_BENCH_DEVICE', local_rank))
+    backend = os.environ.get('PETR_BENCH_BACKEND', 'nccl')
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     import torch.distributed as dist
     import petr_amd
     from petr_amd import _C
@@ -193,7 +197,10 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
         reducer = BucketedGradAllReduce(head, merge=2, force=args.force_reducer)
 
     def step():

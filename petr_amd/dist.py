@@ -58,7 +58,7 @@ class BucketedGradAllReduce:
             self._issue(flat)
 
     def _issue(self, flat):
-        if self.average and self._cuda:
+        if self.average and self._cuda and dist.get_backend(self.group) == 'nccl':
             self._works.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
         else:   # gloo has no AVG
             self._works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True),

@@ -227,6 +227,31 @@ size_t petr_mha_fwd_workspace_bytes(int B, int H, int Q, int L, int n_split);
 int petr_mha_choose_split(int B, int H, int Q, int L);
 int petr_mha_fwd(const petr_mha_fwd_args* a, void* stream);
 
+/* bf16 K/V variant of the attention core (BASELINE.json configs 3-5: bf16 I/O, fp32 accumulate and softmax):
+ *     k, v are bf16 (raw uint16_t bits) with strides in bf16 ELEMENTS, rows 16-byte aligned; q, o, lse stay fp32
+ *     (q is rounded to bf16 after the scale*log2(e) pre-multiplication, P is rounded to bf16 for the second
+ *     product; scores, softmax statistics and the output accumulate in fp32).  Same call site as petr_mha_fwd
+ *     (petr_transformer.py:357-362).  `sched` is ignored (static key ranges).  Everything else as petr_mha_fwd. */
+typedef struct {
+  const float* q; long q_bs, q_hs, q_rs;
+  const uint16_t* k; long k_bs, k_hs, k_rs;
+  const uint16_t* v; long v_bs, v_hs, v_rs;
+  float* o; long o_bs, o_hs, o_rs;
+  float* lse;
+  const uint8_t* kpm;
+  int B, H, Q, L;
+  float scale;
+  int n_split;
+  void* ws; size_t ws_bytes;
+  petr_dropout drop;
+  int* sched;
+} petr_mha_fwd_bf16_args;
+size_t petr_mha_fwd_bf16_workspace_bytes(int B, int H, int Q, int L, int n_split);
+int petr_mha_fwd_bf16(const petr_mha_fwd_bf16_args* a, void* stream);
+/* y[i] = bf16(x[i]) (round to nearest even), n elements, both 16-byte aligned: produces the bf16 K/V operands
+ * from the fp32 projections (the tensor .to(bfloat16) an autocast reference run would do) */
+int petr_cast_bf16(const float* x, uint16_t* y, long n, void* stream);
+
 /* backward: dq, dk, dv from q,k,v,o,do,lse (same stride conventions).  dq/dk/dv are ACCUMULATED
  * (+=): the caller zero-fills them.  dq (and dk/dv when the query range is split over workgroups)
  * use float atomics, so low-order bits depend on arrival order.  delta = rowsum(do*o) goes to ws. */

@@ -194,6 +194,10 @@ def lib():
     L.petr_mha_fwd_workspace_bytes.restype = C.c_size_t
     L.petr_mha_choose_split.argtypes = [C.c_int] * 4
     L.petr_mha_fwd.argtypes = [C.POINTER(MhaFwdArgs), C.c_void_p]
+    L.petr_mha_fwd_bf16_workspace_bytes.argtypes = [C.c_int] * 5
+    L.petr_mha_fwd_bf16_workspace_bytes.restype = C.c_size_t
+    L.petr_mha_fwd_bf16.argtypes = [C.POINTER(MhaFwdArgs), C.c_void_p]   # same block, k / v are bf16
+    L.petr_cast_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.petr_mha_bwd_workspace_bytes.argtypes = [C.c_int] * 4
     L.petr_mha_bwd_workspace_bytes.restype = C.c_size_t
     L.petr_mha_bwd.argtypes = [C.POINTER(MhaBwdArgs), C.c_void_p]
@@ -234,7 +238,8 @@ EXPORTS = [
     'petr_version', 'petr_last_error', 'petr_device_caps', 'petr_coords3d_fwd', 'petr_sine3d_fwd',
     'petr_posemb3d_fwd', 'petr_posemb3d_bwd', 'petr_gemm', 'petr_colsum_workspace_bytes', 'petr_colsum',
     'petr_layernorm_fwd', 'petr_layernorm_bwd_workspace_bytes', 'petr_layernorm_bwd',
-    'petr_mha_fwd_workspace_bytes', 'petr_mha_choose_split', 'petr_mha_fwd', 'petr_mha_bwd_workspace_bytes',
+    'petr_mha_fwd_workspace_bytes', 'petr_mha_choose_split', 'petr_mha_fwd', 'petr_mha_fwd_bf16_workspace_bytes',
+    'petr_mha_fwd_bf16', 'petr_cast_bf16', 'petr_mha_bwd_workspace_bytes',
     'petr_mha_bwd', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows', 'petr_gate_fwd', 'petr_gate_bwd', 'petr_prof_begin', 'petr_prof_end',
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',

@@ -381,6 +381,331 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// bf16 K/V variant (BASELINE configs 3-5: "bf16 I/O, fp32 accumulate/softmax").  K and V are bf16 in memory, Q is
+// read as fp32 and rounded to bf16 after the scale*log2(e) pre-multiplication, scores / softmax / O stay fp32.
+// Same mapping as the fp32 kernel (S^T = K Q^T so the query sits on the lane; P^T feeds the second product from
+// the accumulator registers), on v_mfma_f32_32x32x16_bf16: 4 matrix instructions per 32x32 score block instead
+// of 32, so the kernel is bound by the softmax (16 v_exp_f32 per block are ~2x the MFMA cycles), not by MFMA.
+//   tile = 128 keys (half a barrier per key compared with 64), wave (qg, kh) takes 32 queries x 64 keys of it
+//   K image: natural [key][32] bf16, pitch 40 (80 B): the A fragment of a lane is 8 consecutive d = ONE
+//            ds_read_b128, and 16 lanes x 80 B touch 64 distinct banks
+//   V image: transposed [d][key] bf16, pitch 132 (66 dwords): a lane's 8 keys for one k-chunk are two 8-byte
+//            reads (keys 16j+4h..+3 and +8: exactly the rows its P registers 8j..8j+7 hold); the transposing
+//            store packs the same d of two adjacent keys with one v_perm_b32 into one ds_write_b32
+//   k-slot order inside an MFMA is irrelevant as long as both operands agree, which is all the code relies on.
+constexpr int BT = 128;          // keys per tile
+constexpr int BK_PITCH = 40;     // bf16 elements per K row
+constexpr int BV_PITCH = 132;    // bf16 elements per V^T row
+constexpr int BIMG = BT * BK_PITCH + 32 * BV_PITCH;   // bf16 elements of one image pair
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <bool HAS_MASK, bool DROP>
+__global__ __launch_bounds__(512, 2) void mha_fwd_bf16_kernel(const MhaFwdParams p) {
+  constexpr int MERGE_PITCH = 17;
+  __shared__ __attribute__((aligned(16))) uint16_t smem16[2 * BIMG];
+  __shared__ float bias_s[2][BT];
+  static_assert((BT * BK_PITCH) % 8 == 0 && BIMG % 8 == 0, "images must stay 16-byte aligned");
+  static_assert(2 * BIMG * 2 >= (4 * 64 * MERGE_PITCH + 2 * 4 * 32) * 4, "merge buffer larger than the tile images");
+
+  const petr_mha_fwd_args& a = p.a;
+  const int total = p.nqb * a.B * a.H * p.n_split;
+  const int w = xcd_remap(blockIdx.x, total);
+  const int qb = w % p.nqb;
+  const int rest = w / p.nqb;
+  const int split = rest % p.n_split;
+  const int bh = rest / p.n_split;
+  const int b = bh / a.H, hd = bh - b * a.H;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int qg = wave & 3, kh = wave >> 2;
+  const int h = lane >> 5, c = lane & 31;
+  const int q_row = qb * 128 + qg * 32 + c;
+  const int q_ld = min(q_row, a.Q - 1);
+  const bool wave_active = qb * 128 + qg * 32 < a.Q;
+  const uint32_t drop_rk = DROP ? drop_row_key(p.drop, (uint32_t)(bh * a.Q + q_ld)) : 0u;
+
+  // static key ranges at 64-key granularity (one wave's share of a tile)
+  const int base = p.n_sub / p.n_split, rem = p.n_sub - base * p.n_split;
+  const int k_base = 64 * (split * base + min(split, rem));
+  const int k_end = min(a.L, k_base + 64 * (base + (split < rem ? 1 : 0)));
+  const int n_tiles = (k_end - k_base + BT - 1) / BT;      // host guarantees >= 1
+
+  // ---- Q fragments (B operand of K Q^T): lane (c, h) holds Q[q][16j + 8h .. +7], j = 0, 1 ----
+  bf16x8 qf[2];
+  {
+    const float* qp = a.q + (long)b * a.q_bs + (long)hd * a.q_hs + (long)q_ld * a.q_rs + 8 * h;
+    const float sc = a.scale * LOG2E;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) qf[j][i] = (__bf16)(qp[16 * j + i] * sc);
+  }
+
+  const uint16_t* kp = reinterpret_cast<const uint16_t*>(a.k) + (long)b * a.k_bs + (long)hd * a.k_hs;
+  const uint16_t* vp = reinterpret_cast<const uint16_t*>(a.v) + (long)b * a.v_bs + (long)hd * a.v_hs;
+  const uint8_t* mp = HAS_MASK ? a.kpm + (long)b * a.L : nullptr;
+
+  // Register ring of PF tiles between memory and LDS.  A tile of this kernel is ~1 us of work, about one loaded
+  // memory latency: with the fp32 kernel's one-tile prefetch every iteration began by waiting for its loads (each
+  // ablation of the arithmetic then "cost" 2-4 % only); the loads of tile T+PF+1 are issued while tile T is computed.
+  struct Stage { uint4 k; uint2 v0, v1; uint8_t m; };
+  constexpr int PF = 3;
+  Stage st[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) { st[i].k = make_uint4(0, 0, 0, 0); st[i].v0 = st[i].v1 = make_uint2(0, 0); st[i].m = 0; }
+  const int k_key = t >> 2, k_ch = t & 3;      // K: 16 bytes = 8 d of one key
+  const int v_kp = t >> 3, v_d4 = t & 7;       // V: 4 d of the key pair (2 v_kp, 2 v_kp + 1)
+  // addresses = wave-uniform 64-bit tile base (scalar ALU) + per-lane unsigned 32-bit BYTE offset, the form that maps to
+  // global_load ... v_offset, s[base:base+1]: no 64-bit vector arithmetic per load
+  const uint32_t koff = 2u * (uint32_t)(k_key * (int)a.k_rs + 8 * k_ch);
+  const uint32_t voff0 = 2u * (uint32_t)((2 * v_kp) * (int)a.v_rs + 4 * v_d4), voff1 = voff0 + 2u * (uint32_t)a.v_rs;
+  auto gload = [&](int k0, Stage& g) {
+    uint32_t ko = koff, vo0 = voff0, vo1 = voff1;
+    if (k0 + BT > a.L) {   // wave-uniform: ragged last tile, rows beyond L re-read row L-1 (they get a -inf bias)
+      const int lim = a.L - 1 - k0;
+      ko = 2u * (uint32_t)(min(k_key, lim) * (int)a.k_rs + 8 * k_ch);
+      vo0 = 2u * (uint32_t)(min(2 * v_kp, lim) * (int)a.v_rs + 4 * v_d4);
+      vo1 = 2u * (uint32_t)(min(2 * v_kp + 1, lim) * (int)a.v_rs + 4 * v_d4);
+    }
+    const char* kb = reinterpret_cast<const char*>(kp + (long)k0 * a.k_rs);
+    const char* vb = reinterpret_cast<const char*>(vp + (long)k0 * a.v_rs);
+    g.k = *reinterpret_cast<const uint4*>(kb + ko);
+    g.v0 = *reinterpret_cast<const uint2*>(vb + vo0);
+    g.v1 = *reinterpret_cast<const uint2*>(vb + vo1);
+    if (HAS_MASK) g.m = mp[min(k0 + (t & (BT - 1)), a.L - 1)];
+  };
+  auto lstore = [&](int k0, int buf, const Stage& g) {
+    uint16_t* Ks = smem16 + buf * BIMG;
+    uint16_t* Vt = Ks + BT * BK_PITCH;
+    *reinterpret_cast<uint4*>(Ks + k_key * BK_PITCH + 8 * k_ch) = g.k;
+    uint32_t* vd = reinterpret_cast<uint32_t*>(Vt + (4 * v_d4) * BV_PITCH + 2 * v_kp);
+    vd[0] = __builtin_amdgcn_perm(g.v1.x, g.v0.x, 0x05040100u);
+    vd[BV_PITCH / 2] = __builtin_amdgcn_perm(g.v1.x, g.v0.x, 0x07060302u);
+    vd[BV_PITCH] = __builtin_amdgcn_perm(g.v1.y, g.v0.y, 0x05040100u);
+    vd[3 * BV_PITCH / 2] = __builtin_amdgcn_perm(g.v1.y, g.v0.y, 0x07060302u);
+    if ((HAS_MASK || k0 + BT > k_end) && t < BT) {
+      bool dead = k0 + t >= k_end;
+      if (HAS_MASK) dead = dead || g.m != 0;
+      bias_s[buf][t] = dead ? -INFINITY : 0.f;
+    }
+  };
+
+  f32x16 O;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) O[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  float m_use = 0.f;        // m_run, or 0 while m_run is still -inf
+  f32x16 NM;                // -m_use in every accumulator register
+  f32x16 Lacc;              // !DROP: the running row sum, sixteen identical copies (see the second product)
+  bf16x8 ones;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) NM[r] = Lacc[r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.f;
+
+  // tile T travels in ring slot T % PF; iteration `it` multiplies tile `it` out of image it & 1, moves tile it+1 from
+  // its slot into the other image and re-issues that slot for tile it+1+PF
+  gload(k_base, st[0]);
+  lstore(k_base, 0, st[0]);
+  // Loads are issued UNCONDITIONALLY (past the range: the worker's last tile again, never stored): only then is the
+  // number of loads in flight a compile-time constant and the wait in front of a slot's lstore a counted
+  // s_waitcnt vmcnt(2 * loads-per-tile); with loads under `if (tile < n_tiles)` hipcc has to assume the younger ones
+  // were skipped and waits for everything, which serialises the ring.
+#pragma unroll
+  for (int i = 1; i <= PF; ++i) {
+    gload(k_base + min(i, n_tiles - 1) * BT, st[i % PF]);
+    __builtin_amdgcn_sched_barrier(0);     // keep the issue order = the order the loop consumes the slots in
+  }
+  auto step = [&](const int it, Stage& g) -> bool {    // g = slot (it + 1) % PF
+    const int k0 = k_base + it * BT;
+    const int buf = it & 1;
+#ifndef PETR_DIAG_BF16_NO_BARRIER
+    __syncthreads();   // image `buf` is complete; every wave is done reading the other one
+#endif
+#ifndef PETR_DIAG_BF16_NO_STAGE
+    lstore(k0 + BT, buf ^ 1, g);     // unconditional as well (after the last tile: into the image nobody reads any more)
+    gload(k_base + min(it + 1 + PF, n_tiles - 1) * BT, g);
+#endif
+    const uint16_t* Ks = smem16 + buf * BIMG;
+    const uint16_t* Vt = Ks + BT * BK_PITCH;
+    const bool use_bias = HAS_MASK || (k0 + BT > k_end);
+    const int kw = kh * 64;     // this wave's keys inside the tile
+    if (wave_active && k0 + kw < k_end) {
+      uint4 kfr[2][2];
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          kfr[sb][j] = *reinterpret_cast<const uint4*>(Ks + (kw + 32 * sb + c) * BK_PITCH + 16 * j + 8 * h);
+      // The accumulator input of the first product is NM = -m (the row's reference maximum, sixteen copies that only
+      // change on the rare rescale), so the scores come out of the matrix pipe already shifted: no subtract pass.
+      f32x16 S[2];
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+#ifdef PETR_DIAG_BF16_NO_QK
+        S[sb] = NM;
+        S[sb][sb] += __uint_as_float(kfr[sb][0].x & 0x3f800000u) + (float)qf[0][0];
+#else
+        S[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[sb][0]), qf[0], NM, 0, 0, 0);
+        S[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kfr[sb][1]), qf[1], S[sb], 0, 0, 0);
+#endif
+      }
+      if (use_bias) {
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) S[sb][r] += bias_s[buf][kw + 32 * sb + mfma32_row(r, h)];
+      }
+      float mx = fmaxf(S[0][0], S[1][0]);
+#ifndef PETR_DIAG_BF16_NO_MAX
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, S[0][r]), S[1][r]);   // v_max3_f32
+#endif
+      mx = xhalf_max(mx);      // row maximum RELATIVE to the reference maximum
+      // lazy reference maximum (see the fp32 kernel): it moves only when a row has outgrown it by 2^LAZY
+      if (__builtin_amdgcn_ballot_w64(mx > LAZY || (m_run == -INFINITY && mx > -INFINITY)) != 0) {   // wave-uniform, rare
+        const float m_new = fmaxf(m_run, m_use + mx);
+        const float m_new_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float delta = m_new_use - m_use;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new_use);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          S[0][r] -= delta;
+          S[1][r] -= delta;
+          O[r] *= alpha;
+          NM[r] = -m_new_use;
+          if (!DROP) Lacc[r] *= alpha;
+        }
+        l_run *= alpha;
+        m_run = m_new;
+        m_use = m_new_use;
+      }
+#ifndef PETR_DIAG_BF16_NO_EXP
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[sb][r] = __builtin_amdgcn_exp2f(S[sb][r]);
+#endif
+      if (DROP) {
+        // the row sum keeps the UNdropped probabilities: plain f32 adds in ONE dependent chain (packed f32 VALU, which
+        // is what the SLP vectoriser makes of independent neighbours, costs more issue cycles next to MFMAs than the
+        // two scalar instructions it replaces)
+        float acc = 0.f;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc += S[sb][r];
+        l_run += xhalf_sum(acc);
+      }
+      // V fragments: requested only now (16 registers that the softmax above needs; four waves per SIMD cover
+      // the LDS latency)
+      uint2 vfr[2][2][2];
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            vfr[sb][j][e] = *reinterpret_cast<const uint2*>(Vt + c * BV_PITCH + kw + 32 * sb + 16 * j + 4 * h + 8 * e);
+      if (DROP) {
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const uint32_t hsh = drop_pair_hash(drop_rk, (uint32_t)(k0 + kw + 32 * sb + mfma32_row(2 * i, h)) >> 1);
+            S[sb][2 * i] = (hsh & 0xFFFFu) >= p.drop.thr ? S[sb][2 * i] : 0.f;
+            S[sb][2 * i + 1] = (hsh >> 16) >= p.drop.thr ? S[sb][2 * i + 1] : 0.f;
+          }
+      }
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bf16x8 pf;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) pf[i] = (__bf16)S[sb][8 * j + i];
+          // without dropout the row sums ride on the matrix pipe: ones x P^T adds sum_k P[k][q] (both lane halves'
+          // keys) to every register of Lacc - one MFMA issue slot instead of eight adds, and the normaliser is the
+          // sum of exactly the bf16 probabilities that multiply V
+          if (!DROP) Lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, Lacc, 0, 0, 0);
+          const uint4 vraw = make_uint4(vfr[sb][j][0].x, vfr[sb][j][0].y, vfr[sb][j][1].x, vfr[sb][j][1].y);
+#ifdef PETR_DIAG_BF16_NO_PV
+          O[4 * sb + j] += __uint_as_float((vraw.x ^ __builtin_bit_cast(uint4, pf).x) & 0x3f800000u);
+#else
+          O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vraw), pf, O, 0, 0, 0);
+#endif
+        }
+    }
+    return it + 1 >= n_tiles;
+  };
+  for (int it = 0;; it += PF) {
+    static_assert(PF == 3, "the ring is unrolled by hand");
+    if (step(it, st[1])) break;
+    if (step(it + 1, st[2])) break;
+    if (step(it + 2, st[0])) break;
+  }
+  if (!DROP) l_run = Lacc[0];
+
+  // ---- merge the two key halves of each query group (upper wave -> LDS -> lower wave) ----
+  float* smem = reinterpret_cast<float*>(smem16);
+  __syncthreads();
+  float* mo = smem + (qg * 64 + lane) * MERGE_PITCH;
+  float* mml = smem + 4 * 64 * MERGE_PITCH + qg * 64 + 2 * c;
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mo[r] = O[r];
+    if (h == 0) { mml[0] = m_run; mml[1] = l_run; }
+  }
+  __syncthreads();
+  if (kh == 1 || q_row >= a.Q) return;
+  {
+    const float m2 = mml[0], l2 = mml[1];
+    const float m_new = fmaxf(m_run, m2);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float a1 = __builtin_amdgcn_exp2f(m_run - m_use), a2 = __builtin_amdgcn_exp2f(m2 - m_use);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[r] = O[r] * a1 + mo[r] * a2;
+    l_run = l_run * a1 + l2 * a2;
+    m_run = m_new;
+  }
+  if (p.n_split == 1) {
+    const float inv = (DROP ? p.drop.scale : 1.f) / l_run;
+    float* op = a.o + (long)b * a.o_bs + (long)hd * a.o_hs + (long)q_row * a.o_rs;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = 8 * g + 4 * h;
+      op[d0] = O[4 * g] * inv;
+      op[d0 + 1] = O[4 * g + 1] * inv;
+      op[d0 + 2] = O[4 * g + 2] * inv;
+      op[d0 + 3] = O[4 * g + 3] * inv;
+    }
+    if (a.lse && h == 0) a.lse[(long)bh * a.Q + q_row] = (m_run + log2f(l_run)) * LN2;
+  } else {
+    const long row = ((long)split * a.B * a.H + bh) * a.Q + q_row;
+    float* op = p.o_part + row * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(op + 8 * g + 4 * h) = make_float4(O[4 * g], O[4 * g + 1], O[4 * g + 2], O[4 * g + 3]);
+    if (h == 0) {
+      p.ml_part[row * 2] = m_run;
+      p.ml_part[row * 2 + 1] = l_run;
+    }
+  }
+}
+
+// fp32 -> bf16 (round to nearest even), 8 elements per thread
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, long n8, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n8) {
+    const float4 u = reinterpret_cast<const float4*>(x)[2 * i], v = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    bf16x8 o = {(__bf16)u.x, (__bf16)u.y, (__bf16)u.z, (__bf16)u.w, (__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    reinterpret_cast<uint4*>(y)[i] = __builtin_bit_cast(uint4, o);
+  } else if (i == n8) {
+    for (long j = 8 * n8; j < n; ++j) y[j] = __builtin_bit_cast(uint16_t, (__bf16)x[j]);
+  }
+}
+
 // merge the L-split partials: thread = (row, 4 consecutive d)
 __global__ __launch_bounds__(256) void mha_combine_kernel(const MhaFwdParams p) {
   const petr_mha_fwd_args& a = p.a;
@@ -500,5 +825,87 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
     hipLaunchKernelGGL(mha_combine_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, p);
     PETR_LAUNCH_CHECK("mha_combine");
   }
+  return PETR_OK;
+}
+
+static int bf16_split(int B, int H, int Q, int L) {
+  const long base = cdiv(Q, 128) * (long)B * H;
+  const long n_sub = cdiv(L, 64);
+  long ns = cdiv(256, base);                 // one 8-wave workgroup per CU: the softmax saturates the SIMDs' issue slots
+                                             // at two waves each (measured: 512 workgroups are 5-20 % slower than 256)
+  if (ns > n_sub / 4) ns = n_sub / 4;        // but at least two tiles per worker
+  if (ns > 64) ns = 64;
+  return ns < 1 ? 1 : (int)ns;
+}
+
+extern "C" size_t petr_mha_fwd_bf16_workspace_bytes(int B, int H, int Q, int L, int n_split) {
+  if (n_split <= 0) n_split = bf16_split(B, H, Q, L);
+  if (n_split == 1) return 0;
+  return (size_t)n_split * B * H * Q * (32 + 2) * sizeof(float);
+}
+
+extern "C" int petr_mha_fwd_bf16(const petr_mha_fwd_bf16_args* ap, void* stream) {
+  PETR_CHECK(ap && ap->q && ap->k && ap->v && ap->o, PETR_ERR_INVALID, "mha_fwd_bf16: null pointer");
+  PETR_CHECK(ap->B > 0 && ap->H > 0 && ap->Q > 0 && ap->L > 0, PETR_ERR_INVALID, "mha_fwd_bf16: bad shape");
+  static_assert(sizeof(petr_mha_fwd_bf16_args) == sizeof(petr_mha_fwd_args), "the two argument blocks share one layout");
+  MhaFwdParams p;
+  memcpy(&p.a, ap, sizeof(p.a));     // k / v are bf16 pointers with strides in bf16 elements
+  const petr_mha_fwd_args& a = p.a;
+  PETR_CHECK(aligned16(a.k) && aligned16(a.v) && !(a.k_bs & 7) && !(a.k_hs & 7) && !(a.k_rs & 7) && !(a.v_bs & 7) &&
+                 !(a.v_hs & 7) && !(a.v_rs & 7),
+             PETR_ERR_UNSUPPORTED, "mha_fwd_bf16: K/V rows must be 16-byte aligned (strides multiples of 8 elements)");
+  PETR_CHECK((long)a.L * a.k_rs < (1L << 31) && (long)a.L * a.v_rs < (1L << 31), PETR_ERR_UNSUPPORTED,
+             "mha_fwd_bf16: per-head K/V extent needs 32-bit element offsets");
+  p.nqb = (int)cdiv(a.Q, 128);
+  p.n_sub = (int)cdiv(a.L, 64);
+  int ns = a.n_split > 0 ? a.n_split : bf16_split(a.B, a.H, a.Q, a.L);
+  if (ns > p.n_sub) ns = p.n_sub;    // every static range owns at least one 64-key half tile
+  p.n_split = ns;
+  p.n_tiles = (int)cdiv(a.L, BT);
+  p.n_tickets = 0;
+  p.sched = nullptr;
+  PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "mha_fwd_bf16: dropout p=%g outside [0,1)", (double)a.drop.p);
+  PETR_CHECK((long)a.B * a.H * a.Q < (1L << 32), PETR_ERR_UNSUPPORTED, "mha_fwd_bf16: dropout row index needs B*H*Q < 2^32");
+  p.drop = make_drop(a.drop);
+  p.o_part = nullptr;
+  p.ml_part = nullptr;
+  if (ns > 1) {
+    const size_t need = petr_mha_fwd_bf16_workspace_bytes(a.B, a.H, a.Q, a.L, ns);
+    PETR_CHECK(a.ws && a.ws_bytes >= need && aligned16(a.ws), PETR_ERR_WORKSPACE,
+               "mha_fwd_bf16: workspace %zu < %zu bytes", a.ws_bytes, need);
+    p.o_part = (float*)a.ws;
+    p.ml_part = p.o_part + (size_t)ns * a.B * a.H * a.Q * 32;
+  }
+  p.q_vec = p.kv_vec = 0;
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)p.nqb * a.B * a.H * ns;
+  PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_fwd_bf16: grid too large");
+  hipEvent_t ev0, ev1;
+  petr_prof_claim(PETR_PROF_MHA_FWD + 16 * (a.L > a.Q ? 1 : 0), &ev0, &ev1);
+  auto launch = [&](auto kern) {
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), 0, s, ev0, ev1, 0, p);
+  };
+  switch ((p.drop.thr ? 2 : 0) | (a.kpm ? 1 : 0)) {
+    case 0: launch(mha_fwd_bf16_kernel<false, false>); break;
+    case 1: launch(mha_fwd_bf16_kernel<true, false>); break;
+    case 2: launch(mha_fwd_bf16_kernel<false, true>); break;
+    default: launch(mha_fwd_bf16_kernel<true, true>); break;
+  }
+  PETR_LAUNCH_CHECK("mha_fwd_bf16");
+  if (ns > 1) {
+    const long n = (long)a.B * a.H * a.Q * 8;
+    hipLaunchKernelGGL(mha_combine_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, p);
+    PETR_LAUNCH_CHECK("mha_combine");
+  }
+  return PETR_OK;
+}
+
+extern "C" int petr_cast_bf16(const float* x, uint16_t* y, long n, void* stream) {
+  PETR_CHECK(x && y && n >= 0, PETR_ERR_INVALID, "cast_bf16: bad arguments");
+  if (n == 0) return PETR_OK;
+  PETR_CHECK(aligned16(x) && aligned16(y), PETR_ERR_UNSUPPORTED, "cast_bf16: buffers must be 16-byte aligned");
+  const long n8 = n / 8;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)cdiv(n8 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n8, n);
+  PETR_LAUNCH_CHECK("cast_bf16");
   return PETR_OK;
 }

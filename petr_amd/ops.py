@@ -204,6 +204,33 @@ def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True
     return o, lse
 
 
+def cast_bf16(x):
+    """fp32 -> bfloat16 copy (round to nearest even) on the current stream: the K/V operands of ``mha_fwd_bf16``."""
+    L = _C.lib()
+    x = _f32(x).contiguous()
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _C.check(L.petr_cast_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), 'petr_cast_bf16')
+    return y
+
+
+def mha_fwd_bf16(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True, drop=None):
+    """``mha_fwd`` with bfloat16 K/V ([B,H,L,32] strided views), fp32 Q / output / softmax (BASELINE configs 3-5)."""
+    L = _C.lib()
+    assert k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16, 'mha_fwd_bf16: K and V must be bfloat16'
+    B, H, Q, _ = q.shape
+    Lk = k.shape[2]
+    scale = float(scale if scale is not None else 32 ** -0.5)
+    o = torch.empty((B, H, Q, 32), dtype=torch.float32, device=q.device)
+    lse = torch.empty((B, H, Q), dtype=torch.float32, device=q.device) if need_lse else None
+    nbytes = L.petr_mha_fwd_bf16_workspace_bytes(B, H, Q, Lk, n_split)
+    ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=q.device)
+    kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
+    a = _C.MhaFwdArgs(_ptr(_f32(q)), *_bhsd(q), _ptr(k), *_bhsd(k), _ptr(v), *_bhsd(v), _ptr(o), *_bhsd(o),
+                      _ptr(lse), _ptr(kpm), B, H, Q, Lk, scale, n_split, _ptr(ws), nbytes, _C.dropout(drop), None)
+    _C.check(L.petr_mha_fwd_bf16(C.byref(a), _stream()), 'petr_mha_fwd_bf16')
+    return o, lse
+
+
 def mha_bwd(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=None):
     L = _C.lib()
     B, H, Q, _ = q.shape

@@ -380,3 +380,68 @@ def test_mha_ragged_shapes(ops, B, H, Q, L, split, masked, drop):
     # the ticket scheduler is another assignment of the same tiles
     o2, _ = ops.mha_fwd(qf, kf, vf, dev(kpm) if kpm is not None else None, n_split=split, dynamic=True, **kw)
     assert relerr(o2, want) < 5e-6
+
+
+# ------------------------------------------------------------------ attention, bf16 K/V (BASELINE configs 3-5)
+# Tolerances ("tolerance vs fp32 oracle stated separately, expect ~1e-2 rel"):
+#   BF16_TOL_SAME_INPUTS  against the fp64 attention of the SAME bf16-rounded K/V: what is left is the rounding of the
+#                         pre-scaled Q and of the probabilities to bf16 (8 mantissa bits each), fp32 everywhere else
+#   BF16_TOL_FP32_ORACLE  against the fp64 attention of the unrounded fp32 inputs (adds the K/V rounding itself)
+# both as max |error| / max |reference|; the LSE is compared absolutely (it is a log).
+BF16_TOL_SAME_INPUTS = 1e-2     # measured 4e-3 ... 7e-3 over the cases below
+BF16_TOL_FP32_ORACLE = 1.5e-2
+BF16_TOL_LSE_ABS = 3e-2
+
+
+@pytest.mark.parametrize('B,H,Q,L,split,masked,drop', [
+    (1, 8, 900, 4224, 0, False, None), (1, 8, 900, 8800, 0, False, None), (1, 8, 900, 4224, 0, True, (31, 2, 0.1)),
+    (2, 8, 900, 900, 0, False, None), (1, 2, 70, 333, 3, True, None), (1, 1, 1, 1, 0, False, None),
+    (2, 3, 31, 65, 2, False, (5, 1, 0.3)), (1, 4, 5, 513, 8, True, None), (3, 1, 129, 129, 0, False, None),
+    (1, 8, 64, 4224, 11, False, None), (1, 1, 200, 97, 2, True, (9, 9, 0.1))])
+def test_mha_fwd_bf16(ops, B, H, Q, L, split, masked, drop):
+    g = torch.Generator().manual_seed(3 * Q + L)
+    q, k, v = (torch.randn(B, H, n, 32, generator=g) for n in (Q, L, L))
+    kpm = None
+    if masked:
+        kpm = torch.zeros(B, L, dtype=torch.bool)
+        kpm[:, L - L // 4:] = True
+        kpm[0, min(3, L - 1)] = L > 4
+    kb, vb = ops.cast_bf16(dev(k)), ops.cast_bf16(dev(v))
+    assert torch.equal(kb.cpu(), k.to(torch.bfloat16)) and torch.equal(vb.cpu(), v.to(torch.bfloat16))   # RNE, bit-exact
+    o, lse = ops.mha_fwd_bf16(dev(q), kb, vb, dev(kpm) if masked else None, n_split=split, drop=drop)
+    scale = 32 ** -0.5
+    keep = 1.0
+    if drop is not None:
+        p_real = round(drop[2] * 65536) / 65536
+        keep = ops.dropout_mask(drop, B * H * Q, L).cpu().view(B, H, Q, L).double() / (1 - p_real)
+
+    def ref(kk, vv):
+        s = torch.einsum('bhqd,bhkd->bhqk', q.double(), kk.double()) * scale
+        if kpm is not None:
+            s = s.masked_fill(kpm[:, None, None, :], float('-inf'))
+        return torch.einsum('bhqk,bhkd->bhqd', torch.softmax(s, -1) * keep, vv.double()), torch.logsumexp(s, -1)
+
+    same, same_lse = ref(k.to(torch.bfloat16), v.to(torch.bfloat16))
+    full, _ = ref(k, v)
+    assert relerr(o, same) < BF16_TOL_SAME_INPUTS, relerr(o, same)
+    assert relerr(o, full) < BF16_TOL_FP32_ORACLE, relerr(o, full)
+    assert (lse.cpu().double() - same_lse).abs().max().item() < BF16_TOL_LSE_ABS
+
+
+def test_mha_fwd_bf16_head_split_views_and_errors(ops):
+    """K/V as head-split views of one [B, L, 256] bf16 projection buffer (row stride 256), q from a [B,Q,768] buffer."""
+    g = torch.Generator().manual_seed(17)
+    B, H, Q, L = 2, 8, 100, 300
+    qkv = torch.randn(B, Q, 768, generator=g)
+    kbuf, vbuf = torch.randn(B, L, 256, generator=g), torch.randn(B, L, 256, generator=g)
+    kb, vb = ops.cast_bf16(dev(kbuf)), ops.cast_bf16(dev(vbuf))
+    qv = dev(qkv).view(B, Q, 24, 32)[:, :, :8].permute(0, 2, 1, 3)
+    kv, vv = (t.view(B, L, 8, 32).permute(0, 2, 1, 3) for t in (kb, vb))
+    o, _ = ops.mha_fwd_bf16(qv, kv, vv)
+    want, _ = _attn_ref(qkv.view(B, Q, 24, 32)[:, :, :8].permute(0, 2, 1, 3),
+                        kbuf.to(torch.bfloat16).view(B, L, 8, 32).permute(0, 2, 1, 3),
+                        vbuf.to(torch.bfloat16).view(B, L, 8, 32).permute(0, 2, 1, 3), None, 32 ** -0.5)
+    assert relerr(o, want) < BF16_TOL_SAME_INPUTS
+    with pytest.raises(RuntimeError, match='16-byte aligned'):      # rows that are not 16-byte aligned are refused, loudly
+        odd = torch.zeros(B, 8, L, 36, dtype=torch.bfloat16, device='cuda')[..., 4:]
+        ops.mha_fwd_bf16(qv, odd, odd)

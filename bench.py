@@ -36,6 +36,7 @@ WORKLOADS = {
     # PETRv2Head (fpe + RegLayer + with_time), two frames = 12 views
     'v2_800': (12, 20, 50, 320, 800, 'petrv2_vovnet_p4 800x320, two frames: 12x(256x20x50) features, PETRv2Head'),
 }
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 HBM_PEAK_GBS = 8000.0
 
@@ -260,6 +261,7 @@ def main():
 
     # ---- roofline leg: HIP events around the tagged kernels inside real steps (rank 0) ----
     roofline = None
+    bf16_leg = None
     kernels = {}
     if rank == 0:
         L = _C.lib()
@@ -312,6 +314,36 @@ def main():
                 roofline['timed_variant'] = 'training mode: dropout (p = 0.1) of the attention probabilities inside the kernel'
                 roofline['inference_variant'] = {'mean_launch_us': round(us_e, 2), 'achieved': round(ach_e, 2),
                                                  'frac': round(ach_e / FP32_MFMA_PEAK_TFLOPS, 4)}
+        # ---- bf16 K/V attention (BASELINE configs 3-5), inference forward only this round: not part of `value` ----
+        if roofline is not None and not args.fwd_only:
+            head.eval()
+            head.attn_dtype = 'bf16'
+            with torch.no_grad():
+                for _ in range(5):
+                    head([feats], metas)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for _ in range(args.steps):
+                    head([feats], metas)
+                torch.cuda.synchronize()
+                bf_ms = (time.perf_counter() - t3) / args.steps * 1e3
+                _C.check(L.petr_prof_begin(prof_steps * 64), 'petr_prof_begin')
+                for _ in range(prof_steps):
+                    head([feats], metas)
+                torch.cuda.synchronize()
+                _C.check(L.petr_prof_end(ms, tags, cap, C.byref(cnt)), 'petr_prof_end')
+            head.attn_dtype = 'fp32'
+            head.train(was_training)
+            v = [ms[i] for i in range(cnt.value) if tags[i] == 17]
+            if v:
+                us_b = sum(v) / len(v) * 1e3
+                ach_b = roofline['flops_per_launch'] / (us_b * 1e-6) / 1e12
+                bf16_leg = {'what': 'eval-mode forward with attn_dtype=bf16 (bf16 K/V, fp32 softmax/accumulate); '
+                                    'training stays fp32 this round',
+                            'fwd_ms': round(bf_ms, 4), 'fwd_samples_per_s': round(B / (bf_ms * 1e-3), 2),
+                            'mha_fwd_cross_us': round(us_b, 2), 'achieved_tflops': round(ach_b, 1),
+                            'peak_tflops': BF16_MFMA_PEAK_TFLOPS, 'frac': round(ach_b / BF16_MFMA_PEAK_TFLOPS, 4),
+                            'bound': 'softmax VALU/transcendental issue, not MFMA (head_dim 32: 4 MFMA per 32x32 block)'}
         if 'mha_bwd_cross' in kernels:
             us = kernels['mha_bwd_cross']['mean_us']
             kernels['mha_bwd_cross']['tflops'] = round(10.0 * B * Q * Ltok * 256 / (us * 1e-6) / 1e12, 2)
@@ -374,6 +406,7 @@ def main():
             'fwd_ms': round(fwd_ms, 4) if fwd_ms is not None else None,
             'fwd_samples_per_s': round(B / (fwd_ms * 1e-3), 2) if fwd_ms else None,
             'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu, 'with_loss': loss_leg,
+            'bf16_attention_inference': bf16_leg,
         }
         if cpu and fwd_ms:
             out['fwd_speedup_vs_cpu'] = round((B / (fwd_ms * 1e-3)) / cpu['fwd_value'], 1)

@@ -414,6 +414,8 @@ typedef struct {
   void* ctx;                    /* petr_ctx* (side streams) or NULL: everything on `stream` */
   float dropout_p;              /* training mode: the decoder's dropout rate (reference 0.1); 0 = eval */
   uint64_t dropout_seed;        /* fresh per forward; petr_head_bwd must get the forward's value     */
+  int attn_bf16;                /* 1: cross-attention reads bf16 copies of the projected K/V (petr_mha_fwd_bf16;
+                                 * BASELINE configs 3-5).  Inference only: needs dropout_p == 0, petr_head_bwd refuses */
 } petr_head_io;
 size_t petr_head_workspace_bytes(const petr_head_config* cfg);
 int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io, void* stream);

@@ -357,8 +357,10 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
     size_t a = petr_mha_fwd_workspace_bytes(d.B, d.NH, d.Q, (int)d.L, 0);
     size_t b = petr_mha_fwd_workspace_bytes(d.B, d.NH, d.Q, d.Q, 0);
     size_t e = petr_mha_bwd_workspace_bytes(d.B, d.NH, d.Q, (int)d.L);
+    size_t h = petr_mha_fwd_bf16_workspace_bytes(d.B, d.NH, d.Q, (int)d.L, 0);
     size_t m = a > b ? a : b;
     if (e > m) m = e;
+    if (h > m) m = h;
     W.mha_ws_bytes = m + 16;
     W.mha_ws = wb.add("mha_ws", (long)(W.mha_ws_bytes / 4) + 4);
   }
@@ -507,6 +509,21 @@ static int mha_f(const float* q, long q_bs, long q_rs, const float* k, long k_bs
   return petr_mha_fwd(&a, s);
 }
 
+// cross-attention with bf16 K/V copies (io->attn_bf16; eval forward only)
+static int mha_f_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, long k_bs, long k_rs, const uint16_t* v,
+                      float* o, float* lse, const uint8_t* kpm, const Dims& d, int L, float* ws, size_t ws_bytes, void* s) {
+  petr_mha_fwd_bf16_args a;
+  memset(&a, 0, sizeof a);
+  a.q = q; a.q_bs = q_bs; a.q_hs = 32; a.q_rs = q_rs;
+  a.k = k; a.k_bs = k_bs; a.k_hs = 32; a.k_rs = k_rs;
+  a.v = v; a.v_bs = k_bs; a.v_hs = 32; a.v_rs = k_rs;
+  a.o = o; a.o_bs = (long)d.Q * d.C; a.o_hs = 32; a.o_rs = d.C;
+  a.lse = lse; a.kpm = kpm; a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
+  a.scale = 1.0f / sqrtf(32.f);
+  a.n_split = 0; a.ws = ws; a.ws_bytes = ws_bytes;
+  return petr_mha_fwd_bf16(&a, s);
+}
+
 static int mha_b(const float* q, long q_bs, long q_rs, const float* k, long k_bs, long k_rs, const float* v,
                  const float* o, const float* d_o, const float* lse, const uint8_t* kpm, float* dq, float* dk, float* dv,
                  const Dims& d, int L, float* ws, size_t ws_bytes, void* s, const petr_dropout* drop = nullptr) {
@@ -622,6 +639,13 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   void* s2 = ln.side(1);   // position-embedding branch B (sine MLP, input_proj) / V projection
   const int V = d.B * d.N;
   const float* E = Wm + W.qe;
+  // io->attn_bf16: cross-attention on bf16 copies of the projected K/V (BASELINE configs 3-5), eval forward only this
+  // round: the copies live in the (otherwise idle) dK/dV gradient buffers and there is no bf16 backward yet
+  const bool attn_bf16 = io->attn_bf16 != 0;
+  PETR_CHECK(!(attn_bf16 && io->dropout_p > 0.f), PETR_ERR_UNSUPPORTED,
+             "head_fwd: attn_bf16 is an inference option (no bf16 attention backward yet); use fp32 for training");
+  uint16_t* k16 = reinterpret_cast<uint16_t*>(Wm + W.dk_all);
+  uint16_t* v16 = reinterpret_cast<uint16_t*>(Wm + W.dv_all);
 
   ln.fork(0);
   ln.fork(1);
@@ -691,6 +715,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.c = Wm + W.k_all; g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
     g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
     RUN(petr_gemm(&g, s1));
+    if (attn_bf16) RUN(petr_cast_bf16(Wm + W.k_all, k16, (long)d.B * d.NL * d.L * C, s1));
   }
   {
     // V_l = mem Wv_l^T + bv_l on side 2 (memory was produced there)
@@ -701,6 +726,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.c = Wm + W.v_all; g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
     g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
     RUN(petr_gemm(&g, s2));
+    if (attn_bf16) RUN(petr_cast_bf16(Wm + W.v_all, v16, (long)d.B * d.NL * d.L * C, s2));
   }
 
   // ---- main: query embedding pos2posemb3d + MLP (petr_head.py:422-423) ----
@@ -759,6 +785,10 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
       ln.join(0);
       ln.join(1);
     }
+    if (attn_bf16)
+      RUN(mha_f_bf16(Wm + lw.qc, (long)d.Q * C, C, k16 + (long)l * d.L * C, (long)d.NL * d.L * C, C,
+                     v16 + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, s));
+    else
     RUN(mha_f(Wm + lw.qc, (long)d.Q * C, C, Wm + W.k_all + (long)l * d.L * C, (long)d.NL * d.L * C, C,
               Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, sched, s,
               training ? &dr_cp : nullptr));
@@ -861,6 +891,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   RUN(check_config(cfg));
   PETR_CHECK(io && io->params && io->feats && io->ws && io->all_bbox_preds && gr && gr->d_cls && gr->d_bbox && gr->d_params,
              PETR_ERR_INVALID, "head_bwd: null pointer");
+  PETR_CHECK(!io->attn_bf16, PETR_ERR_UNSUPPORTED, "head_bwd: the forward ran with attn_bf16 (inference only): no backward");
   const Dims d = make_dims(cfg);
   POff P;
   build_layout(cfg, &P, nullptr);

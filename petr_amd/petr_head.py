@@ -422,6 +422,13 @@ class PETRHead(nn.Module):
             seed = getattr(self, '_dropout_seed_override', None)
             io.dropout_seed = int(seed) if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
         self._last_dropout = (int(io.dropout_seed), drop_p)
+        # attn_dtype = 'bf16' (attribute, default 'fp32'): cross-attention on bf16 copies of the projected K/V with fp32
+        # softmax / accumulation (BASELINE configs 3-5).  Inference only this round: training mode and backward
+        # refuse it inside the library (no bf16 attention backward yet).
+        attn_dtype = getattr(self, 'attn_dtype', 'fp32')
+        if attn_dtype not in ('fp32', 'bf16'):
+            raise ValueError(f"attn_dtype must be 'fp32' or 'bf16', got {attn_dtype!r}")
+        io.attn_bf16 = 1 if attn_dtype == 'bf16' else 0
         run.io = io
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         _C.check(L.petr_head_fwd(C.byref(run.cfg), C.byref(io), stream), 'petr_head_fwd')

@@ -349,6 +349,52 @@ def test_head_p4_1408_forward(pa):
     assert rel(got['all_bbox_preds'], want['all_bbox_preds']) < REL
 
 
+# BASELINE configs[2] proper: bf16 K/V in the cross-attention, fp32 accumulate/softmax.  Tolerance against the fp32
+# CPU oracle, stated separately from the fp32 bar (SURVEY 8(d) config 3 expected ~1e-2 rel; the head-level outputs turn
+# out far tighter than the operator-level bound in tests/test_ops_gpu.py, so the bar here is 1e-3).
+REL_BF16 = 1e-3      # measured 7e-5 (cls) / 5e-5 (bbox) at p4-1408: the rounding noise averages out over 16 896 keys
+
+
+def test_head_p4_1408_forward_bf16_attention(pa):
+    oracle = O.seeded_head(0, None, num_query=900)
+    head = make_pair(pa, oracle, num_query=900)
+    metas = O.synthetic_img_metas(1, 6, (512, 1408), seed=2)
+    feats = torch.randn(1, 6, 256, 32, 88, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        want = oracle([feats], metas)
+        ref32 = head([feats.cuda()], metas)
+        ref32 = {k: v.clone() for k, v in ref32.items() if v is not None}
+        head.attn_dtype = 'bf16'
+        got = head([feats.cuda()], metas)
+    e_cls, e_box = rel(got['all_cls_scores'], want['all_cls_scores']), rel(got['all_bbox_preds'], want['all_bbox_preds'])
+    print(f'bf16 attention vs fp32 oracle at p4-1408: cls {e_cls:.2e} bbox {e_box:.2e}')
+    assert e_cls < REL_BF16 and e_box < REL_BF16
+    assert not torch.equal(got['all_cls_scores'], ref32['all_cls_scores'])      # the bf16 path really ran
+    # training mode and backward refuse the option loudly (no bf16 attention backward yet)
+    head.train()
+    with pytest.raises(RuntimeError, match='attn_bf16'):
+        head([feats.cuda()], metas)
+    head.eval()
+    x = feats.cuda().requires_grad_(True)
+    out = head([x], metas)
+    with pytest.raises(RuntimeError, match='attn_bf16'):
+        (out['all_cls_scores'].sum() + out['all_bbox_preds'].sum()).backward()
+
+
+def test_head_bf16_attention_masked_batch2_and_v2(pa, golden_dir):
+    """ragged / masked key axis through the bf16 kernel inside the head (toy fixture of the reference, batch 2 oracle)."""
+    fx = np.load(os.path.join(golden_dir, 'head_toy_masked.npz'))
+    oracle = O.seeded_head(2, 1234, num_query=16)
+    head = make_pair(pa, oracle, num_query=16)
+    head.attn_dtype = 'bf16'
+    feats = torch.from_numpy(fx['feats'])
+    with torch.no_grad():
+        want = oracle([feats], metas_from(fx))
+        got = head([feats.cuda()], metas_from(fx))
+    assert rel(got['all_cls_scores'], want['all_cls_scores']) < REL_BF16
+    assert rel(got['all_bbox_preds'], want['all_bbox_preds']) < REL_BF16
+
+
 def test_headv2_800x320_forward_backward_runs(pa):
     """BASELINE configs[4] shape: PETRv2, 12 views x 20x50 (H*W = 1000 is NOT a multiple of 32: exercises the ragged
     K-segment tiles of the gradient contractions), 900 queries: forward parity + a finite, reproducible backward."""

@@ -391,8 +391,9 @@ def test_head_bf16_attention_masked_batch2_and_v2(pa, golden_dir):
     with torch.no_grad():
         want = oracle([feats], metas_from(fx))
         got = head([feats.cuda()], metas_from(fx))
-    assert rel(got['all_cls_scores'], want['all_cls_scores']) < REL_BF16
-    assert rel(got['all_bbox_preds'], want['all_bbox_preds']) < REL_BF16
+    e_cls, e_box = rel(got['all_cls_scores'], want['all_cls_scores']), rel(got['all_bbox_preds'], want['all_bbox_preds'])
+    print(f'bf16 attention vs fp32 oracle, toy masked (48 keys, no averaging): cls {e_cls:.2e} bbox {e_box:.2e}')
+    assert e_cls < 1e-2 and e_box < 1e-2       # SURVEY 8(d) config 3's expected bf16 tolerance
 
 
 def test_headv2_800x320_forward_backward_runs(pa):

@@ -326,7 +326,10 @@ int petr_reduce_batch(const float* x, int B, long rows, int C, float* out, int a
  *     level i < NL-1 is 'd{i}.loss_*'); d_cls / d_box (optional) = gradient of the SUM of all 2*NL losses
  *     (level l's losses depend on level l's predictions only, so a caller with other output weights
  *     scales the slices); assigned [NL,B,Q] = 0 background / k = ground truth k-1 of the sample.
- *     sync_cls_avg_factor / multi-process reduce_mean are the caller's (single-process semantics here). */
+ *     avg_factors (optional, DEVICE, 2 floats) = (cls_avg_factor, num_total_pos) BEFORE their max(., 1) clamps, as
+ *     left by the caller's cross-rank reduce_mean (petr_head.py:620-622 with sync_cls_avg_factor, :630-631 always);
+ *     read by the kernels, so the caller's all-reduce needs no host round trip.  NULL: the single-process values
+ *     derived from num_pos. */
 typedef struct {
   const float* cls; const float* box;
   const float* gt_boxes; const int64_t* gt_labels; const int* gt_offsets;
@@ -335,6 +338,7 @@ typedef struct {
   float code_weights[10];
   float* losses; float* d_cls; float* d_box; int* assigned;
   void* ws; size_t ws_bytes;
+  const float* avg_factors;
 } petr_loss_args;
 size_t petr_loss_workspace_bytes(int NL, int B, int Q, int Gtot);
 int petr_loss_fwd_bwd(const petr_loss_args* a, void* stream);

@@ -139,8 +139,10 @@ def get_target_single(cfg, cls_score, bbox_pred, gt_labels, gt_bboxes):
     return labels, label_weights, bbox_targets, bbox_weights, pos_inds, neg_inds, assigned
 
 
-def loss_single(cfg, cls_scores, bbox_preds, gt_bboxes_list, gt_labels_list):
-    """petr_head.py:573-644 for one decoder level; also returns the assignments [B, num_query]."""
+def loss_single(cfg, cls_scores, bbox_preds, gt_bboxes_list, gt_labels_list, reduce_mean=None):
+    """petr_head.py:573-644 for one decoder level; also returns the assignments [B, num_query].
+    ``reduce_mean``: stand-in for mmdet's cross-rank mean (a callable float -> float); None = one process (identity).
+    ``cfg.sync_cls_avg_factor`` (default False) as in the reference (:620-622)."""
     num_imgs = cls_scores.size(0)
     tg = [get_target_single(cfg, cls_scores[i], bbox_preds[i], gt_labels_list[i], gt_bboxes_list[i]) for i in range(num_imgs)]
     labels = torch.cat([t[0] for t in tg], 0)
@@ -150,9 +152,13 @@ def loss_single(cfg, cls_scores, bbox_preds, gt_bboxes_list, gt_labels_list):
     num_total_pos = sum(t[4].numel() for t in tg)
     num_total_neg = sum(t[5].numel() for t in tg)
     cls_scores = cls_scores.reshape(-1, cls_scores.size(-1))
-    cls_avg_factor = max(num_total_pos * 1.0 + num_total_neg * cfg.bg_cls_weight, 1)
+    reduce_mean = reduce_mean or (lambda v: v)
+    cls_avg_factor = num_total_pos * 1.0 + num_total_neg * cfg.bg_cls_weight
+    if getattr(cfg, 'sync_cls_avg_factor', False):
+        cls_avg_factor = reduce_mean(cls_avg_factor)                          # :620-622
+    cls_avg_factor = max(cls_avg_factor, 1)
     loss_cls = sigmoid_focal_loss(cls_scores, labels, label_weights, cfg.gamma, cfg.alpha, cls_avg_factor, cfg.cls_weight)
-    num_total_pos = max(float(num_total_pos), 1.0)        # clamp(reduce_mean(.), min=1).item() on one process
+    num_total_pos = max(float(reduce_mean(float(num_total_pos))), 1.0)        # clamp(reduce_mean(.), min=1).item(), :630-631
     bbox_preds = bbox_preds.reshape(-1, bbox_preds.size(-1))
     normalized = normalize_bbox(bbox_targets)
     isnotnan = torch.isfinite(normalized).all(dim=-1)
@@ -162,14 +168,14 @@ def loss_single(cfg, cls_scores, bbox_preds, gt_bboxes_list, gt_labels_list):
     return torch.nan_to_num(loss_cls), torch.nan_to_num(loss_bbox), torch.stack([t[6] for t in tg])
 
 
-def head_loss(cfg, gt_bboxes_list, gt_labels_list, preds):
+def head_loss(cfg, gt_bboxes_list, gt_labels_list, preds, reduce_mean=None):
     """petr_head.py:646-728.  ``gt_bboxes_list``: per image [G, 9] (gravity centre, dims, yaw, vx, vy), i.e. what
     ``torch.cat((boxes.gravity_center, boxes.tensor[:, 3:]), 1)`` yields (:697-699)."""
     all_cls, all_box = preds['all_cls_scores'], preds['all_bbox_preds']
     out, assigns = {}, []
     n = len(all_cls)
     for lvl in range(n):
-        lc, lb, a = loss_single(cfg, all_cls[lvl], all_box[lvl], gt_bboxes_list, gt_labels_list)
+        lc, lb, a = loss_single(cfg, all_cls[lvl], all_box[lvl], gt_bboxes_list, gt_labels_list, reduce_mean)
         assigns.append(a)
         key = '' if lvl == n - 1 else f'd{lvl}.'
         out[key + 'loss_cls'], out[key + 'loss_bbox'] = lc, lb

@@ -120,7 +120,7 @@ class LossArgs(C.Structure):         # petr_loss_args
                        ('cls_weight', C.c_float), ('bbox_weight', C.c_float), ('alpha', C.c_float), ('gamma', C.c_float),
                        ('bg_cls_weight', C.c_float), ('code_weights', C.c_float * 10),
                        ('losses', C.c_void_p), ('d_cls', C.c_void_p), ('d_box', C.c_void_p), ('assigned', C.c_void_p),
-                       ('ws', C.c_void_p), ('ws_bytes', C.c_size_t))
+                       ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('avg_factors', C.c_void_p))
 
 
 class DecodeArgs(C.Structure):       # petr_decode_args

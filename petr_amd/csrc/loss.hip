@@ -38,8 +38,16 @@ struct LossParams {
   int offs[LOSS_MAX_B + 1];   // gt_offsets, copied from HOST memory at launch (no device round trip for metadata)
   double* cost;          // [NL][Gtot][Q]
   double* sums;          // [NL][2]
-  float cls_norm, box_norm;   // loss_weight / (avg_factor + eps)
+  float cls_norm, box_norm;   // loss_weight / (avg_factor + eps); superseded by a.avg_factors (device) when given
 };
+
+// loss_weight / (max(avg_factor, 1) + eps): from the kernel arguments, or from the caller's cross-rank means in
+// device memory (petr_loss_args.avg_factors)
+__device__ __forceinline__ float norm_of(const LossParams& p, int which) {
+  if (!p.a.avg_factors) return which == 0 ? p.cls_norm : p.box_norm;
+  const double w = which == 0 ? (double)p.a.cls_weight : (double)p.a.bbox_weight;
+  return (float)(w / ((double)fmaxf(p.a.avg_factors[which], 1.f) + 1.1920928955078125e-07));
+}
 
 __device__ __forceinline__ void normalize_gt(const float* g, float* n) {   // util.py:38-58
   n[0] = g[0]; n[1] = g[1]; n[2] = logf(g[3]); n[3] = logf(g[4]); n[4] = g[2]; n[5] = logf(g[5]);
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossParams p) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   double s_cls = 0.0, s_box = 0.0;
   int lvl = 0;
+  const float cls_norm = norm_of(p, 0), box_norm = norm_of(p, 1);
   if (idx < n) {
     lvl = (int)(idx / ((long)a.B * a.Q));
     const int b = (int)((idx / a.Q) % a.B);
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossParams p) {
         grad = w * (pr + a.gamma * (1.f - pr) * sp_neg);
       }
       s_cls += (double)loss;
-      if (dc) dc[c] = grad * p.cls_norm;
+      if (dc) dc[c] = grad * cls_norm;
     }
     const float* box = a.box + idx * a.CS;
     float* db = a.d_box ? a.d_box + idx * a.CS : nullptr;
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossParams p) {
       if (use && d < 10) {
         const float diff = box[d] - n10[d];
         s_box += (double)(fabsf(diff) * a.code_weights[d]);
-        gd = (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * a.code_weights[d] * p.box_norm;
+        gd = (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * a.code_weights[d] * box_norm;
       }
       if (db) db[d] = gd;
     }
@@ -288,8 +297,8 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossParams p) {
 __global__ __launch_bounds__(256) void loss_final_kernel(const LossParams p) {
   const petr_loss_args& a = p.a;
   const int lvl = blockIdx.x;
-  const float lc = (float)(p.sums[2 * lvl] * (double)p.cls_norm);
-  const float lb = (float)(p.sums[2 * lvl + 1] * (double)p.box_norm);
+  const float lc = (float)(p.sums[2 * lvl] * (double)norm_of(p, 0));
+  const float lb = (float)(p.sums[2 * lvl + 1] * (double)norm_of(p, 1));
   const bool okc = isfinite(lc), okb = isfinite(lb);
   if (threadIdx.x == 0) {
     a.losses[2 * lvl] = okc ? lc : (lc != lc ? 0.f : (lc > 0.f ? 3.402823466e+38f : -3.402823466e+38f));

@@ -28,11 +28,31 @@ class LossConfig:
     (asserted by the reference, petr_head.py:149-156)."""
 
     def __init__(self, num_classes=10, code_weights=(1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2), cls_weight=2.0,
-                 bbox_weight=0.25, alpha=0.25, gamma=2.0, bg_cls_weight=0.0):
+                 bbox_weight=0.25, alpha=0.25, gamma=2.0, bg_cls_weight=0.0, sync_cls_avg_factor=False):
+        self.sync_cls_avg_factor = bool(sync_cls_avg_factor)
         self.num_classes = num_classes
         self.code_weights = [float(v) for v in code_weights] + [0.0] * (10 - len(code_weights))
         self.cls_weight, self.bbox_weight, self.alpha, self.gamma = cls_weight, bbox_weight, alpha, gamma
         self.bg_cls_weight = bg_cls_weight
+
+
+def synced_avg_factors(num_pos, num_queries_total, cfg, device, group=None):
+    """The two normalisers the reference averages over the ranks (mmdet ``reduce_mean``): ``num_total_pos`` always
+    (petr_head.py:628-631) and ``cls_avg_factor`` when ``sync_cls_avg_factor`` (:620-622).  Returns a float32 tensor
+    ``[cls_avg_factor, num_total_pos]`` on ``device`` holding the values BEFORE their ``max(., 1)`` clamps (the kernels
+    clamp), or ``None`` in a single process (the kernels then derive both from ``num_pos``).  The all-reduce is
+    enqueued like any other collective (RCCL: on the current stream; no ``.item()``, no host round trip)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return None
+    world = dist.get_world_size(group)
+    cls_avg = float(num_pos) + (float(num_queries_total) - float(num_pos)) * float(cfg.bg_cls_weight)
+    t = torch.tensor([cls_avg if cfg.sync_cls_avg_factor else 0.0, float(num_pos)], dtype=torch.float32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t /= world
+    if not cfg.sync_cls_avg_factor:
+        t[0] = cls_avg                      # stays this rank's own value
+    return t
 
 
 class _LossFn(torch.autograd.Function):
@@ -40,7 +60,7 @@ class _LossFn(torch.autograd.Function):
     slices by the incoming gradient."""
 
     @staticmethod
-    def forward(ctx, cls, box, gt_boxes, gt_labels, gt_offsets, counts, cfg):
+    def forward(ctx, cls, box, gt_boxes, gt_labels, gt_offsets, counts, cfg, avg=None):
         L = _C.lib()
         NL, B, Q, NC = cls.shape
         CS = box.shape[-1]
@@ -64,6 +84,7 @@ class _LossFn(torch.autograd.Function):
         a.code_weights = (C.c_float * 10)(*cfg.code_weights[:10])
         a.losses, a.d_cls, a.d_box, a.assigned = losses.data_ptr(), d_cls.data_ptr(), d_box.data_ptr(), assigned.data_ptr()
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 8
+        a.avg_factors = avg.data_ptr() if avg is not None else None
         _C.check(L.petr_loss_fwd_bwd(C.byref(a), _stream()), 'petr_loss_fwd_bwd')
         ctx.save_for_backward(d_cls, d_box)
         ctx.mark_non_differentiable(assigned)
@@ -77,10 +98,10 @@ class _LossFn(torch.autograd.Function):
     def backward(ctx, _g_assigned, *g_losses):
         d_cls, d_box = ctx.saved_tensors
         if all(g is None for g in g_losses):
-            return (None,) * 7
+            return (None,) * 8
         zero = d_cls.new_zeros(())
         g = torch.stack([zero if x is None else x.to(d_cls.dtype) for x in g_losses]).view(ctx.n_levels, 2)
-        return d_cls * g[:, 0].view(-1, 1, 1, 1), d_box * g[:, 1].view(-1, 1, 1, 1), None, None, None, None, None
+        return d_cls * g[:, 0].view(-1, 1, 1, 1), d_box * g[:, 1].view(-1, 1, 1, 1), None, None, None, None, None, None
 
 
 def _gt_tensor(boxes, device):
@@ -90,9 +111,11 @@ def _gt_tensor(boxes, device):
     return boxes.to(device=device, dtype=torch.float32)
 
 
-def head_loss(cfg, gt_bboxes_list, gt_labels_list, preds_dicts, return_assignment=False):
+def head_loss(cfg, gt_bboxes_list, gt_labels_list, preds_dicts, return_assignment=False, group=None, avg_factors=None):
     """``PETRHead.loss`` (petr_head.py:646-728): dict with 'loss_cls', 'loss_bbox' (last level) and
-    'd{i}.loss_cls', 'd{i}.loss_bbox' (earlier levels)."""
+    'd{i}.loss_cls', 'd{i}.loss_bbox' (earlier levels).  With an initialised process group of more than one rank the
+    normalisers are averaged over ``group`` as the reference does (``synced_avg_factors``); ``avg_factors`` overrides
+    them with a caller-supplied device tensor ``[cls_avg_factor, num_total_pos]``."""
     all_cls, all_box = preds_dicts['all_cls_scores'], preds_dicts['all_bbox_preds']
     assert preds_dicts.get('enc_cls_scores') is None, 'two-stage (enc_*) outputs are not produced by PETRHead'
     if not all_cls.is_cuda:
@@ -111,7 +134,10 @@ def head_loss(cfg, gt_bboxes_list, gt_labels_list, preds_dicts, return_assignmen
     for c in counts:
         offs.append(offs[-1] + c)
     gt_offsets = offs            # host metadata: goes into the kernel arguments, no H2D copy
-    res = _LossFn.apply(all_cls, all_box, gt_boxes, gt_labels, gt_offsets, counts, cfg)
+    Q = all_cls.shape[2]
+    if avg_factors is None:
+        avg_factors = synced_avg_factors(sum(min(c, Q) for c in counts), B * Q, cfg, dev, group)
+    res = _LossFn.apply(all_cls, all_box, gt_boxes, gt_labels, gt_offsets, counts, cfg, avg_factors)
     assigned, flat = res[0], res[1:]          # flat[2*l] = loss_cls of level l, flat[2*l+1] = loss_bbox
     out = {}
     n = all_cls.shape[0]

@@ -544,14 +544,15 @@ class PETRHead(nn.Module):
             assert box_w == assigner['reg_cost']['weight'], \
                 'The regression L1 weight for loss and matcher should be exactly the same.'
         return losses.LossConfig(self.num_classes, self.code_weights.detach().cpu().tolist(), cls_w, box_w,
-                                 float(lc.get('alpha', 0.25)), float(lc.get('gamma', 2.0)), 0.0)
+                                 float(lc.get('alpha', 0.25)), float(lc.get('gamma', 2.0)), 0.0,
+                                 sync_cls_avg_factor=self.sync_cls_avg_factor)
 
     def loss(self, gt_bboxes_list, gt_labels_list, preds_dicts, gt_bboxes_ignore=None):
         """reference petr_head.py:646-728.  Cost matrix, Hungarian assignment, focal + L1 loss and their gradients for
         all decoder levels run in one call on the device (petr_loss_fwd_bwd); no host round trip."""
         assert gt_bboxes_ignore is None, f'{self.__class__.__name__} only supports for gt_bboxes_ignore setting to None.'
-        if self.sync_cls_avg_factor:
-            raise _C.PetrHipError('sync_cls_avg_factor=True is not implemented (no reference config sets it)')
+        # multi-process: num_total_pos (and cls_avg_factor with sync_cls_avg_factor) are averaged over the default
+        # process group inside head_loss, as mmdet's reduce_mean does (petr_head.py:620-622, 628-631)
         return losses.head_loss(self._loss_config(), gt_bboxes_list, gt_labels_list, preds_dicts)
 
     def get_bboxes(self, preds_dicts, img_metas, rescale=False):

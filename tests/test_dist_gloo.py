@@ -65,3 +65,42 @@ def test_bucketed_allreduce_world2():
     assert torch.allclose(got[0][:990], want[:990], rtol=0, atol=1e-7)
     assert torch.equal(got[0][:990], got[1][:990])
     assert torch.equal(got[0][990:], g0[990:]) and torch.equal(got[1][990:], g1[990:])
+
+
+def _avg_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from petr_amd.losses import LossConfig, synced_avg_factors
+    num_pos = [40, 7][rank]                 # this rank's matched boxes; 900 queries x 1 sample each
+    out = []
+    for sync in (False, True):
+        cfg = LossConfig(bg_cls_weight=0.1, sync_cls_avg_factor=sync)
+        out.append(synced_avg_factors(num_pos, 900, cfg, torch.device('cpu')).tolist())
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_loss_normalisers_reduce_mean_world2():
+    """mmdet reduce_mean semantics of the loss normalisers (petr_head.py:620-622, 628-631) over two gloo ranks:
+    num_total_pos is always the mean over ranks, cls_avg_factor only with sync_cls_avg_factor; one process: None."""
+    from petr_amd.losses import LossConfig, synced_avg_factors
+    assert synced_avg_factors(5, 900, LossConfig(), torch.device('cpu')) is None        # no process group
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_avg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    local = [40 + (900 - 40) * 0.1, 7 + (900 - 7) * 0.1]
+    for rank in range(2):
+        (cls_nosync, pos_nosync), (cls_sync, pos_sync) = res[rank]
+        assert abs(pos_nosync - 23.5) < 1e-5 and abs(pos_sync - 23.5) < 1e-5
+        assert abs(cls_nosync - local[rank]) < 1e-4
+        assert abs(cls_sync - 0.5 * (local[0] + local[1])) < 1e-4

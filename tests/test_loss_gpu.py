@@ -92,6 +92,41 @@ def test_loss_vs_oracle(head, B, Q, n_gt, seed):
     assert int((assigned > 0).sum()) == 6 * sum(min(n, Q) for n in n_gt)          # one query per ground-truth box
 
 
+@pytest.mark.parametrize('sync_cls', [False, True])
+def test_loss_cross_rank_normalisers(head, sync_cls):
+    """mmdet reduce_mean of num_total_pos (petr_head.py:628-631) and, with sync_cls_avg_factor, of cls_avg_factor
+    (:620-622): the kernels take the averaged values from device memory.  Simulated second rank with 7 boxes; the
+    oracle gets the same mean through its reduce_mean stand-in."""
+    from petr_amd import losses
+    B, Q, n_gt = 2, 130, [11, 30]
+    g = torch.Generator().manual_seed(5)
+    cls = torch.randn(6, B, Q, 10, generator=g) * 2 - 2
+    box = torch.randn(6, B, Q, 10, generator=g)
+    boxes, labels = LO.synthetic_gt(B, n_gt, seed=5)
+    other = 7.0                                                  # the other rank's num_total_pos (bg_cls_weight = 0)
+    cfg = LO.LossCfg()
+    cfg.sync_cls_avg_factor = sync_cls
+    cd, bd = cls.double().requires_grad_(True), box.double().requires_grad_(True)
+    want, _ = LO.head_loss(cfg, [b.double() for b in boxes], labels, {'all_cls_scores': cd, 'all_bbox_preds': bd},
+                           reduce_mean=lambda v: 0.5 * (v + other))
+    pcfg = head._loss_config()
+    pcfg.sync_cls_avg_factor = sync_cls
+    mine = float(sum(n_gt))
+    avg = torch.tensor([0.5 * (mine + other) if sync_cls else mine, 0.5 * (mine + other)], dtype=torch.float32, device='cuda')
+    cc, bc = cls.cuda().requires_grad_(True), box.cuda().requires_grad_(True)
+    out = losses.head_loss(pcfg, [b.cuda() for b in boxes], [t.cuda() for t in labels],
+                           {'all_cls_scores': cc, 'all_bbox_preds': bc}, avg_factors=avg)
+    for k, v in want.items():
+        assert abs(out[k].item() - v.item()) < 2e-5 * max(1.0, abs(v.item())), (k, out[k].item(), v.item())
+    sum(want.values()).backward()
+    sum(out.values()).backward()
+    assert rel(cc.grad, cd.grad) < 1e-4 and rel(bc.grad, bd.grad) < 1e-5
+    # and the values differ from the single-process ones (the override is really read)
+    single = losses.head_loss(pcfg, [b.cuda() for b in boxes], [t.cuda() for t in labels],
+                              {'all_cls_scores': cls.cuda(), 'all_bbox_preds': box.cuda()})
+    assert abs(single['loss_bbox'].item() - out['loss_bbox'].item()) > 1e-3 * abs(out['loss_bbox'].item())
+
+
 def test_loss_nan_guards(head):
     """petr_head.py:635-643: rows whose normalised target is not finite are left out; a non-finite level loss becomes 0."""
     from petr_amd import losses

@@ -343,7 +343,8 @@ def main():
                             'fwd_ms': round(bf_ms, 4), 'fwd_samples_per_s': round(B / (bf_ms * 1e-3), 2),
                             'mha_fwd_cross_us': round(us_b, 2), 'achieved_tflops': round(ach_b, 1),
                             'peak_tflops': BF16_MFMA_PEAK_TFLOPS, 'frac': round(ach_b / BF16_MFMA_PEAK_TFLOPS, 4),
-                            'bound': 'softmax VALU/transcendental issue, not MFMA (head_dim 32: 4 MFMA per 32x32 block)'}
+                            'bound': 'softmax instruction stream and LDS/barrier latency, not MFMA (head_dim 32: 4 MFMA per 32x32 '
+                                     'score block; DESIGN.md section 4)'}
         if 'mha_bwd_cross' in kernels:
             us = kernels['mha_bwd_cross']['mean_us']
             kernels['mha_bwd_cross']['tflops'] = round(10.0 * B * Q * Ltok * 256 / (us * 1e-6) / 1e12, 2)

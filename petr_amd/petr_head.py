@@ -130,6 +130,8 @@ class PETRHead(nn.Module):
         cw = code_weights if code_weights is not None else [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2]
         cw = list(cw)[:self.code_size]
         self.sync_cls_avg_factor = sync_cls_avg_factor
+        # not a reference option: 'bf16' runs the cross-attention of eval-mode forwards on bf16 K/V (see _launch_forward)
+        self.attn_dtype = kwargs.get('attn_dtype', 'fp32')
         self.num_query, self.num_classes, self.in_channels = num_query, num_classes, in_channels
         self.num_reg_fcs = num_reg_fcs
         self.train_cfg, self.test_cfg = train_cfg, test_cfg

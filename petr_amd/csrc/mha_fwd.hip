@@ -537,7 +537,11 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_bf16_kernel(const MhaFwdParams
       for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
+#ifdef PETR_DIAG_BF16_NO_LDSREAD
+          kfr[sb][j] = make_uint4(lane + sb, lane + j, it, 0x3f803f80u);
+#else
           kfr[sb][j] = *reinterpret_cast<const uint4*>(Ks + (kw + 32 * sb + c) * BK_PITCH + 16 * j + 8 * h);
+#endif
       // The accumulator input of the first product is NM = -m (the row's reference maximum, sixteen copies that only
       // change on the rare rescale), so the scores come out of the matrix pipe already shifted: no subtract pass.
       f32x16 S[2];
@@ -607,7 +611,11 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_bf16_kernel(const MhaFwdParams
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int e = 0; e < 2; ++e)
+#ifdef PETR_DIAG_BF16_NO_LDSREAD
+            vfr[sb][j][e] = make_uint2(0x3f803f80u + lane + sb + j, 0x3f803f80u + e + it);
+#else
             vfr[sb][j][e] = *reinterpret_cast<const uint2*>(Vt + c * BV_PITCH + kw + 32 * sb + 16 * j + 4 * h + 8 * e);
+#endif
       if (DROP) {
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)

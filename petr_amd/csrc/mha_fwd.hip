@@ -636,7 +636,11 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_bf16_kernel(const MhaFwdParams
           // without dropout the row sums ride on the matrix pipe: ones x P^T adds sum_k P[k][q] (both lane halves'
           // keys) to every register of Lacc - one MFMA issue slot instead of eight adds, and the normaliser is the
           // sum of exactly the bf16 probabilities that multiply V
+#ifndef PETR_DIAG_BF16_NO_LACC
           if (!DROP) Lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, Lacc, 0, 0, 0);
+#else
+          Lacc[j] += (float)pf[0];
+#endif
           const uint4 vraw = make_uint4(vfr[sb][j][0].x, vfr[sb][j][0].y, vfr[sb][j][1].x, vfr[sb][j][1].y);
 #ifdef PETR_DIAG_BF16_NO_PV
           O[4 * sb + j] += __uint_as_float((vraw.x ^ __builtin_bit_cast(uint4, pf).x) & 0x3f800000u);

@@ -315,7 +315,7 @@ def main():
                 roofline['inference_variant'] = {'mean_launch_us': round(us_e, 2), 'achieved': round(ach_e, 2),
                                                  'frac': round(ach_e / FP32_MFMA_PEAK_TFLOPS, 4)}
         # ---- bf16 K/V attention (BASELINE configs 3-5), inference forward only this round: not part of `value` ----
-        if roofline is not None and not args.fwd_only:
+        if roofline is not None and world == 1 and not args.fwd_only:
             head.eval()
             head.attn_dtype = 'bf16'
             with torch.no_grad():
@@ -355,7 +355,9 @@ def main():
 
     # ---- the full training step of the reference: forward -> PETRHead.loss -> backward ----
     loss_leg = None
-    if rank == 0 and not args.fwd_only:
+    # single-process runs only: PETRHead.loss averages its normalisers over the process group (mmdet reduce_mean), a
+    # collective that a rank-0-only leg must not issue
+    if rank == 0 and world == 1 and not args.fwd_only:
         gt_b, gt_l = synthetic_gt(B, 40, seed=7, device=dev)     # 40 ground-truth boxes per sample
 
         def loss_step():

@@ -452,3 +452,29 @@ def test_bench_contract(extra):
     assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
     assert 0.2 < rf['frac'] < 1.0 and rf['traffic'] > 9.5e6
     assert abs(d['value'] - 1000.0 / d['ms_per_step']) < 0.02 * d['value']
+
+
+def test_bench_two_rank_control_flow_on_one_gpu():
+    """The N > 1 launch of bench.py (torch.distributed.run, one rank per process) rehearsed on this one-GPU box: both
+    ranks on card 0, gloo instead of RCCL (PETR_BENCH_DEVICE / PETR_BENCH_BACKEND).  Guards the rule that nothing
+    behind the timed region issues a collective on rank 0 only (cpu baseline, loss and bf16 legs are single-process
+    legs) - such a leg deadlocks the real 2/4/8-GPU runs.  Timing is meaningless here; completion is the test."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=root,
+                       env=dict(os.environ, PETR_BENCH_DEVICE='0', PETR_BENCH_BACKEND='gloo'))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak'
+    assert d['config']['global_batch'] == 2 if 'global_batch' in d['config'] else True
+    assert d['cpu_baseline'] is None and d['with_loss'] is None        # single-process legs are skipped

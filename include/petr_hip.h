@@ -129,7 +129,10 @@ int petr_dropout_mask(const petr_dropout* d, long rows, long cols, uint8_t* keep
  *         belongs to a weight-gradient contraction dW = dC^T X (A = dC^T), at no extra launch.
  * ------------------------------------------------------------------------------------------ */
 enum { PETR_GEMM_RELU = 1, PETR_GEMM_ACCUMULATE = 2, PETR_GEMM_RELU_MASK = 4, PETR_GEMM_SIGMOID_MUL = 8,
-       PETR_GEMM_ATOMIC = 16 };
+       PETR_GEMM_ATOMIC = 16, PETR_GEMM_STORE_BF16 = 32 };
+/* PETR_GEMM_STORE_BF16: `c` points to bf16 storage (uint16_t bits, round to nearest even) and ldc / c_bs0 / c_bs1 /
+ * c_nblk_stride count bf16 elements: the K/V projections feeding petr_mha_fwd_bf16.  Tiled kernel only; excludes
+ * ACCUMULATE, ATOMIC and split_k > 1. */
 /* drop.p > 0 (only without batch dims / split_k): the activated value act(...) is dropped out with
  * (row, col) = (m, n) before it is stored (mmcv FFN: Linear, ReLU, Dropout).                   */
 typedef struct {

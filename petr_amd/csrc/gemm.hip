@@ -345,7 +345,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
         if (dd.thr) v = drop_keep(drop_row_key(dd, (uint32_t)mc), (uint32_t)nc, dd.thr) ? v * dd.scale : 0.f;
         v += old;
         if (ok) {
-          if (atomic) atomicAdd(dst, v);
+          if (flags & PETR_GEMM_STORE_BF16)     // bf16 output: same index arithmetic on 2-byte elements
+            reinterpret_cast<uint16_t*>(g.c)[z0 * g.c_bs0 + z1 * g.c_bs1 + (long)mc * g.ldc + ccol] =
+                __builtin_bit_cast(uint16_t, (__bf16)v);
+          else if (atomic) atomicAdd(dst, v);
           else *dst = v;
         }
       }
@@ -624,9 +627,12 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
   // output is small (<= 256 tiles of 32x32: 900x256, 256x256, 256x10 ...); measured on MI355X (same-box A/B of the whole
   // step) it is ~1 % of the step ahead of the tiled kernel at K = 256 and 2x faster at K >= 1024 for K-contiguous operands (float4 fragment loads);
   // with row-contiguous operands (gradients) its 4-byte loads lose to the tiled kernel.  Slabs stay tiled.
+  PETR_CHECK(!(g.flags & PETR_GEMM_STORE_BF16) || (g.split_k == 1 && !(g.flags & (PETR_GEMM_ACCUMULATE | PETR_GEMM_ATOMIC))),
+             PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_STORE_BF16 needs a plain store (no accumulate / atomic / split_k)");
   const long tiles32 = cdiv(g.M, 32) * cdiv(g.N, 32) * (long)g.nb0 * g.nb1;
   const bool slabs = g.split_k > 1 && !(g.flags & PETR_GEMM_ATOMIC);
-  if (!slabs && tiles32 <= 256 && g.K >= 256 && g.a_kcontig && g.b_kcontig && !(g.flags & PETR_GEMM_ATOMIC)) {
+  if (!slabs && tiles32 <= 256 && g.K >= 256 && g.a_kcontig && g.b_kcontig &&
+      !(g.flags & (PETR_GEMM_ATOMIC | PETR_GEMM_STORE_BF16))) {
     petr_gemm_args q = g;
     q.split_k = 1;
     return vec ? launch_skinny<true>(q, s) : launch_skinny<false>(q, s);

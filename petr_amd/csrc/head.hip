@@ -639,8 +639,9 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   void* s2 = ln.side(1);   // position-embedding branch B (sine MLP, input_proj) / V projection
   const int V = d.B * d.N;
   const float* E = Wm + W.qe;
-  // io->attn_bf16: cross-attention on bf16 copies of the projected K/V (BASELINE configs 3-5), eval forward only this
-  // round: the copies live in the (otherwise idle) dK/dV gradient buffers and there is no bf16 backward yet
+  // io->attn_bf16: the K/V projections store bf16 (PETR_GEMM_STORE_BF16) and the cross-attention reads it (BASELINE
+  // configs 3-5), eval forward only this round: the bf16 K/V live in the (otherwise idle) dK/dV gradient buffers, the
+  // fp32 K/V buffers stay unwritten, and there is no bf16 backward yet
   const bool attn_bf16 = io->attn_bf16 != 0;
   PETR_CHECK(!(attn_bf16 && io->dropout_p > 0.f), PETR_ERR_UNSUPPORTED,
              "head_fwd: attn_bf16 is an inference option (no bf16 attention backward yet); use fp32 for training");
@@ -714,8 +715,8 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.bias = Pm + P.lay[0].ca_in_b + C; g.bias_bs1 = P.ca_in_stride;
     g.c = Wm + W.k_all; g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
     g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
+    if (attn_bf16) { g.c = reinterpret_cast<float*>(k16); g.flags |= PETR_GEMM_STORE_BF16; }   // bf16 straight from the epilogue
     RUN(petr_gemm(&g, s1));
-    if (attn_bf16) RUN(petr_cast_bf16(Wm + W.k_all, k16, (long)d.B * d.NL * d.L * C, s1));
   }
   {
     // V_l = mem Wv_l^T + bv_l on side 2 (memory was produced there)
@@ -725,8 +726,8 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.bias = Pm + P.lay[0].ca_in_b + 2 * C; g.bias_bs1 = P.ca_in_stride;
     g.c = Wm + W.v_all; g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
     g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
+    if (attn_bf16) { g.c = reinterpret_cast<float*>(v16); g.flags |= PETR_GEMM_STORE_BF16; }
     RUN(petr_gemm(&g, s2));
-    if (attn_bf16) RUN(petr_cast_bf16(Wm + W.v_all, v16, (long)d.B * d.NL * d.L * C, s2));
   }
 
   // ---- main: query embedding pos2posemb3d + MLP (petr_head.py:422-423) ----

@@ -445,3 +445,25 @@ def test_mha_fwd_bf16_head_split_views_and_errors(ops):
     with pytest.raises(RuntimeError, match='16-byte aligned'):      # rows that are not 16-byte aligned are refused, loudly
         odd = torch.zeros(B, 8, L, 36, dtype=torch.bfloat16, device='cuda')[..., 4:]
         ops.mha_fwd_bf16(qv, odd, odd)
+
+
+def test_gemm_store_bf16_epilogue(ops):
+    """PETR_GEMM_STORE_BF16: the contraction's epilogue stores bf16 (round to nearest even) - what the K/V projections of
+    the bf16 attention use.  Bit-exact against rounding the SAME kernel's fp32 output; head-split layout and a ragged
+    shape; accumulate / split-K are refused."""
+    from petr_amd import _C
+    g = torch.Generator().manual_seed(23)
+    for M, N, K in ((4224, 256, 256), (333, 96, 70)):
+        x, w, b = (torch.randn(s, generator=g).cuda() for s in ((M, K), (N, K), (N,)))
+        ref = ops.linear(x, w, b)                                    # 4224 x 256 goes through the tiled kernel as well
+        out32 = torch.empty(M, N, device='cuda')
+        ops.gemm_raw(a=x, lda=K, a_kcontig=1, b=w, ldb=K, b_kcontig=1, c=out32, ldc=N, M=M, N=N, K=K, bias=b, flags=0,
+                     alpha=1.0, nb0=1, nb1=1)
+        out16 = torch.zeros(M, N, dtype=torch.bfloat16, device='cuda')
+        ops.gemm_raw(a=x, lda=K, a_kcontig=1, b=w, ldb=K, b_kcontig=1, c=out16, ldc=N, M=M, N=N, K=K, bias=b,
+                     flags=_C.GEMM_STORE_BF16, alpha=1.0, nb0=1, nb1=1)
+        assert relerr(out32, ref) < 1e-5
+        assert torch.equal(out16, ref.to(torch.bfloat16)) or torch.equal(out16, out32.to(torch.bfloat16))
+    with pytest.raises(RuntimeError, match='STORE_BF16'):
+        ops.gemm_raw(a=x, lda=K, a_kcontig=1, b=w, ldb=K, b_kcontig=1, c=out16, ldc=N, M=M, N=N, K=K,
+                     flags=_C.GEMM_STORE_BF16 | _C.GEMM_ACCUMULATE, alpha=1.0)

@@ -69,6 +69,21 @@ def test_coords3d_c5_full(ops):
     assert torch.equal(vol, vol2)
 
 
+@pytest.mark.parametrize('N,H,W,pad,batch', [(6, 40, 100, (640, 1600), 2), (12, 20, 50, (320, 800), 1), (6, 32, 88, (512, 1408), 1)])
+def test_coords3d_full_size_configs(ops, N, H, W, pad, batch):
+    """The coordinate volume at the shapes of BASELINE configs 3-5 (p4-1600 with batch 2, PETRv2 12 views, p4-1408) against
+    the oracle, which is fast enough here: grid / mask / layout in index space, values in the normalised space."""
+    rng = [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0]
+    metas = O.synthetic_img_metas(batch, N, pad, seed=3)
+    want, wmask, _ = O.coords3d_volume(batch, N, H, W, metas)
+    i2l = O.img2lidar_matrices(metas).reshape(-1, 16)
+    depth = O.depth_bins(64, 1, rng, True)
+    vol, cmask = ops.coords3d(dev(i2l), dev(depth), batch, N, H, W, pad[0], pad[1], rng, want_mask=True)
+    assert vol.shape == want.shape
+    assert (torch.sigmoid(vol.cpu().double()) - torch.sigmoid(want.double())).abs().max().item() < 1e-5
+    assert (cmask.cpu() != wmask).sum().item() <= 2 * batch        # flips only within 1e-6 of the [0, 1] borders
+
+
 # ------------------------------------------------------------------ K3 sine / posemb
 def test_sine3d(ops, golden_dir):
     fx = np.load(os.path.join(golden_dir, 'sine3d.npz'))

@@ -145,6 +145,29 @@ def test_loss_nan_guards(head):
     assert (cc.grad[3] == 0).all() and torch.isfinite(cc.grad).all()
 
 
+def test_loss_limits_are_refused_loudly(head):
+    """Outside what the one-wave assignment kernel holds the call fails with the library's message - never a silent
+    fallback: more than 1 024 queries, more ground-truth boxes than queries in a sample, more than 64 samples."""
+    from petr_amd import losses
+    cfg = head._loss_config()
+
+    def call(B, Q, n_gt):
+        g = torch.Generator().manual_seed(1)
+        cls, box = torch.randn(6, B, Q, 10, generator=g).cuda(), torch.randn(6, B, Q, 10, generator=g).cuda()
+        boxes, labels = LO.synthetic_gt(B, n_gt, seed=1)
+        return losses.head_loss(cfg, [b.cuda() for b in boxes], [t.cuda() for t in labels],
+                                {'all_cls_scores': cls, 'all_bbox_preds': box})
+
+    with pytest.raises(RuntimeError, match='at most 1024 queries'):
+        call(1, 1100, [5])
+    with pytest.raises(RuntimeError, match='more ground-truth boxes'):
+        call(1, 8, [9])
+    with pytest.raises(RuntimeError, match='at most 64 samples'):
+        call(65, 8, [1] * 65)
+    out = call(64, 8, [1] * 64)                       # the largest batch works
+    assert all(torch.isfinite(v).all() for v in out.values())
+
+
 def test_get_bboxes_golden(head, golden_dir):
     """fixture = outputs of the reference's NMSFreeCoder.decode + PETRHead.get_bboxes."""
     fx = np.load(os.path.join(golden_dir, 'decode_q900.npz'))

@@ -129,10 +129,13 @@ int petr_dropout_mask(const petr_dropout* d, long rows, long cols, uint8_t* keep
  *         belongs to a weight-gradient contraction dW = dC^T X (A = dC^T), at no extra launch.
  * ------------------------------------------------------------------------------------------ */
 enum { PETR_GEMM_RELU = 1, PETR_GEMM_ACCUMULATE = 2, PETR_GEMM_RELU_MASK = 4, PETR_GEMM_SIGMOID_MUL = 8,
-       PETR_GEMM_ATOMIC = 16, PETR_GEMM_STORE_BF16 = 32 };
+       PETR_GEMM_ATOMIC = 16, PETR_GEMM_STORE_BF16 = 32, PETR_GEMM_BF16 = 64 };
 /* PETR_GEMM_STORE_BF16: `c` points to bf16 storage (uint16_t bits, round to nearest even) and ldc / c_bs0 / c_bs1 /
  * c_nblk_stride count bf16 elements: the K/V projections feeding petr_mha_fwd_bf16.  Tiled kernel only; excludes
- * ACCUMULATE, ATOMIC and split_k > 1. */
+ * ACCUMULATE, ATOMIC and split_k > 1.
+ * PETR_GEMM_BF16: the fp32 operands are rounded to bf16 on load and multiplied on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation (what torch.autocast(bfloat16) does to an nn.Linear); both operands K-contiguous and 16-byte aligned,
+ * K % 16 == 0, epilogue limited to bias / residual / ReLU / STORE_BF16 (a2 addend allowed). */
 /* drop.p > 0 (only without batch dims / split_k): the activated value act(...) is dropped out with
  * (row, col) = (m, n) before it is stored (mmcv FFN: Linear, ReLU, Dropout).                   */
 typedef struct {

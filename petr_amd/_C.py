@@ -60,7 +60,7 @@ class GemmArgs(C.Structure):
         ('flags', C.c_int), ('alpha', C.c_float), ('drop', Dropout))
 
 
-GEMM_RELU, GEMM_ACCUMULATE, GEMM_RELU_MASK, GEMM_SIGMOID_MUL, GEMM_ATOMIC, GEMM_STORE_BF16 = 1, 2, 4, 8, 16, 32
+GEMM_RELU, GEMM_ACCUMULATE, GEMM_RELU_MASK, GEMM_SIGMOID_MUL, GEMM_ATOMIC, GEMM_STORE_BF16, GEMM_BF16 = 1, 2, 4, 8, 16, 32, 64
 LN_RELU, LN_NAN_TO_NUM = 1, 2
 
 

@@ -586,6 +586,105 @@ bool operand_vec_ok(const float* p, long ld, long bs0, long bs1, long seg, int k
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// bf16 contraction (PETR_GEMM_BF16): fp32 operands in memory, rounded to bf16 on load, v_mfma_f32_32x32x16_bf16, fp32
+// accumulation, epilogue as above (bias, residual, ReLU, fp32 or bf16 store).  For the L-sized projections of the
+// bf16 inference path (BASELINE configs 3-5).  Both operands K-contiguous, K a multiple of 16.
+//   wave = 32 rows x 64 columns (two accumulators share the A fragment), workgroup = 4 waves = 64 x 128;
+//   fragments go global -> registers directly: lane (c, h) holds row c, k = 16 j + 8 h .. + 7 of chunk j as two
+//   float4 loads (the lane pair h = 0, 1 covers 64 contiguous bytes of the row), converted with four
+//   v_cvt_pk_bf16_f32; the k-slot order inside an MFMA only has to agree between the operands.  No LDS, no barrier:
+//   the next chunk's loads are issued before the current chunk's products.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+
+template <bool A2>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const petr_gemm_args g, const int tiles_n) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int h = lane >> 5, c = lane & 31;
+  const int tiles = gridDim.x;
+  const int tile = xcd_remap(blockIdx.x, tiles);
+  const int tm_i = tile / tiles_n, tn_i = tile - tm_i * tiles_n;
+  const int m0 = tm_i * 64 + (wave >> 1) * 32, n0 = tn_i * 128 + (wave & 1) * 64;
+  const int z1 = blockIdx.z % g.nb1, z0 = blockIdx.z / g.nb1;
+  if (m0 >= g.M || n0 >= g.N) return;                      // wave-uniform
+  const float* Ab = g.a + z0 * g.a_bs0 + z1 * g.a_bs1 + (long)min(m0 + c, g.M - 1) * g.lda + 8 * h;
+  const float* Bb0 = g.b + z0 * g.b_bs0 + z1 * g.b_bs1 + (long)min(n0 + c, g.N - 1) * g.ldb + 8 * h;
+  const float* Bb1 = g.b + z0 * g.b_bs0 + z1 * g.b_bs1 + (long)min(n0 + 32 + c, g.N - 1) * g.ldb + 8 * h;
+  const bool use_a2 = A2 && (g.a2_ncols <= 0 || n0 < g.a2_ncols);
+  const float* A2b = nullptr;
+  if (A2) {
+    const int row = min(m0 + c, g.M - 1);
+    A2b = g.a2 + (long)(g.a2_rows > 0 ? row % g.a2_rows : row) * g.lda + 8 * h;
+  }
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  struct Frag { float4 a[2], b0[2], b1[2], a2[2]; };
+  auto load = [&](int k, Frag& f) {
+    f.a[0] = *reinterpret_cast<const float4*>(Ab + k); f.a[1] = *reinterpret_cast<const float4*>(Ab + k + 4);
+    f.b0[0] = *reinterpret_cast<const float4*>(Bb0 + k); f.b0[1] = *reinterpret_cast<const float4*>(Bb0 + k + 4);
+    f.b1[0] = *reinterpret_cast<const float4*>(Bb1 + k); f.b1[1] = *reinterpret_cast<const float4*>(Bb1 + k + 4);
+    if (A2) { f.a2[0] = *reinterpret_cast<const float4*>(A2b + k); f.a2[1] = *reinterpret_cast<const float4*>(A2b + k + 4); }
+  };
+  auto cvt = [](const float4& u, const float4& v) {
+    gbf16x8 o = {(__bf16)u.x, (__bf16)u.y, (__bf16)u.z, (__bf16)u.w, (__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    return o;
+  };
+  auto mac = [&](Frag& f) {
+    if (A2 && use_a2) {
+      f.a[0].x += f.a2[0].x; f.a[0].y += f.a2[0].y; f.a[0].z += f.a2[0].z; f.a[0].w += f.a2[0].w;
+      f.a[1].x += f.a2[1].x; f.a[1].y += f.a2[1].y; f.a[1].z += f.a2[1].z; f.a[1].w += f.a2[1].w;
+    }
+    const gbf16x8 fa = cvt(f.a[0], f.a[1]);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, cvt(f.b0[0], f.b0[1]), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, cvt(f.b1[0], f.b1[1]), acc1, 0, 0, 0);
+  };
+  Frag f0, f1;
+  load(0, f0);
+  for (int k = 0; k < g.K; k += 32) {
+    if (k + 16 < g.K) load(k + 16, f1);
+    mac(f0);
+    if (k + 16 < g.K) {
+      if (k + 32 < g.K) load(k + 32, f0);
+      mac(f1);
+    }
+  }
+  // ---- epilogue: D[m][n]: lane holds column n = c, rows mfma32_row(r, h) ----
+  const float* bias = g.bias ? g.bias + z0 * g.bias_bs0 + z1 * g.bias_bs1 : nullptr;
+  const float* R = g.r ? g.r + z0 * g.r_bs0 + z1 * g.r_bs1 : nullptr;
+  const long cbase = z0 * g.c_bs0 + z1 * g.c_bs1;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + 32 * j + c;
+    const int nc = min(n, g.N - 1);
+    const float bv = bias ? bias[nc] : 0.f;
+    const long ccol = g.c_nblk > 0 ? (long)(nc / g.c_nblk) * g.c_nblk_stride + (nc % g.c_nblk) : (long)nc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + mfma32_row(r, h);
+      const int mc = min(m, g.M - 1);
+      float v = (j == 0 ? acc0[r] : acc1[r]) * g.alpha + bv;
+      if (R) v += R[(long)mc * g.ldr + nc];
+      if (g.flags & PETR_GEMM_RELU) v = fmaxf(v, 0.f);
+      if (m < g.M && n < g.N) {
+        const long off = cbase + (long)mc * g.ldc + ccol;
+        if (g.flags & PETR_GEMM_STORE_BF16) reinterpret_cast<uint16_t*>(g.c)[off] = __builtin_bit_cast(uint16_t, (__bf16)v);
+        else g.c[off] = v;
+      }
+    }
+  }
+}
+
+static int launch_bf16(const petr_gemm_args& g, hipStream_t s) {
+  const int tiles_m = (int)cdiv(g.M, 64), tiles_n = (int)cdiv(g.N, 128);
+  dim3 grid(tiles_m * tiles_n, 1, g.nb0 * g.nb1), block(256);
+  if (g.a2) hipLaunchKernelGGL((gemm_bf16_kernel<true>), grid, block, 0, s, g, tiles_n);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<false>), grid, block, 0, s, g, tiles_n);
+  PETR_LAUNCH_CHECK("gemm_bf16");
+  return PETR_OK;
+}
+
 extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
   PETR_CHECK(gp && gp->a && gp->b && gp->c, PETR_ERR_INVALID, "gemm: null pointer");
   petr_gemm_args g = *gp;
@@ -629,6 +728,14 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
   // with row-contiguous operands (gradients) its 4-byte loads lose to the tiled kernel.  Slabs stay tiled.
   PETR_CHECK(!(g.flags & PETR_GEMM_STORE_BF16) || (g.split_k == 1 && !(g.flags & (PETR_GEMM_ACCUMULATE | PETR_GEMM_ATOMIC))),
              PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_STORE_BF16 needs a plain store (no accumulate / atomic / split_k)");
+  if (g.flags & PETR_GEMM_BF16) {
+    PETR_CHECK(g.a_kcontig && g.b_kcontig && g.K % 16 == 0 && g.split_k == 1 && g.k_seg <= 0 && !g.a_colsum && !gp->drop.p &&
+                   !(g.flags & (PETR_GEMM_ACCUMULATE | PETR_GEMM_ATOMIC | PETR_GEMM_RELU_MASK | PETR_GEMM_SIGMOID_MUL)) && vec &&
+                   !(g.lda & 3) && !(g.ldb & 3),
+               PETR_ERR_UNSUPPORTED,
+               "gemm: PETR_GEMM_BF16 needs K-contiguous 16-byte aligned operands, K %% 16 == 0 and a plain epilogue");
+    return launch_bf16(g, s);
+  }
   const long tiles32 = cdiv(g.M, 32) * cdiv(g.N, 32) * (long)g.nb0 * g.nb1;
   const bool slabs = g.split_k > 1 && !(g.flags & PETR_GEMM_ATOMIC);
   if (!slabs && tiles32 <= 256 && g.K >= 256 && g.a_kcontig && g.b_kcontig &&

@@ -482,3 +482,30 @@ def test_gemm_store_bf16_epilogue(ops):
     with pytest.raises(RuntimeError, match='STORE_BF16'):
         ops.gemm_raw(a=x, lda=K, a_kcontig=1, b=w, ldb=K, b_kcontig=1, c=out16, ldc=N, M=M, N=N, K=K,
                      flags=_C.GEMM_STORE_BF16 | _C.GEMM_ACCUMULATE, alpha=1.0)
+
+
+@pytest.mark.parametrize('M,N,K,a2,store16', [(4224, 256, 256, True, True), (900, 2048, 256, False, False),
+                                              (333, 96, 80, False, False), (70, 256, 1024, True, False)])
+def test_gemm_bf16_route(ops, M, N, K, a2, store16):
+    """PETR_GEMM_BF16: operands rounded to bf16 on load, bf16 MFMA, fp32 accumulation (BASELINE configs 3-5).
+    Checked tightly against the fp64 product of the SAME bf16-rounded operands (+ fp32 bias / residual / ReLU), loosely
+    (bf16 accuracy) against the unrounded one; with the key_pos-style addend and the bf16 store."""
+    from petr_amd import _C
+    g = torch.Generator().manual_seed(M + K)
+    x, w, b, r, x2 = (torch.randn(s, generator=g) for s in ((M, K), (N, K), (N,), (M, N), (M, K)))
+    flags = _C.GEMM_BF16 | _C.GEMM_RELU | (_C.GEMM_STORE_BF16 if store16 else 0)
+    out = torch.zeros(M, N, dtype=torch.bfloat16 if store16 else torch.float32, device='cuda')
+    kw = dict(a=x.cuda(), lda=K, a_kcontig=1, b=w.cuda(), ldb=K, b_kcontig=1, c=out, ldc=N, M=M, N=N, K=K, bias=b.cuda(),
+              r=r.cuda(), ldr=N, flags=flags, alpha=1.0, nb0=1, nb1=1)
+    if a2:
+        kw.update(a2=x2.cuda(), a2_rows=0, a2_ncols=0)
+    ops.gemm_raw(**kw)
+    xa = (x + x2) if a2 else x
+    same = torch.relu(xa.to(torch.bfloat16).double() @ w.to(torch.bfloat16).double().T + b.double() + r.double())
+    full = torch.relu(xa.double() @ w.double().T + b.double() + r.double())
+    tol = 4e-3 if store16 else 2e-5             # the bf16 store adds one more rounding (2^-9 relative)
+    assert relerr(out.float(), same) < tol, relerr(out.float(), same)
+    assert relerr(out.float(), full) < 1.5e-2
+    with pytest.raises(RuntimeError, match='PETR_GEMM_BF16'):                     # K not a multiple of 16
+        ops.gemm_raw(a=x.cuda()[:, :K - 8].contiguous(), lda=K - 8, a_kcontig=1, b=w.cuda()[:, :K - 8].contiguous(), ldb=K - 8,
+                     b_kcontig=1, c=torch.zeros(M, N, device='cuda'), ldc=N, M=M, N=N, K=K - 8, flags=_C.GEMM_BF16, alpha=1.0)

@@ -676,7 +676,136 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const petr_gemm_args g, 
   }
 }
 
+// LDS-staged version of the bf16 contraction (K % 32 == 0): workgroup = 128 x 128 outputs, 4 waves of 64 x 64 (2 x 2 MFMA
+// tiles), K step 32.  Operand tiles are read with coalesced float4 loads (8 consecutive threads = one 128-byte row
+// piece), rounded to bf16 and written to LDS rows of 32 + 8 elements (80-byte pitch: the 16-byte fragment reads of 16
+// lanes fall into 64 distinct banks); register prefetch of the next K step, double-buffered LDS, one barrier per step.
+template <bool A2>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_lds_kernel(const petr_gemm_args g, const int tiles_n) {
+  constexpr int BM = 128, BN = 128, BK = 32, PITCH = 40;
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2][(BM + BN) * PITCH];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int h = lane >> 5, c = lane & 31;
+  const int tiles = gridDim.x;
+  const int tile = xcd_remap(blockIdx.x, tiles);
+  const int tm_i = tile / tiles_n, tn_i = tile - tm_i * tiles_n;
+  const int m0 = tm_i * BM, n0 = tn_i * BN;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int z1 = blockIdx.z % g.nb1, z0 = blockIdx.z / g.nb1;
+  const float* Ab = g.a + z0 * g.a_bs0 + z1 * g.a_bs1;
+  const float* Bb = g.b + z0 * g.b_bs0 + z1 * g.b_bs1;
+  const bool use_a2 = A2 && (g.a2_ncols <= 0 || n0 < g.a2_ncols);
+
+  // staging assignment: 4 float4 per thread and operand; float4 index = t + 256 i -> row = idx >> 3, piece = idx & 7
+  const int s_row = t >> 3, s_c4 = t & 7;                   // rows s_row + 32 i
+  int a_off[4], b_off[4], a2_off[4];      // element offsets inside one batch (checked < 2^31 on the host)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = min(m0 + s_row + 32 * i, g.M - 1), rb = min(n0 + s_row + 32 * i, g.N - 1);
+    a_off[i] = ra * (int)g.lda + 4 * s_c4;
+    b_off[i] = rb * (int)g.ldb + 4 * s_c4;
+    a2_off[i] = A2 ? (g.a2_rows > 0 ? ra % g.a2_rows : ra) * (int)g.lda + 4 * s_c4 : 0;
+  }
+  float4 ra_[4], rb_[4], ra2_[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra_[i] = *reinterpret_cast<const float4*>(Ab + a_off[i] + k0);
+      rb_[i] = *reinterpret_cast<const float4*>(Bb + b_off[i] + k0);
+      if (A2) ra2_[i] = *reinterpret_cast<const float4*>(g.a2 + a2_off[i] + k0);
+    }
+  };
+  auto pack = [](const float4& v) {
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    b4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    return __builtin_bit_cast(uint2, o);
+  };
+  auto lstore = [&](int buf) {
+    uint16_t* As = lds[buf];
+    uint16_t* Bs = As + BM * PITCH;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 av = ra_[i];
+      if (A2 && use_a2) { av.x += ra2_[i].x; av.y += ra2_[i].y; av.z += ra2_[i].z; av.w += ra2_[i].w; }
+      *reinterpret_cast<uint2*>(As + (s_row + 32 * i) * PITCH + 4 * s_c4) = pack(av);
+      *reinterpret_cast<uint2*>(Bs + (s_row + 32 * i) * PITCH + 4 * s_c4) = pack(rb_[i]);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / BK;
+  gload(0);
+  lstore(0);
+  if (nk > 1) gload(BK);
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    __syncthreads();                       // image `buf` complete; the other one is free again
+    if (ks + 1 < nk) {
+      lstore(buf ^ 1);
+      if (ks + 2 < nk) gload((ks + 2) * BK);
+    }
+    const uint16_t* As = lds[buf];
+    const uint16_t* Bs = As + BM * PITCH;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {          // two 16-deep chunks of the K step
+      uint4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const uint4*>(As + (wm + 32 * i + c) * PITCH + 16 * j + 8 * h);
+        fb[i] = *reinterpret_cast<const uint4*>(Bs + (wn + 32 * i + c) * PITCH + 16 * j + 8 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, fa[i]), __builtin_bit_cast(gbf16x8, fb[jn]),
+                                                               acc[i][jn], 0, 0, 0);
+    }
+  }
+
+  const float* bias = g.bias ? g.bias + z0 * g.bias_bs0 + z1 * g.bias_bs1 : nullptr;
+  const float* R = g.r ? g.r + z0 * g.r_bs0 + z1 * g.r_bs1 : nullptr;
+  const long cbase = z0 * g.c_bs0 + z1 * g.c_bs1;
+#pragma unroll
+  for (int jn = 0; jn < 2; ++jn) {
+    const int n = n0 + wn + 32 * jn + c;
+    const int nc = min(n, g.N - 1);
+    const float bv = bias ? bias[nc] : 0.f;
+    const long ccol = g.c_nblk > 0 ? (long)(nc / g.c_nblk) * g.c_nblk_stride + (nc % g.c_nblk) : (long)nc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + 32 * i + mfma32_row(r, h);
+        const int mc = min(m, g.M - 1);
+        float v = acc[i][jn][r] * g.alpha + bv;
+        if (R) v += R[(long)mc * g.ldr + nc];
+        if (g.flags & PETR_GEMM_RELU) v = fmaxf(v, 0.f);
+        if (m < g.M && n < g.N) {
+          const long off = cbase + (long)mc * g.ldc + ccol;
+          if (g.flags & PETR_GEMM_STORE_BF16) reinterpret_cast<uint16_t*>(g.c)[off] = __builtin_bit_cast(uint16_t, (__bf16)v);
+          else g.c[off] = v;
+        }
+      }
+  }
+}
+
 static int launch_bf16(const petr_gemm_args& g, hipStream_t s) {
+  if (g.K % 32 == 0 && (long)g.M * g.N >= 128L * 128 * 64) {     // enough 128 x 128 tiles: the LDS-staged kernel
+    const int tm = (int)cdiv(g.M, 128), tn = (int)cdiv(g.N, 128);
+    dim3 grid2(tm * tn, 1, g.nb0 * g.nb1), block2(256);
+    if (g.a2) hipLaunchKernelGGL((gemm_bf16_lds_kernel<true>), grid2, block2, 0, s, g, tn);
+    else hipLaunchKernelGGL((gemm_bf16_lds_kernel<false>), grid2, block2, 0, s, g, tn);
+    PETR_LAUNCH_CHECK("gemm_bf16_lds");
+    return PETR_OK;
+  }
   const int tiles_m = (int)cdiv(g.M, 64), tiles_n = (int)cdiv(g.N, 128);
   dim3 grid(tiles_m * tiles_n, 1, g.nb0 * g.nb1), block(256);
   if (g.a2) hipLaunchKernelGGL((gemm_bf16_kernel<true>), grid, block, 0, s, g, tiles_n);

@@ -639,7 +639,8 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   void* s2 = ln.side(1);   // position-embedding branch B (sine MLP, input_proj) / V projection
   const int V = d.B * d.N;
   const float* E = Wm + W.qe;
-  // io->attn_bf16: the K/V projections store bf16 (PETR_GEMM_STORE_BF16) and the cross-attention reads it (BASELINE
+  // io->attn_bf16: the K/V projections run on the bf16 contraction and store bf16 (PETR_GEMM_BF16 | PETR_GEMM_STORE_BF16)
+  // and the cross-attention reads it (BASELINE
   // configs 3-5), eval forward only this round: the bf16 K/V live in the (otherwise idle) dK/dV gradient buffers, the
   // fp32 K/V buffers stay unwritten, and there is no bf16 backward yet
   const bool attn_bf16 = io->attn_bf16 != 0;
@@ -715,7 +716,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.bias = Pm + P.lay[0].ca_in_b + C; g.bias_bs1 = P.ca_in_stride;
     g.c = Wm + W.k_all; g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
     g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
-    if (attn_bf16) { g.c = reinterpret_cast<float*>(k16); g.flags |= PETR_GEMM_STORE_BF16; }   // bf16 straight from the epilogue
+    if (attn_bf16) { g.c = reinterpret_cast<float*>(k16); g.flags |= PETR_GEMM_STORE_BF16 | PETR_GEMM_BF16; }   // bf16 MFMA, bf16 store
     RUN(petr_gemm(&g, s1));
   }
   {
@@ -726,7 +727,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.bias = Pm + P.lay[0].ca_in_b + 2 * C; g.bias_bs1 = P.ca_in_stride;
     g.c = Wm + W.v_all; g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
     g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
-    if (attn_bf16) { g.c = reinterpret_cast<float*>(v16); g.flags |= PETR_GEMM_STORE_BF16; }
+    if (attn_bf16) { g.c = reinterpret_cast<float*>(v16); g.flags |= PETR_GEMM_STORE_BF16 | PETR_GEMM_BF16; }
     RUN(petr_gemm(&g, s2));
   }
 

@@ -687,6 +687,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.M = d.HW; g.N = 4 * C; g.K = 3 * d.D; g.nb0 = V; g.flags = PETR_GEMM_RELU;
     RUN(petr_gemm(&g, s1));
     g = lin_fwd(Wm + W.h1, Pm + P.pe_w2, Pm + P.pe_b2, Wm + (cfg->with_fpe ? W.pe1 : W.pos), d.BL, C, 4 * C);
+    if (attn_bf16) g.flags |= PETR_GEMM_BF16;      // bf16 mode: the K-contiguous L-sized contractions run on bf16 MFMA
     RUN(petr_gemm(&g, s1));
     // wait for side 2 (memory, sine hidden)
     if (ln.ctx) {
@@ -697,15 +698,17 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     if (cfg->with_fpe) {
       // feature-guided PE (petrv2_head.py:464-466, SELayer :48-60): pos3d * sigmoid(expand(relu(reduce(x))))
       g = lin_fwd(Wm + W.mem, Pm + P.fpe_rw, Pm + P.fpe_rb, Wm + W.fpe_h, d.BL, C, C);
-      g.flags = PETR_GEMM_RELU;
+      g.flags = PETR_GEMM_RELU | (attn_bf16 ? PETR_GEMM_BF16 : 0);
       RUN(petr_gemm(&g, s1));
       g = lin_fwd(Wm + W.fpe_h, Pm + P.fpe_ew, Pm + P.fpe_eb, Wm + W.fpe_u, d.BL, C, C);
+      if (attn_bf16) g.flags |= PETR_GEMM_BF16;
       RUN(petr_gemm(&g, s1));
       RUN(petr_gate_fwd(Wm + W.pe1, Wm + W.fpe_u, Wm + W.pos, d.BL * C, s1));
     }
     // pos += adapt_pos3d(sine) (petr_head.py:400-402)
     g = lin_fwd(Wm + W.h2, Pm + P.ad_w2, Pm + P.ad_b2, Wm + W.pos, d.BL, C, 4 * C);
-    g.flags = PETR_GEMM_ACCUMULATE;
+    if (attn_bf16) { g.flags = PETR_GEMM_BF16; g.r = Wm + W.pos; g.ldr = C; }   // same sum with pos as the residual operand
+    else g.flags = PETR_GEMM_ACCUMULATE;
     RUN(petr_gemm(&g, s1));
     // key = memory + key_pos (petr_transformer.py:343-344), once for all layers
     RUN(petr_add_rows(Wm + W.mem, Wm + W.pos, Wm + W.mempos, d.BL, 0, C, s1));

@@ -426,6 +426,25 @@ def test_headv2_800x320_forward_backward_runs(pa):
         assert e < 5e-3, (name, e)
 
 
+def test_headv2_800x320_forward_bf16_mode(pa):
+    """BASELINE configs[4] shape (PETRv2, 12 views x 20x50, 900 queries) in the bf16 inference mode: bf16 K/V projections,
+    bf16 feature-guided-PE and position-embedding contractions, bf16 K/V cross-attention; against the fp32 CPU oracle."""
+    kw = dict(num_query=900, v2=True, with_fpe=True, with_time=True, with_multi=True, code_weights=[1.0] * 10)
+    oracle = O.seeded_head(1, None, **kw)
+    head = pa.build_head(pa.petrv2_head_cfg(num_query=900))
+    head.load_state_dict(oracle.state_dict())
+    head = head.cuda().eval()
+    head.attn_dtype = 'bf16'
+    metas = O.synthetic_img_metas(1, 12, (320, 800), seed=4, with_time=True)
+    feats = torch.randn(1, 12, 256, 20, 50, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        want = oracle([feats], metas)
+        got = head([feats.cuda()], metas)
+    e_cls, e_box = rel(got['all_cls_scores'], want['all_cls_scores']), rel(got['all_bbox_preds'], want['all_bbox_preds'])
+    print(f'bf16 mode vs fp32 oracle at v2 800x320: cls {e_cls:.2e} bbox {e_box:.2e}')
+    assert e_cls < REL_BF16 and e_box < REL_BF16
+
+
 @pytest.mark.parametrize('extra', [[], ['--force-reducer']])
 def test_bench_contract(extra):
     """bench.py prints ONE JSON line with the driver's contract keys (+ roofline / cpu_baseline objects); the

@@ -134,8 +134,8 @@ enum { PETR_GEMM_RELU = 1, PETR_GEMM_ACCUMULATE = 2, PETR_GEMM_RELU_MASK = 4, PE
  * c_nblk_stride count bf16 elements: the K/V projections feeding petr_mha_fwd_bf16.  Tiled kernel only; excludes
  * ACCUMULATE, ATOMIC and split_k > 1.
  * PETR_GEMM_BF16: the fp32 operands are rounded to bf16 on load and multiplied on v_mfma_f32_32x32x16_bf16 with fp32
- * accumulation (what torch.autocast(bfloat16) does to an nn.Linear); both operands K-contiguous and 16-byte aligned,
- * K % 16 == 0, epilogue limited to bias / residual / ReLU / STORE_BF16 (a2 addend allowed). */
+ * accumulation (what torch.autocast(bfloat16) does to an nn.Linear / 1x1 conv); B K-contiguous, A K-contiguous or (for
+ * K % 32 == 0 and >= 64 output tiles) K-major, 16-byte aligned, K % 16 == 0, epilogue limited to bias / residual / ReLU / STORE_BF16 (a2 addend allowed). */
 /* drop.p > 0 (only without batch dims / split_k): the activated value act(...) is dropped out with
  * (row, col) = (m, n) before it is stored (mmcv FFN: Linear, ReLU, Dropout).                   */
 typedef struct {

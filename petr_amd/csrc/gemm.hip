@@ -680,7 +680,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const petr_gemm_args g, 
 // tiles), K step 32.  Operand tiles are read with coalesced float4 loads (8 consecutive threads = one 128-byte row
 // piece), rounded to bf16 and written to LDS rows of 32 + 8 elements (80-byte pitch: the 16-byte fragment reads of 16
 // lanes fall into 64 distinct banks); register prefetch of the next K step, double-buffered LDS, one barrier per step.
-template <bool A2>
+// AKM: A is K-major (A(m,k) = a[k*lda + m], the NCHW feature / coordinate maps): a thread stages one row m and 16
+// consecutive k with dword loads that are coalesced ACROSS the lanes (consecutive m), so the LDS image needs no transposition.
+template <bool A2, bool AKM>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_lds_kernel(const petr_gemm_args g, const int tiles_n) {
   constexpr int BM = 128, BN = 128, BK = 32, PITCH = 40;
   __shared__ __attribute__((aligned(16))) uint16_t lds[2][(BM + BN) * PITCH];
@@ -707,10 +709,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_lds_kernel(const petr_gemm_a
     a2_off[i] = A2 ? (g.a2_rows > 0 ? ra % g.a2_rows : ra) * (int)g.lda + 4 * s_c4 : 0;
   }
   float4 ra_[4], rb_[4], ra2_[4];
+  const int km_row = min(m0 + (t & 127), g.M - 1), km_k = (t >> 7) * 16;      // AKM: row and first k of this thread
   auto gload = [&](int k0) {
+    if (AKM) {
+      const float* src = Ab + (long)(k0 + km_k) * g.lda + km_row;
+      float* dst = reinterpret_cast<float*>(ra_);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dst[e] = src[(long)e * g.lda];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra_[i] = *reinterpret_cast<const float4*>(Ab + a_off[i] + k0);
+      if (!AKM) ra_[i] = *reinterpret_cast<const float4*>(Ab + a_off[i] + k0);
       rb_[i] = *reinterpret_cast<const float4*>(Bb + b_off[i] + k0);
       if (A2) ra2_[i] = *reinterpret_cast<const float4*>(g.a2 + a2_off[i] + k0);
     }
@@ -723,11 +732,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_lds_kernel(const petr_gemm_a
   auto lstore = [&](int buf) {
     uint16_t* As = lds[buf];
     uint16_t* Bs = As + BM * PITCH;
+    if (AKM) {
+      const uint2 p0 = pack(ra_[0]), p1 = pack(ra_[1]), p2 = pack(ra_[2]), p3 = pack(ra_[3]);
+      uint4* d = reinterpret_cast<uint4*>(As + (t & 127) * PITCH + km_k);
+      d[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
+      d[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float4 av = ra_[i];
-      if (A2 && use_a2) { av.x += ra2_[i].x; av.y += ra2_[i].y; av.z += ra2_[i].z; av.w += ra2_[i].w; }
-      *reinterpret_cast<uint2*>(As + (s_row + 32 * i) * PITCH + 4 * s_c4) = pack(av);
+      if (!AKM) {
+        float4 av = ra_[i];
+        if (A2 && use_a2) { av.x += ra2_[i].x; av.y += ra2_[i].y; av.z += ra2_[i].z; av.w += ra2_[i].w; }
+        *reinterpret_cast<uint2*>(As + (s_row + 32 * i) * PITCH + 4 * s_c4) = pack(av);
+      }
       *reinterpret_cast<uint2*>(Bs + (s_row + 32 * i) * PITCH + 4 * s_c4) = pack(rb_[i]);
     }
   };
@@ -798,11 +815,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_lds_kernel(const petr_gemm_a
 }
 
 static int launch_bf16(const petr_gemm_args& g, hipStream_t s) {
-  if (g.K % 32 == 0 && (long)g.M * g.N >= 128L * 128 * 64) {     // enough 128 x 128 tiles: the LDS-staged kernel
+  const bool staged = g.K % 32 == 0 && (long)g.M * g.N * g.nb0 * g.nb1 >= 128L * 128 * 64;
+  PETR_CHECK(g.a_kcontig || staged, PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_BF16 with a K-major A needs K %% 32 == 0 and >= 64 output tiles");
+  if (staged) {     // enough 128 x 128 tiles: the LDS-staged kernel
     const int tm = (int)cdiv(g.M, 128), tn = (int)cdiv(g.N, 128);
     dim3 grid2(tm * tn, 1, g.nb0 * g.nb1), block2(256);
-    if (g.a2) hipLaunchKernelGGL((gemm_bf16_lds_kernel<true>), grid2, block2, 0, s, g, tn);
-    else hipLaunchKernelGGL((gemm_bf16_lds_kernel<false>), grid2, block2, 0, s, g, tn);
+    if (!g.a_kcontig) hipLaunchKernelGGL((gemm_bf16_lds_kernel<false, true>), grid2, block2, 0, s, g, tn);
+    else if (g.a2) hipLaunchKernelGGL((gemm_bf16_lds_kernel<true, false>), grid2, block2, 0, s, g, tn);
+    else hipLaunchKernelGGL((gemm_bf16_lds_kernel<false, false>), grid2, block2, 0, s, g, tn);
     PETR_LAUNCH_CHECK("gemm_bf16_lds");
     return PETR_OK;
   }
@@ -858,11 +878,11 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
   PETR_CHECK(!(g.flags & PETR_GEMM_STORE_BF16) || (g.split_k == 1 && !(g.flags & (PETR_GEMM_ACCUMULATE | PETR_GEMM_ATOMIC))),
              PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_STORE_BF16 needs a plain store (no accumulate / atomic / split_k)");
   if (g.flags & PETR_GEMM_BF16) {
-    PETR_CHECK(g.a_kcontig && g.b_kcontig && g.K % 16 == 0 && g.split_k == 1 && g.k_seg <= 0 && !g.a_colsum && !gp->drop.p &&
+    PETR_CHECK(g.b_kcontig && g.K % 16 == 0 && g.split_k == 1 && g.k_seg <= 0 && !g.a_colsum && !gp->drop.p &&
                    !(g.flags & (PETR_GEMM_ACCUMULATE | PETR_GEMM_ATOMIC | PETR_GEMM_RELU_MASK | PETR_GEMM_SIGMOID_MUL)) && vec &&
-                   !(g.lda & 3) && !(g.ldb & 3),
+                   (!g.a_kcontig || !(g.lda & 3)) && !(g.ldb & 3),
                PETR_ERR_UNSUPPORTED,
-               "gemm: PETR_GEMM_BF16 needs K-contiguous 16-byte aligned operands, K %% 16 == 0 and a plain epilogue");
+               "gemm: PETR_GEMM_BF16 needs a K-contiguous B, 16-byte aligned operands, K %% 16 == 0 and a plain epilogue");
     return launch_bf16(g, s);
   }
   const long tiles32 = cdiv(g.M, 32) * cdiv(g.N, 32) * (long)g.nb0 * g.nb1;

@@ -646,6 +646,10 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   const bool attn_bf16 = io->attn_bf16 != 0;
   PETR_CHECK(!(attn_bf16 && io->dropout_p > 0.f), PETR_ERR_UNSUPPORTED,
              "head_fwd: attn_bf16 is an inference option (no bf16 attention backward yet); use fp32 for training");
+  // bf16 mode: the 1x1 convolutions over NCHW maps take the K-major variant of the bf16 contraction where it applies
+  auto bf16_km = [&](const petr_gemm_args& q) {
+    return attn_bf16 && q.K % 32 == 0 && (long)q.M * q.N * (q.nb0 > 0 ? q.nb0 : 1) >= 128L * 128 * 64 && !(q.lda & 3) && !(q.ldb & 3);
+  };
   uint16_t* k16 = reinterpret_cast<uint16_t*>(Wm + W.dk_all);
   uint16_t* v16 = reinterpret_cast<uint16_t*>(Wm + W.dv_all);
 
@@ -658,6 +662,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.b = Pm + P.in_w; g.ldb = d.Cin; g.b_kcontig = 1;
     g.c = Wm + W.mem; g.ldc = C; g.c_bs0 = (long)d.HW * C; g.bias = Pm + P.in_b;
     g.M = d.HW; g.N = C; g.K = d.Cin; g.nb0 = V;
+    if (bf16_km(g)) g.flags |= PETR_GEMM_BF16;
     RUN(petr_gemm(&g, s2));
     petr_sine3d_args b;
     memset(&b, 0, sizeof b);
@@ -669,6 +674,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.b = Pm + P.ad_w1; g.ldb = C * 3 / 2; g.b_kcontig = 1;
     g.c = Wm + W.h2; g.ldc = 4 * C; g.c_bs0 = (long)d.HW * 4 * C; g.bias = Pm + P.ad_b1;
     g.M = d.HW; g.N = 4 * C; g.K = C * 3 / 2; g.nb0 = V; g.flags = PETR_GEMM_RELU;
+    if (bf16_km(g)) g.flags |= PETR_GEMM_BF16;
     RUN(petr_gemm(&g, s2));
   }
   // ---- side 1: 3D position embedding (petr_head.py:286-334): coords3d, conv 3D->4C, ReLU, conv 4C->C ----
@@ -685,6 +691,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.b = Pm + P.pe_w1; g.ldb = 3 * d.D; g.b_kcontig = 1;
     g.c = Wm + W.h1; g.ldc = 4 * C; g.c_bs0 = (long)d.HW * 4 * C; g.bias = Pm + P.pe_b1;
     g.M = d.HW; g.N = 4 * C; g.K = 3 * d.D; g.nb0 = V; g.flags = PETR_GEMM_RELU;
+    if (bf16_km(g)) g.flags |= PETR_GEMM_BF16;
     RUN(petr_gemm(&g, s1));
     g = lin_fwd(Wm + W.h1, Pm + P.pe_w2, Pm + P.pe_b2, Wm + (cfg->with_fpe ? W.pe1 : W.pos), d.BL, C, 4 * C);
     if (attn_bf16) g.flags |= PETR_GEMM_BF16;      // bf16 mode: the K-contiguous L-sized contractions run on bf16 MFMA

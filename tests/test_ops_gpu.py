@@ -509,3 +509,20 @@ def test_gemm_bf16_route(ops, M, N, K, a2, store16):
     with pytest.raises(RuntimeError, match='PETR_GEMM_BF16'):                     # K not a multiple of 16
         ops.gemm_raw(a=x.cuda()[:, :K - 8].contiguous(), lda=K - 8, a_kcontig=1, b=w.cuda()[:, :K - 8].contiguous(), ldb=K - 8,
                      b_kcontig=1, c=torch.zeros(M, N, device='cuda'), ldc=N, M=M, N=N, K=K - 8, flags=_C.GEMM_BF16, alpha=1.0)
+
+
+@pytest.mark.parametrize('V,Cin,HW,N', [(6, 256, 704, 256), (2, 192, 4000, 1024), (3, 384, 1000, 1024)])
+def test_gemm_bf16_route_channel_major_input(ops, V, Cin, HW, N):
+    """PETR_GEMM_BF16 with a K-major A operand: a 1x1 convolution reading an NCHW map [V][Cin][HW] (input_proj, the first
+    position-embedding convolutions), batched over the views, token-major output.  Shapes: c5 (HW = 704), p4-1600
+    (HW = 4 000), PETRv2 (HW = 1 000, not a multiple of 128: ragged row tiles)."""
+    from petr_amd import _C
+    g = torch.Generator().manual_seed(V * HW)
+    x, w, b = torch.randn(V, Cin, HW, generator=g), torch.randn(N, Cin, generator=g), torch.randn(N, generator=g)
+    out = torch.zeros(V, HW, N, device='cuda')
+    ops.gemm_raw(a=x.cuda(), lda=HW, a_kcontig=0, a_bs0=Cin * HW, b=w.cuda(), ldb=Cin, b_kcontig=1, c=out, ldc=N, c_bs0=HW * N,
+                 bias=b.cuda(), M=HW, N=N, K=Cin, nb0=V, nb1=1, flags=_C.GEMM_BF16 | _C.GEMM_RELU, alpha=1.0)
+    same = torch.relu(torch.einsum('vkm,nk->vmn', x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double()) + b.double())
+    full = torch.relu(torch.einsum('vkm,nk->vmn', x.double(), w.double()) + b.double())
+    assert relerr(out, same) < 2e-5, relerr(out, same)
+    assert relerr(out, full) < 1.5e-2

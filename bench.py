@@ -338,8 +338,8 @@ def main():
             if v:
                 us_b = sum(v) / len(v) * 1e3
                 ach_b = roofline['flops_per_launch'] / (us_b * 1e-6) / 1e12
-                bf16_leg = {'what': 'eval-mode forward with attn_dtype=bf16 (K/V projections on bf16 MFMA storing bf16, bf16 K/V cross-attention, '
-                                    'fp32 softmax/accumulate); '
+                bf16_leg = {'what': 'eval-mode forward with attn_dtype=bf16 (token-sized contractions on bf16 MFMA, K/V stored as bf16, bf16 K/V '
+                                    'cross-attention, fp32 softmax/accumulate); '
                                     'training stays fp32 this round',
                             'fwd_ms': round(bf_ms, 4), 'fwd_samples_per_s': round(B / (bf_ms * 1e-3), 2),
                             'mha_fwd_cross_us': round(us_b, 2), 'achieved_tflops': round(ach_b, 1),

@@ -280,6 +280,31 @@ typedef struct {
 size_t petr_mha_bwd_workspace_bytes(int B, int H, int Q, int L);
 int petr_mha_bwd(const petr_mha_bwd_args* a, void* stream);
 
+/* bf16 variant of the backward (gradient of petr_mha_fwd_bf16; BASELINE configs 3-5: the training step in bf16):
+ *     k, v are bf16 (raw uint16_t bits, strides in bf16 ELEMENTS, rows 16-byte aligned); q, o, d_o, lse, dq, dk, dv are
+ *     fp32 (rows of q / o / d_o 16-byte aligned).  q is rounded to bf16 after the scale*log2(e) pre-multiplication (as
+ *     the forward does), d_o, the recomputed probabilities and ds are rounded to bf16 for the second products; LSE,
+ *     delta = rowsum(d_o*o) and all five accumulators are fp32 (v_mfma_f32_32x32x16_bf16).  Same call site and the
+ *     same (+=) output convention as petr_mha_bwd; no workspace.                                              */
+typedef struct {
+  const float* q; long q_bs, q_hs, q_rs;
+  const uint16_t* k; long k_bs, k_hs, k_rs;
+  const uint16_t* v; long v_bs, v_hs, v_rs;
+  const float* o; long o_bs, o_hs, o_rs;
+  const float* d_o; long do_bs, do_hs, do_rs;
+  const float* lse;
+  const uint8_t* kpm;
+  float* dq; long dq_bs, dq_hs, dq_rs;
+  float* dk; long dk_bs, dk_hs, dk_rs;
+  float* dv; long dv_bs, dv_hs, dv_rs;
+  int B, H, Q, L;
+  float scale;
+  void* ws; size_t ws_bytes;   /* unused (0 bytes needed); kept so that the block mirrors petr_mha_bwd_args */
+  petr_dropout drop;           /* must equal the forward's */
+} petr_mha_bwd_bf16_args;
+size_t petr_mha_bwd_bf16_workspace_bytes(int B, int H, int Q, int L);
+int petr_mha_bwd_bf16(const petr_mha_bwd_bf16_args* a, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Box epilogue (models/dense_heads/petr_head.py:441-460; petrv2_head.py:513-531):
  *     t = reg[lvl,b,q,:]; t[0:2] = sigmoid(t[0:2] + logit(ref[q,0:2])); t[4] = sigmoid(t[4] + logit(ref[q,2]));
@@ -424,8 +449,11 @@ typedef struct {
   void* ctx;                    /* petr_ctx* (side streams) or NULL: everything on `stream` */
   float dropout_p;              /* training mode: the decoder's dropout rate (reference 0.1); 0 = eval */
   uint64_t dropout_seed;        /* fresh per forward; petr_head_bwd must get the forward's value     */
-  int attn_bf16;                /* 1: cross-attention reads bf16 copies of the projected K/V (petr_mha_fwd_bf16;
-                                 * BASELINE configs 3-5).  Inference only: needs dropout_p == 0, petr_head_bwd refuses */
+  int attn_bf16;                /* 1: bf16 mode (BASELINE configs 3-5): every token-sized contraction of the forward AND
+                                 * of petr_head_bwd rounds its fp32 operands to bf16 (fp32 accumulate), K/V are stored as
+                                 * bf16 and the cross-attention runs petr_mha_fwd_bf16 / petr_mha_bwd_bf16; parameters,
+                                 * gradients, softmax, LayerNorm and the query-sized work stay fp32.  petr_head_bwd must
+                                 * get the forward's value */
 } petr_head_io;
 size_t petr_head_workspace_bytes(const petr_head_config* cfg);
 int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io, void* stream);

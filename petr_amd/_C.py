@@ -201,6 +201,9 @@ def lib():
     L.petr_mha_bwd_workspace_bytes.argtypes = [C.c_int] * 4
     L.petr_mha_bwd_workspace_bytes.restype = C.c_size_t
     L.petr_mha_bwd.argtypes = [C.POINTER(MhaBwdArgs), C.c_void_p]
+    L.petr_mha_bwd_bf16_workspace_bytes.argtypes = [C.c_int] * 4
+    L.petr_mha_bwd_bf16_workspace_bytes.restype = C.c_size_t
+    L.petr_mha_bwd_bf16.argtypes = [C.POINTER(MhaBwdArgs), C.c_void_p]   # same block, k / v are bf16
     L.petr_bbox_epilogue_fwd.argtypes = [C.POINTER(BboxArgs), C.c_void_p]
     L.petr_bbox_epilogue_bwd.argtypes = [C.POINTER(BboxArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.petr_prof_begin.argtypes = [C.c_int]
@@ -240,7 +243,7 @@ EXPORTS = [
     'petr_layernorm_fwd', 'petr_layernorm_bwd_workspace_bytes', 'petr_layernorm_bwd',
     'petr_mha_fwd_workspace_bytes', 'petr_mha_choose_split', 'petr_mha_fwd', 'petr_mha_fwd_bf16_workspace_bytes',
     'petr_mha_fwd_bf16', 'petr_cast_bf16', 'petr_mha_bwd_workspace_bytes',
-    'petr_mha_bwd', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows', 'petr_gate_fwd', 'petr_gate_bwd', 'petr_prof_begin', 'petr_prof_end',
+    'petr_mha_bwd', 'petr_mha_bwd_bf16_workspace_bytes', 'petr_mha_bwd_bf16', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows', 'petr_gate_fwd', 'petr_gate_bwd', 'petr_prof_begin', 'petr_prof_end',
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
     'petr_ctx_create', 'petr_ctx_destroy', 'petr_ctx_join_into', 'petr_dropout_mask', 'petr_loss_workspace_bytes', 'petr_loss_fwd_bwd',

@@ -1,0 +1,276 @@
+// General bf16 contraction (PETR_GEMM_BF16 with any operand layout):
+//   C[m,n] (+)= act(alpha * sum_k bf16(A(m,k)) * bf16(B(n,k)) + bias + R), fp32 accumulate on v_mfma_f32_32x32x16_bf16.
+//
+// The training step of BASELINE configs 3-5 (bf16) needs the token-sized (L = 12 000 .. 24 000 rows) GRADIENT
+// contractions on the bf16 matrix cores as well: input gradients (B = a weight read K-major), weight gradients
+// (A = dY^T and B = X both K-major, K = B*L cut into segments, split over workgroups, float-atomic accumulation,
+// bias gradient as column sums) - the same contractions the reference gets from autograd of its 1x1 convs /
+// nn.Linear layers (petr_head.py:220-274, petr_transformer.py:357-362) under autocast.  gemm.hip's two bf16 kernels
+// only take a K-contiguous B and a plain epilogue; this one takes every layout combination of petr_gemm_args.
+//
+//   workgroup = 128 x 128 outputs, 4 waves of 64 x 64 (2 x 2 MFMA tiles), K step 32, 256 threads;
+//   LDS image of both operands: [row][32 k] bf16 at an 80-byte pitch (16-byte fragment reads conflict-free);
+//     K-contiguous operand: a thread stages 4 float4 (8 threads = one 128-byte row piece), rounds, 8-byte LDS stores;
+//     K-major operand (x[k*ld + row]): a thread stages ONE row and 16 consecutive k with dword loads that are
+//       coalesced across the lanes (consecutive rows), rounds, two 16-byte LDS stores - no transposition anywhere;
+//   register prefetch of the next K step, double-buffered LDS, one barrier per step;
+//   loads are unconditional from clamped addresses, the zero-fill select happens at the LDS store and only on ragged
+//   tiles (wave-uniform test), so interior tiles carry no per-element VALU besides the rounding;
+//   K segments (k_seg), K slices over workgroups (split_k: slabs or float atomics), two batch dims, epilogue: bias,
+//   residual, ReLU, ReLU-mask, accumulate, bf16 store; a_colsum (bias gradient) from the fp32 staging registers of a
+//   K-major A, i.e. the exact fp32 column sums, not sums of rounded values.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hbf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GB_BM = 128, GB_BN = 128, GB_BK = 32, GB_PITCH = 40;
+
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  hbf16x4 o = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+  return __builtin_bit_cast(uint2, o);
+}
+
+// one operand tile (128 rows x 32 k) in flight between global memory and LDS
+template <bool KC>
+struct Stage16 {
+  float v[16];            // KC: 4 float4 (row = (t>>3) + 32 i, k = 4 (t&7) ..+3);  KM: row t&127, k = 16 (t>>7) + e
+  // loop-invariant addressing
+  int off[4];             // KC: element offset of float4 i from the tile origin (row clamped); KM: off[0] = clamped row
+  unsigned rowok;         // KC: bit i = row i valid; KM: bit 0
+  __device__ __forceinline__ void init(long ld, int row0, int rows) {
+    const int t = threadIdx.x;
+    rowok = 0;
+    if (KC) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = row0 + (t >> 3) + 32 * i;
+        off[i] = min(row, rows - 1) * (int)ld + 4 * (t & 7);
+        rowok |= (row < rows ? 1u : 0u) << i;
+      }
+    } else {
+      const int row = row0 + (t & 127);
+      off[0] = min(row, rows - 1);
+      off[1] = off[2] = off[3] = 0;
+      rowok = row < rows ? 1u : 0u;
+    }
+  }
+  // base = operand + batch + segment; k0 = first k of the tile inside the segment, kend = segment length
+  __device__ __forceinline__ void load(const float* base, long ld, int k0, int kend) {
+    const int t = threadIdx.x;
+    if (KC) {
+      const int kc = min(k0 + 4 * (t & 7), kend - 4) - 4 * (t & 7);    // clamp keeps the float4 inside the row
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 x = *reinterpret_cast<const float4*>(base + off[i] + kc);
+        v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+      }
+    } else {
+      const int kb = k0 + 16 * (t >> 7);
+      if (kb + 16 <= kend) {                      // wave-uniform: all 16 k inside the segment
+        const float* src = base + (long)kb * ld + off[0];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = src[(long)e * ld];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = base[(long)min(kb + e, kend - 1) * ld + off[0]];
+      }
+    }
+  }
+  // round to bf16 and write the [row][k] image; `ragged`: the tile crosses the operand's row or K bound (uniform)
+  __device__ __forceinline__ void store(uint16_t* img, bool ragged, int k0, int kend) {
+    const int t = threadIdx.x;
+    if (KC) {
+      if (ragged) {
+        const bool kok = k0 + 4 * (t & 7) < kend;       // K % 4 == 0: a float4 is entirely inside or outside
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool ok = kok && ((rowok >> i) & 1u);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * i + e] = ok ? v[4 * i + e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<uint2*>(img + ((t >> 3) + 32 * i) * GB_PITCH + 4 * (t & 7)) =
+            pack4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    } else {
+      if (ragged) {
+        const int kb = k0 + 16 * (t >> 7);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = (rowok && kb + e < kend) ? v[e] : 0.f;
+      }
+      uint4* d = reinterpret_cast<uint4*>(img + (t & 127) * GB_PITCH + 16 * (t >> 7));
+      const uint2 p0 = pack4(v[0], v[1], v[2], v[3]), p1 = pack4(v[4], v[5], v[6], v[7]);
+      const uint2 p2 = pack4(v[8], v[9], v[10], v[11]), p3 = pack4(v[12], v[13], v[14], v[15]);
+      d[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
+      d[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
+    }
+  }
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_gen_kernel(const petr_gemm_args g, const int tiles_m, const int tiles_n) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2][(GB_BM + GB_BN) * GB_PITCH];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int h = lane >> 5, c = lane & 31;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm_i = tile / tiles_n, tn_i = tile - tm_i * tiles_n;
+  const int m0 = tm_i * GB_BM, n0 = tn_i * GB_BN;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  int z = blockIdx.z;
+  const int ks = z % g.split_k;
+  z /= g.split_k;
+  const int z1 = z % g.nb1, z0 = z / g.nb1;
+  const float* Ab = g.a + z0 * g.a_bs0 + z1 * g.a_bs1;
+  const float* Bb = g.b + z0 * g.b_bs0 + z1 * g.b_bs1;
+
+  const int kseg = g.k_seg > 0 ? g.k_seg : g.K;
+  const int nseg = g.k_seg > 0 ? g.K / g.k_seg : 1;
+  const int tps = (kseg + GB_BK - 1) / GB_BK;
+  const int ktiles = nseg * tps;
+  const int kt_per = (ktiles + g.split_k - 1) / g.split_k;
+  const int kt_begin = ks * kt_per;
+  const int kt_end = min(ktiles, kt_begin + kt_per);
+
+  Stage16<AKC> sa;
+  Stage16<BKC> sb;
+  sa.init(g.lda, m0, g.M);
+  sb.init(g.ldb, n0, g.N);
+  const bool rows_ragged_a = m0 + GB_BM > g.M, rows_ragged_b = n0 + GB_BN > g.N;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bool do_colsum = g.a_colsum != nullptr && tn_i == 0;    // host guarantees a K-major A with a_colsum
+  float colacc = 0.f;
+
+  int k0_cur = 0, k0_nxt = 0;       // first k (inside its segment) of the tile held in registers / of the one being loaded
+  auto gload = [&](int kt, int& k0_out) {
+    const int seg = kt / tps;
+    const int k0 = (kt - seg * tps) * GB_BK;
+    k0_out = k0;
+    sa.load(Ab + (long)seg * g.a_seg_stride, g.lda, k0, kseg);
+    sb.load(Bb + (long)seg * g.b_seg_stride, g.ldb, k0, kseg);
+  };
+  auto lstore = [&](int buf, int k0) {
+    const bool kr = k0 + GB_BK > kseg;
+    if (!AKC && do_colsum) {        // exact fp32 column sums of A (= dC^T): the bias gradient of a weight-gradient contraction
+      const int kb = k0 + 16 * (t >> 7);
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s += (kb + e < kseg) ? sa.v[e] : 0.f;
+      colacc += s;
+    }
+    sa.store(lds[buf], rows_ragged_a || kr, k0, kseg);
+    sb.store(lds[buf] + GB_BM * GB_PITCH, rows_ragged_b || kr, k0, kseg);
+  };
+
+  const int nk = kt_end - kt_begin;
+  if (nk > 0) {
+    gload(kt_begin, k0_cur);
+    lstore(0, k0_cur);
+    if (nk > 1) gload(kt_begin + 1, k0_nxt);
+    for (int it = 0; it < nk; ++it) {
+      const int buf = it & 1;
+      __syncthreads();                       // image `buf` complete; the other one is free again
+      if (it + 1 < nk) {
+        lstore(buf ^ 1, k0_nxt);
+        if (it + 2 < nk) gload(kt_begin + it + 2, k0_nxt);
+      }
+      const uint16_t* As = lds[buf];
+      const uint16_t* Bs = As + GB_BM * GB_PITCH;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {          // two 16-deep chunks of the K step
+        uint4 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[i] = *reinterpret_cast<const uint4*>(As + (wm + 32 * i + c) * GB_PITCH + 16 * j + 8 * h);
+          fb[i] = *reinterpret_cast<const uint4*>(Bs + (wn + 32 * i + c) * GB_PITCH + 16 * j + 8 * h);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jn = 0; jn < 2; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, fa[i]),
+                                                                 __builtin_bit_cast(hbf16x8, fb[jn]), acc[i][jn], 0, 0, 0);
+      }
+    }
+  }
+
+  if (!AKC && do_colsum && m0 + (t & 127) < g.M)
+    atomicAdd(g.a_colsum + z0 * g.cs_bs0 + z1 * g.cs_bs1 + m0 + (t & 127), colacc);
+
+  // ---- epilogue (as gemm_kernel) ----
+  const bool atomic = (g.flags & PETR_GEMM_ATOMIC) != 0;
+  const bool plain = g.split_k > 1 && !atomic;       // K slices store raw partial sums
+  float* C = g.c + z0 * g.c_bs0 + z1 * g.c_bs1 + (atomic ? 0 : (long)ks * g.c_split_stride);
+  const float* bias = (!plain && g.bias) ? g.bias + z0 * g.bias_bs0 + z1 * g.bias_bs1 : nullptr;
+  const float* R = (!plain && g.r) ? g.r + z0 * g.r_bs0 + z1 * g.r_bs1 : nullptr;
+  const int flags = plain ? 0 : g.flags;
+#pragma unroll
+  for (int jn = 0; jn < 2; ++jn) {
+    const int n = n0 + wn + 32 * jn + c;
+    const int nc = min(n, g.N - 1);
+    const float bv = bias ? bias[nc] : 0.f;
+    const long ccol = g.c_nblk > 0 ? (long)(nc / g.c_nblk) * g.c_nblk_stride + (nc % g.c_nblk) : (long)nc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + 32 * i + mfma32_row(r, h);
+        const int mc = min(m, g.M - 1);
+        const bool ok = m < g.M && n < g.N;
+        float v = acc[i][jn][r] * g.alpha + bv;
+        float* dst = C + (long)mc * g.ldc + ccol;
+        const float rv = R ? R[(long)mc * g.ldr + nc] : 0.f;
+        const float old = (flags & PETR_GEMM_ACCUMULATE) ? *dst : 0.f;
+        if (flags & PETR_GEMM_RELU_MASK) v = rv > 0.f ? v : 0.f;
+        else v += rv;
+        if (flags & PETR_GEMM_RELU) v = fmaxf(v, 0.f);
+        v += old;
+        if (ok) {
+          if (flags & PETR_GEMM_STORE_BF16)
+            reinterpret_cast<uint16_t*>(g.c)[z0 * g.c_bs0 + z1 * g.c_bs1 + (long)mc * g.ldc + ccol] =
+                __builtin_bit_cast(uint16_t, (__bf16)v);
+          else if (atomic) atomicAdd(dst, v);
+          else *dst = v;
+        }
+      }
+  }
+}
+
+}  // namespace
+
+// called by petr_gemm() for PETR_GEMM_BF16 requests that gemm.hip's plain-epilogue kernels do not take
+int petr_gemm_bf16_general(const petr_gemm_args& g, hipStream_t s) {
+  const int kseg = g.k_seg > 0 ? g.k_seg : g.K;
+  PETR_CHECK(!g.a2 && !(g.flags & PETR_GEMM_SIGMOID_MUL), PETR_ERR_UNSUPPORTED,
+             "gemm: PETR_GEMM_BF16 (general) has no a2 addend / sigmoid-gate epilogue");
+  PETR_CHECK(!g.a_colsum || !g.a_kcontig, PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_BF16 a_colsum needs a K-major A");
+  // K-contiguous operands are read as float4 along K, K-major ones as dwords along the rows
+  PETR_CHECK((!g.a_kcontig || (kseg % 4 == 0 && kseg >= 4 && !(g.lda & 3) && !(g.a_bs0 & 3) && !(g.a_bs1 & 3) &&
+                               !(g.a_seg_stride & 3) && aligned16(g.a))) &&
+                 (!g.b_kcontig || (kseg % 4 == 0 && kseg >= 4 && !(g.ldb & 3) && !(g.b_bs0 & 3) && !(g.b_bs1 & 3) &&
+                                   !(g.b_seg_stride & 3) && aligned16(g.b))),
+             PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_BF16 needs 16-byte aligned K-contiguous operands with K %% 4 == 0");
+  // 32-bit element offsets inside one batch / segment
+  PETR_CHECK((long)(g.a_kcontig ? g.M : kseg) * g.lda + (g.a_kcontig ? kseg : g.M) < (1L << 31) &&
+                 (long)(g.b_kcontig ? g.N : kseg) * g.ldb + (g.b_kcontig ? kseg : g.N) < (1L << 31),
+             PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_BF16 operand batch/segment must span < 2^31 elements");
+  const int tm = (int)cdiv(g.M, GB_BM), tn = (int)cdiv(g.N, GB_BN);
+  dim3 grid(tm * tn, 1, g.nb0 * g.nb1 * g.split_k), block(256);
+  if (g.a_kcontig && g.b_kcontig) hipLaunchKernelGGL((gemm_bf16_gen_kernel<true, true>), grid, block, 0, s, g, tm, tn);
+  else if (g.a_kcontig) hipLaunchKernelGGL((gemm_bf16_gen_kernel<true, false>), grid, block, 0, s, g, tm, tn);
+  else if (g.b_kcontig) hipLaunchKernelGGL((gemm_bf16_gen_kernel<false, true>), grid, block, 0, s, g, tm, tn);
+  else hipLaunchKernelGGL((gemm_bf16_gen_kernel<false, false>), grid, block, 0, s, g, tm, tn);
+  PETR_LAUNCH_CHECK("gemm_bf16_gen");
+  return PETR_OK;
+}

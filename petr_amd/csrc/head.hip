@@ -509,11 +509,13 @@ static int mha_f(const float* q, long q_bs, long q_rs, const float* k, long k_bs
   return petr_mha_fwd(&a, s);
 }
 
-// cross-attention with bf16 K/V copies (io->attn_bf16; eval forward only)
+// cross-attention with bf16 K/V (io->attn_bf16)
 static int mha_f_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, long k_bs, long k_rs, const uint16_t* v,
-                      float* o, float* lse, const uint8_t* kpm, const Dims& d, int L, float* ws, size_t ws_bytes, void* s) {
+                      float* o, float* lse, const uint8_t* kpm, const Dims& d, int L, float* ws, size_t ws_bytes, void* s,
+                      const petr_dropout* drop = nullptr) {
   petr_mha_fwd_bf16_args a;
   memset(&a, 0, sizeof a);
+  if (drop) a.drop = *drop;
   a.q = q; a.q_bs = q_bs; a.q_hs = 32; a.q_rs = q_rs;
   a.k = k; a.k_bs = k_bs; a.k_hs = 32; a.k_rs = k_rs;
   a.v = v; a.v_bs = k_bs; a.v_hs = 32; a.v_rs = k_rs;
@@ -543,6 +545,45 @@ static int mha_b(const float* q, long q_bs, long q_rs, const float* k, long k_bs
   a.scale = 1.0f / sqrtf(32.f);
   a.ws = ws; a.ws_bytes = ws_bytes;
   return petr_mha_bwd(&a, s);
+}
+
+// gradient of mha_f_bf16 (io->attn_bf16 training step)
+static int mha_b_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, long k_bs, long k_rs, const uint16_t* v,
+                      const float* o, const float* d_o, const float* lse, const uint8_t* kpm, float* dq, float* dk, float* dv,
+                      const Dims& d, int L, void* s, const petr_dropout* drop = nullptr) {
+  petr_mha_bwd_bf16_args a;
+  memset(&a, 0, sizeof a);
+  if (drop) a.drop = *drop;
+  a.q = q; a.q_bs = q_bs; a.q_hs = 32; a.q_rs = q_rs;
+  a.k = k; a.k_bs = k_bs; a.k_hs = 32; a.k_rs = k_rs;
+  a.v = v; a.v_bs = k_bs; a.v_hs = 32; a.v_rs = k_rs;
+  a.o = o; a.o_bs = (long)d.Q * d.C; a.o_hs = 32; a.o_rs = d.C;
+  a.d_o = d_o; a.do_bs = (long)d.Q * d.C; a.do_hs = 32; a.do_rs = d.C;
+  a.lse = lse; a.kpm = kpm;
+  a.dq = dq; a.dq_bs = q_bs; a.dq_hs = 32; a.dq_rs = q_rs;
+  a.dk = dk; a.dk_bs = k_bs; a.dk_hs = 32; a.dk_rs = k_rs;
+  a.dv = dv; a.dv_bs = k_bs; a.dv_hs = 32; a.dv_rs = k_rs;
+  a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
+  a.scale = 1.0f / sqrtf(32.f);
+  return petr_mha_bwd_bf16(&a, s);
+}
+
+// route a token-sized gradient contraction to the bf16 matrix cores (gemm_bf16.hip): 128 x 128 output tiles, so the
+// K split of a weight gradient is re-derived for that tile size (aim: ~2 workgroups per CU)
+static petr_gemm_args to_bf16(petr_gemm_args g) {
+  g.flags |= PETR_GEMM_BF16;
+  if (g.flags & PETR_GEMM_ATOMIC) {
+    const long nb = (long)(g.nb0 > 0 ? g.nb0 : 1) * (g.nb1 > 0 ? g.nb1 : 1);
+    const long tiles = cdiv(g.M, 128) * cdiv(g.N, 128) * nb;
+    const int kseg = g.k_seg > 0 ? g.k_seg : g.K;
+    const long ktiles = (g.k_seg > 0 ? g.K / g.k_seg : 1) * cdiv(kseg, 32);
+    long sk = 512 / (tiles > 0 ? tiles : 1);
+    if (sk > ktiles / 4) sk = ktiles / 4;
+    if (sk < 1) sk = 1;
+    if (sk > 128) sk = 128;
+    g.split_k = (int)sk;
+  }
+  return g;
 }
 
 }  // namespace
@@ -639,19 +680,17 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   void* s2 = ln.side(1);   // position-embedding branch B (sine MLP, input_proj) / V projection
   const int V = d.B * d.N;
   const float* E = Wm + W.qe;
-  // io->attn_bf16: the K/V projections run on the bf16 contraction and store bf16 (PETR_GEMM_BF16 | PETR_GEMM_STORE_BF16)
-  // and the cross-attention reads it (BASELINE
-  // configs 3-5), eval forward only this round: the bf16 K/V live in the (otherwise idle) dK/dV gradient buffers, the
-  // fp32 K/V buffers stay unwritten, and there is no bf16 backward yet
+  // io->attn_bf16 (BASELINE configs 3-5): every token-sized contraction runs on the bf16 matrix cores (fp32 operands
+  // rounded on load, fp32 accumulation), the K/V projections store bf16 (PETR_GEMM_BF16 | PETR_GEMM_STORE_BF16) into the
+  // front half of the fp32 K/V buffers, which stay otherwise unwritten, and the cross-attention (forward AND
+  // backward: petr_mha_fwd_bf16 / petr_mha_bwd_bf16) reads them; query-sized work (900 rows) stays fp32
   const bool attn_bf16 = io->attn_bf16 != 0;
-  PETR_CHECK(!(attn_bf16 && io->dropout_p > 0.f), PETR_ERR_UNSUPPORTED,
-             "head_fwd: attn_bf16 is an inference option (no bf16 attention backward yet); use fp32 for training");
   // bf16 mode: the 1x1 convolutions over NCHW maps take the K-major variant of the bf16 contraction where it applies
   auto bf16_km = [&](const petr_gemm_args& q) {
     return attn_bf16 && q.K % 32 == 0 && (long)q.M * q.N * (q.nb0 > 0 ? q.nb0 : 1) >= 128L * 128 * 64 && !(q.lda & 3) && !(q.ldb & 3);
   };
-  uint16_t* k16 = reinterpret_cast<uint16_t*>(Wm + W.dk_all);
-  uint16_t* v16 = reinterpret_cast<uint16_t*>(Wm + W.dv_all);
+  uint16_t* k16 = reinterpret_cast<uint16_t*>(Wm + W.k_all);
+  uint16_t* v16 = reinterpret_cast<uint16_t*>(Wm + W.v_all);
 
   ln.fork(0);
   ln.fork(1);
@@ -799,7 +838,8 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     }
     if (attn_bf16)
       RUN(mha_f_bf16(Wm + lw.qc, (long)d.Q * C, C, k16 + (long)l * d.L * C, (long)d.NL * d.L * C, C,
-                     v16 + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, s));
+                     v16 + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, s,
+                     training ? &dr_cp : nullptr));
     else
     RUN(mha_f(Wm + lw.qc, (long)d.Q * C, C, Wm + W.k_all + (long)l * d.L * C, (long)d.NL * d.L * C, C,
               Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, sched, s,
@@ -903,7 +943,6 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   RUN(check_config(cfg));
   PETR_CHECK(io && io->params && io->feats && io->ws && io->all_bbox_preds && gr && gr->d_cls && gr->d_bbox && gr->d_params,
              PETR_ERR_INVALID, "head_bwd: null pointer");
-  PETR_CHECK(!io->attn_bf16, PETR_ERR_UNSUPPORTED, "head_bwd: the forward ran with attn_bf16 (inference only): no backward");
   const Dims d = make_dims(cfg);
   POff P;
   build_layout(cfg, &P, nullptr);
@@ -928,6 +967,12 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
     ln.fork(lane);
     return petr_gemm(&g, ln.side(lane));
   };
+  // io->attn_bf16: the token-sized gradient contractions (K/V projections, position-embedding MLPs, input_proj,
+  // PETRv2's feature-guided PE) and the cross-attention backward run on the bf16 matrix cores, like their forwards
+  const bool bf16 = io->attn_bf16 != 0;
+  auto L16 = [&](const petr_gemm_args& g) { return bf16 ? to_bf16(g) : g; };
+  const uint16_t* k16 = reinterpret_cast<const uint16_t*>(Wm + W.k_all);
+  const uint16_t* v16 = reinterpret_cast<const uint16_t*>(Wm + W.v_all);
 
   for (int stage = stage_begin; stage < stage_end; ++stage) {
     if (stage == 0) {
@@ -1071,6 +1116,12 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       g = lin_dgrad(d_f1, Pm + lp.ca_out_w, d_ao, d.BQ, C, C);
       RUN(petr_gemm(&g, s));
       float* d_qc = Wm + W.d_qc + (long)l * d.BQ * C;
+      if (bf16)
+        RUN(mha_b_bf16(Wm + lw.qc, (long)d.Q * C, C, k16 + (long)l * d.L * C, (long)d.NL * d.L * C, C,
+                       v16 + (long)l * d.L * C, Wm + lw.ao_c, d_ao, Wm + lw.lse_c, kpm, d_qc,
+                       Wm + W.dk_all + (long)l * d.L * C, Wm + W.dv_all + (long)l * d.L * C, d, (int)d.L, s,
+                       training ? &dr[2] : nullptr));
+      else
       RUN(mha_b(Wm + lw.qc, (long)d.Q * C, C, Wm + W.k_all + (long)l * d.L * C, (long)d.NL * d.L * C, C,
                 Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, d_ao, Wm + lw.lse_c, kpm, d_qc,
                 Wm + W.dk_all + (long)l * d.L * C, Wm + W.dv_all + (long)l * d.L * C, d, (int)d.L, mws, W.mha_ws_bytes, s,
@@ -1122,13 +1173,14 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g.k_seg = (int)d.L; g.a_seg_stride = (long)d.NL * d.L * C; g.b_seg_stride = d.L * C;
         g.flags = PETR_GEMM_ATOMIC;
         g.split_k = 8;
-        RUN(wgrad(g));
+        RUN(wgrad(L16(g)));
         g = gemm0();      // d_src[b][t][c] = sum_{l,o} dKV[b][l][t][o] * W_l[o][c]
         g.a = dkv; g.lda = C; g.a_kcontig = 1; g.a_bs0 = (long)d.NL * d.L * C;
         g.b = Pm + P.lay[0].ca_in_w + (long)(kv + 1) * C * C; g.ldb = C; g.b_kcontig = 0;
         g.c = Wm + (kv == 0 ? W.d_mempos : W.d_mem); g.ldc = C; g.c_bs0 = d.L * C;
         g.M = (int)d.L; g.N = C; g.K = d.NL * C; g.nb0 = d.B;
         g.k_seg = C; g.a_seg_stride = d.L * C; g.b_seg_stride = P.ca_in_stride;
+        g = L16(g);
         RUN(petr_gemm(&g, s));
       }
       // d_mem = dV-path + d(mem+pos) ; d_pos = d(mem+pos)
@@ -1139,13 +1191,15 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         // SELayer backward: pos3d = pe1 * sigmoid(u), u = expand(relu(reduce(mem)))
         RUN(petr_gate_bwd(d_pos, Wm + W.pe1, Wm + W.fpe_u, Wm + W.d_pe1, Wm + W.d_fpe_u, d.BL * C, s));
         d_pe = Wm + W.d_pe1;
-        RUN(wgrad(lin_wgrad(Wm + W.d_fpe_u, C, Wm + W.fpe_h, C, Gp + P.fpe_ew, Gp + P.fpe_eb, d.BL, C, C)));
+        RUN(wgrad(L16(lin_wgrad(Wm + W.d_fpe_u, C, Wm + W.fpe_h, C, Gp + P.fpe_ew, Gp + P.fpe_eb, d.BL, C, C))));
         petr_gemm_args g = lin_dgrad(Wm + W.d_fpe_u, Pm + P.fpe_ew, Wm + W.d_fpe_h, d.BL, C, C);
         g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.fpe_h; g.ldr = C;
+        g = L16(g);
         RUN(petr_gemm(&g, s));
-        RUN(wgrad(lin_wgrad(Wm + W.d_fpe_h, C, Wm + W.mem, C, Gp + P.fpe_rw, Gp + P.fpe_rb, d.BL, C, C)));
+        RUN(wgrad(L16(lin_wgrad(Wm + W.d_fpe_h, C, Wm + W.mem, C, Gp + P.fpe_rw, Gp + P.fpe_rb, d.BL, C, C))));
         g = lin_dgrad(Wm + W.d_fpe_h, Pm + P.fpe_rw, Wm + W.d_mem, d.BL, C, C);
         g.flags = PETR_GEMM_ACCUMULATE;
+        g = L16(g);
         RUN(petr_gemm(&g, s));
       }
       // position_encoder and adapt_pos3d (inputs carry no gradient)
@@ -1157,9 +1211,10 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         const int Kin = which == 0 ? 3 * d.D : C * 3 / 2;
         float* d_hpe = Wm + W.d_hpe[which];
         const float* dy = which == 0 ? d_pe : d_pos;
-        RUN(wgrad(lin_wgrad(dy, C, hid, 4 * C, Gp + w2, Gp + b2, d.BL, C, 4 * C)));
+        RUN(wgrad(L16(lin_wgrad(dy, C, hid, 4 * C, Gp + w2, Gp + b2, d.BL, C, 4 * C))));
         petr_gemm_args g = lin_dgrad(dy, Pm + w2, d_hpe, d.BL, C, 4 * C);
         g.flags = PETR_GEMM_RELU_MASK; g.r = hid; g.ldr = 4 * C;
+        g = L16(g);
         RUN(petr_gemm(&g, s));
         g = gemm0();      // dW1[4C, Kin] += sum_{view, hw} d_h[view*HW+hw][f] * feat[view][c][hw]
         g.a = d_hpe; g.lda = 4 * C; g.a_kcontig = 0;
@@ -1168,7 +1223,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g.M = 4 * C; g.N = Kin; g.K = V * d.HW;
         g.k_seg = d.HW; g.a_seg_stride = (long)d.HW * 4 * C; g.b_seg_stride = (long)Kin * d.HW;
         g.flags = PETR_GEMM_ATOMIC; g.split_k = 8;
-        RUN(wgrad(g));
+        RUN(wgrad(L16(g)));
       }
       // input_proj
       {
@@ -1179,13 +1234,14 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g.M = C; g.N = d.Cin; g.K = V * d.HW;
         g.k_seg = d.HW; g.a_seg_stride = (long)d.HW * C; g.b_seg_stride = (long)d.Cin * d.HW;
         g.flags = PETR_GEMM_ATOMIC; g.split_k = 16;
-        RUN(wgrad(g));
+        RUN(wgrad(L16(g)));
         if (gr->d_feats) {
           g = gemm0();      // d_x[view][ci][hw] = sum_o W[o][ci] * d_mem[view*HW+hw][o]
           g.a = Pm + P.in_w; g.lda = d.Cin; g.a_kcontig = 0;
           g.b = Wm + W.d_mem; g.ldb = C; g.b_kcontig = 1; g.b_bs0 = (long)d.HW * C;
           g.c = gr->d_feats; g.ldc = d.HW; g.c_bs0 = (long)d.Cin * d.HW;
           g.M = d.Cin; g.N = d.HW; g.K = C; g.nb0 = V;
+          g = L16(g);
           RUN(petr_gemm(&g, s));
         }
       }

@@ -130,7 +130,8 @@ class PETRHead(nn.Module):
         cw = code_weights if code_weights is not None else [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2]
         cw = list(cw)[:self.code_size]
         self.sync_cls_avg_factor = sync_cls_avg_factor
-        # not a reference option: 'bf16' runs the cross-attention of eval-mode forwards on bf16 K/V (see _launch_forward)
+        # not a reference option: 'bf16' = BASELINE configs 3-5: token-sized contractions and the cross-attention on the
+        # bf16 matrix cores, forward and backward (see _launch_forward)
         self.attn_dtype = kwargs.get('attn_dtype', 'fp32')
         self.num_query, self.num_classes, self.in_channels = num_query, num_classes, in_channels
         self.num_reg_fcs = num_reg_fcs
@@ -424,9 +425,11 @@ class PETRHead(nn.Module):
             seed = getattr(self, '_dropout_seed_override', None)
             io.dropout_seed = int(seed) if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
         self._last_dropout = (int(io.dropout_seed), drop_p)
-        # attn_dtype = 'bf16' (attribute, default 'fp32'): cross-attention on bf16 copies of the projected K/V with fp32
-        # softmax / accumulation (BASELINE configs 3-5).  Inference only this round: training mode and backward
-        # refuse it inside the library (no bf16 attention backward yet).
+        # attn_dtype = 'bf16' (attribute, default 'fp32'; BASELINE configs 3-5): what torch.autocast(bfloat16) would do
+        # to the token-sized part of the head - every L-row contraction (input_proj, both position-embedding MLPs, the
+        # K/V projections, PETRv2's fpe) and the cross-attention round their operands to bf16 and accumulate in fp32, in
+        # the forward and in the backward (petr_mha_bwd_bf16, gemm_bf16.hip); parameters, gradients, softmax statistics,
+        # LayerNorms and the 900-row query side stay fp32.
         attn_dtype = getattr(self, 'attn_dtype', 'fp32')
         if attn_dtype not in ('fp32', 'bf16'):
             raise ValueError(f"attn_dtype must be 'fp32' or 'bf16', got {attn_dtype!r}")

@@ -138,12 +138,129 @@ def cpu_baseline(workload, batch, num_query, budget_s=25.0, train=True):
             'fwd_value': round(batch / dtf, 4), 'ms_per_step': round(dt * 1e3, 2), 'fwd_ms': round(dtf * 1e3, 2)}
 
 
+# algorithmic work per sample, GFLOP of one forward
+HEAD_FWD_GFLOP = {'c5': 63.7, 'p4_1408': 183.6, 'p4_1600': 250.9, 'v2_800': 137.3}
+ATTN_FWD_GFLOP = {'c5': 23.36, 'p4_1408': 93.43, 'p4_1600': 132.71, 'v2_800': 66.36}
+
+
+def step_gflop(workload, batch):
+    """forward + backward: 3x the forward contractions, and the attention backward recomputes P (5 products for the
+    forward's 2): + 0.5x the attention core."""
+    return batch * (3.0 * HEAD_FWD_GFLOP[workload] + 0.5 * ATTN_FWD_GFLOP[workload])
+
+
+PROF_NAMES = {1: 'mha_fwd_self', 17: 'mha_fwd_cross', 2: 'mha_bwd_self', 18: 'mha_bwd_cross', 4: 'coords3d'}
+
+
+def profile_kernels(step_fn, n_steps):
+    """mean duration of the tagged dispatches (HIP events attached to the dispatch on its launch stream) inside real steps"""
+    from petr_amd import _C
+    L = _C.lib()
+    cap = n_steps * 64
+    _C.check(L.petr_prof_begin(cap), 'petr_prof_begin')
+    for _ in range(n_steps):
+        step_fn()
+    torch.cuda.synchronize()
+    ms = (C.c_float * cap)()
+    tags = (C.c_int * cap)()
+    cnt = C.c_int()
+    _C.check(L.petr_prof_end(ms, tags, cap, C.byref(cnt)), 'petr_prof_end')
+    acc = {}
+    for i in range(cnt.value):
+        acc.setdefault(tags[i], []).append(ms[i])
+    return {PROF_NAMES.get(t, str(t)): {'launches': len(v), 'mean_us': round(sum(v) / len(v) * 1e3, 2)} for t, v in acc.items()}
+
+
+def build_workload(workload, batch, num_query, dev, rank=0, need_grad=True):
+    import petr_amd
+    n, h, w, ph, pw, _ = WORKLOADS[workload]
+    torch.manual_seed(0)                     # identical weights on every rank (reference init rules)
+    v2 = workload.startswith('v2')
+    head = petr_amd.build_head((petr_amd.petrv2_head_cfg if v2 else petr_amd.petr_head_cfg)(num_query=num_query))
+    head.init_weights()
+    head = head.to(dev)
+    metas = synthetic_metas(batch, n, (ph, pw), seed=rank * 1000)
+    g = torch.Generator().manual_seed(1234 + rank)           # rank-offset seed: every rank has its own samples
+    feats = torch.randn(batch, n, 256, h, w, generator=g).to(dev).requires_grad_(need_grad)
+    g_cls = torch.randn(6, batch, num_query, 10, generator=g).to(dev)
+    g_box = torch.randn(6, batch, num_query, 10, generator=g).to(dev)
+    return head, metas, feats, g_cls, g_box
+
+
+def extra_workload(workload, dev, num_query, steps, warmup):
+    """One BASELINE single-GPU workload (B = 1 per GPU, the reference's samples_per_gpu) in fp32 and in bf16: training
+    step time, cross-attention kernel times from dispatch events, attention roofline fraction against the dtype's peak."""
+    B = 1
+    n, h, w, _, _, desc = WORKLOADS[workload]
+    Ltok = n * h * w
+    head, metas, feats, g_cls, g_box = build_workload(workload, B, num_query, dev)
+    head.train()
+    torch.manual_seed(2000)
+
+    def step():
+        head.zero_grad_flat()
+        feats.grad = None
+        out = head([feats], metas)
+        torch.autograd.backward([out['all_cls_scores'], out['all_bbox_preds']], [g_cls, g_box])
+
+    res = {'desc': desc, 'tokens': Ltok}
+    for mode in ('fp32', 'bf16'):
+        head.attn_dtype = mode
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        head.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                head([feats], metas)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                head([feats], metas)
+            torch.cuda.synchronize()
+            fwd_ms = (time.perf_counter() - t1) / steps * 1e3
+        head.train()
+        k = profile_kernels(step, min(steps, 10))
+        peak = BF16_MFMA_PEAK_TFLOPS if mode == 'bf16' else FP32_MFMA_PEAK_TFLOPS
+        leg = {'ms_per_step': round(ms, 4), 'samples_per_s': round(B / (ms * 1e-3), 2), 'fwd_ms': round(fwd_ms, 4),
+               'step_tflops': round(step_gflop(workload, B) / ms, 1),
+               'step_frac_of_peak': round(step_gflop(workload, B) / ms / peak, 4)}
+        if 'mha_fwd_cross' in k:
+            us = k['mha_fwd_cross']['mean_us']
+            ach = 4.0 * B * num_query * Ltok * 256 / (us * 1e-6) / 1e12
+            leg['roofline'] = {'kernel': 'cross-attention forward (training variant: dropout inside)', 'bound': 'mfma',
+                               'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                               'mean_launch_us': us}
+        if 'mha_bwd_cross' in k:
+            us = k['mha_bwd_cross']['mean_us']
+            ach = 10.0 * B * num_query * Ltok * 256 / (us * 1e-6) / 1e12
+            leg['mha_bwd_cross'] = {'mean_launch_us': us, 'achieved': round(ach, 2), 'frac': round(ach / peak, 4)}
+        res[mode] = leg
+    head.attn_dtype = 'fp32'
+    del head, feats, g_cls, g_box
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='c5', choices=sorted(WORKLOADS))
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
+                    help='arithmetic of the timed step: fp32 (BASELINE configs[1], the headline) or bf16 (configs 2-4: '
+                         'token-sized contractions + cross-attention on bf16 MFMA, fp32 accumulate)')
+    ap.add_argument('--timed-only', action='store_true',
+                    help='profiling aid: stop after the timed region (no forward-only / kernel-event / loss / bf16 / CPU legs)')
+    ap.add_argument('--no-extra-workloads', action='store_true',
+                    help='skip the other BASELINE single-GPU workloads (p4_1408, p4_1600, v2_800; fp32 and bf16) that '
+                         'the default N=1 run times after the headline')
     ap.add_argument('--batch', type=int, default=1, help='samples per GPU (the reference configs use 1)')
     ap.add_argument('--queries', type=int, default=900)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -157,9 +274,21 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start N fresh ranks ourselves (one process per GPU, the
+        # reference's tools/dist_train.sh:7-9 does the same with torch.distributed.launch).  This parent has not touched
+        # the GPU; it only waits for the child and passes its exit code on (never exec after a GPU init on this pool).
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N')
+        raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
     # rehearsal knobs (not used by the driver): PETR_BENCH_DEVICE pins every rank to one GPU and PETR_BENCH_BACKEND=gloo
@@ -175,18 +304,11 @@ def main():
 
     n, h, w, ph, pw, desc = WORKLOADS[args.workload]
     B, Q = args.batch, args.queries
-    torch.manual_seed(0)                     # identical weights on every rank (reference init rules)
-    v2 = args.workload.startswith('v2')
-    head = petr_amd.build_head((petr_amd.petrv2_head_cfg if v2 else petr_amd.petr_head_cfg)(num_query=Q))
-    head.init_weights()
+    head, metas, feats, g_cls, g_box = build_workload(args.workload, B, Q, dev, rank, need_grad=not args.fwd_only)
     # the metric is the TRAINING step: train() = the reference's dropouts (p = 0.1, six per decoder layer) are active
-    head = head.to(dev).train(not (args.eval_mode or args.fwd_only))
+    head.train(not (args.eval_mode or args.fwd_only))
+    head.attn_dtype = args.dtype
     torch.manual_seed(1000 + rank)           # the per-forward dropout seeds are drawn from this stream: one per rank
-    metas = synthetic_metas(B, n, (ph, pw), seed=rank * 1000)
-    g = torch.Generator().manual_seed(1234 + rank)           # rank-offset seed: every rank has its own samples
-    feats = torch.randn(B, n, 256, h, w, generator=g).to(dev).requires_grad_(not args.fwd_only)
-    g_cls = torch.randn(6, B, Q, 10, generator=g).to(dev)
-    g_box = torch.randn(6, B, Q, 10, generator=g).to(dev)
     reducer = None
     if world > 1 or args.force_reducer:
         # ORDER MATTERS (measured, MI355X / ROCm 7.2): the head's side streams must exist before the RCCL communicator
@@ -243,6 +365,26 @@ def main():
         reducer = None
     if rank == 0:
         log(f'timed region done: {elapsed / args.steps * 1e3:.3f} ms/step')
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({'metric': 'samples/sec PETRHead fwd+bwd', 'value': round(world * B * args.steps / elapsed, 3),
+                              'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                              'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'dtype': args.dtype,
+                              'config': {'workload': args.workload, 'timed_only': True}}), flush=True)
+        if world > 1 or args.force_reducer:
+            dist.destroy_process_group()
+        return
+    # ---- a sustained region of >= 1 s (the driver's K steps at ~5 ms each are a 0.1 s region): same step, more of them ----
+    sustained = None
+    if world == 1 and not args.fwd_only:
+        n_sus = max(args.steps, int(1000.0 / max(elapsed / args.steps * 1e3, 1e-3)) + 1)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        torch.cuda.synchronize()
+        sus = time.perf_counter() - ts
+        sustained = {'steps': n_sus, 'ms_per_step': round(sus / n_sus * 1e3, 4), 'samples_per_s': round(B * n_sus / sus, 2)}
     # ---- forward-only rate (for the ">= 10x the host-CPU forward" target), same steady state ----
     fwd_ms = None
     was_training = head.training
@@ -259,65 +401,65 @@ def main():
             fwd_ms = (time.perf_counter() - t1) / args.steps * 1e3
         head.train(was_training)
 
-    # ---- roofline leg: HIP events around the tagged kernels inside real steps (rank 0) ----
+    # ---- roofline leg: HIP events attached to the tagged dispatches inside real steps (rank 0) ----
     roofline = None
     bf16_leg = None
     kernels = {}
+    peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
+    Ltok = n * h * w
     if rank == 0:
-        L = _C.lib()
         prof_steps = min(args.steps, 20)
-        _C.check(L.petr_prof_begin(prof_steps * 64), 'petr_prof_begin')
-        for _ in range(prof_steps):
-            step()
-        torch.cuda.synchronize()
-        cap = prof_steps * 64
-        ms = (C.c_float * cap)()
-        tags = (C.c_int * cap)()
-        cnt = C.c_int()
-        _C.check(L.petr_prof_end(ms, tags, cap, C.byref(cnt)), 'petr_prof_end')
-        acc = {}
-        for i in range(cnt.value):
-            acc.setdefault(tags[i], []).append(ms[i])
-        names = {1: 'mha_fwd_self', 17: 'mha_fwd_cross', 2: 'mha_bwd_self', 18: 'mha_bwd_cross', 4: 'coords3d'}
-        for tag, v in acc.items():
-            kernels[names.get(tag, str(tag))] = {'launches': len(v), 'mean_us': round(sum(v) / len(v) * 1e3, 2)}
-        Ltok = n * h * w
+        kernels = profile_kernels(step, prof_steps)
         if 'mha_fwd_cross' in kernels:
             us = kernels['mha_fwd_cross']['mean_us']
-            flops = 4.0 * B * Q * Ltok * 256            # QK^T + PV of one layer (SURVEY §8(d))
+            flops = 4.0 * B * Q * Ltok * 256            # QK^T + PV of one layer (SURVEY 8(d))
             ach = flops / (us * 1e-6) / 1e12
-            traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json)
-            try:
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-                if B == 1:
-                    traffic = pmc[args.workload]['mha_fwd_cross']['traffic_bytes']
-            except (OSError, KeyError, ValueError):
-                traffic = None
-            roofline = {'kernel': 'mha_fwd_kernel (cross-attention, one decoder layer)', 'bound': 'mfma',
-                        'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (scripts/pmc_traffic.sh,
+            # method inside the file); only the workload / dtype / batch that was profiled gets a number, everything else null
+            traffic, traffic_source = None, None
+            for fn in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
+                    ent = pmc[args.workload]['mha_fwd_cross']
+                    if B == 1 and ent.get('dtype', 'fp32') == args.dtype:
+                        traffic, traffic_source = ent['traffic_bytes'], f'profiles/{fn} (separate rocprofv3 --pmc passes)'
+                        break
+                except (OSError, KeyError, ValueError, TypeError):
+                    continue
+            roofline = {'kernel': ('mha_fwd_bf16_kernel' if args.dtype == 'bf16' else 'mha_fwd_kernel') +
+                                  ' (cross-attention, one decoder layer)', 'bound': 'mfma',
+                        'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                        'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                         'flops_per_launch': flops, 'mean_launch_us': us}
         if roofline is not None and was_training:
             # the same kernel without the dropout of the probabilities (eval-mode / inference forwards)
             head.eval()
-            _C.check(L.petr_prof_begin(prof_steps * 64), 'petr_prof_begin')
-            with torch.no_grad():
-                for _ in range(prof_steps):
+
+            def fwd_only():
+                with torch.no_grad():
                     head([feats], metas)
-            torch.cuda.synchronize()
-            _C.check(L.petr_prof_end(ms, tags, cap, C.byref(cnt)), 'petr_prof_end')
+            ke = profile_kernels(fwd_only, prof_steps)
             head.train(was_training)
-            v = [ms[i] for i in range(cnt.value) if tags[i] == 17]
-            if v:
-                us_e = sum(v) / len(v) * 1e3
+            if 'mha_fwd_cross' in ke:
+                us_e = ke['mha_fwd_cross']['mean_us']
                 ach_e = roofline['flops_per_launch'] / (us_e * 1e-6) / 1e12
                 roofline['timed_variant'] = 'training mode: dropout (p = 0.1) of the attention probabilities inside the kernel'
                 roofline['inference_variant'] = {'mean_launch_us': round(us_e, 2), 'achieved': round(ach_e, 2),
-                                                 'frac': round(ach_e / FP32_MFMA_PEAK_TFLOPS, 4)}
-        # ---- bf16 K/V attention (BASELINE configs 3-5), inference forward only this round: not part of `value` ----
-        if roofline is not None and world == 1 and not args.fwd_only:
-            head.eval()
+                                                 'frac': round(ach_e / peak, 4)}
+        # ---- the same workload in bf16 (BASELINE configs 2-4 are bf16; configs[1], the headline, is fp32): training step
+        #      AND inference forward, not part of `value` ----
+        if roofline is not None and world == 1 and not args.fwd_only and args.dtype == 'fp32':
             head.attn_dtype = 'bf16'
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            bt_ms = (time.perf_counter() - t3) / args.steps * 1e3
+            kb = profile_kernels(step, prof_steps)
+            head.eval()
             with torch.no_grad():
                 for _ in range(5):
                     head([feats], metas)
@@ -327,31 +469,29 @@ def main():
                     head([feats], metas)
                 torch.cuda.synchronize()
                 bf_ms = (time.perf_counter() - t3) / args.steps * 1e3
-                _C.check(L.petr_prof_begin(prof_steps * 64), 'petr_prof_begin')
-                for _ in range(prof_steps):
-                    head([feats], metas)
-                torch.cuda.synchronize()
-                _C.check(L.petr_prof_end(ms, tags, cap, C.byref(cnt)), 'petr_prof_end')
             head.attn_dtype = 'fp32'
             head.train(was_training)
-            v = [ms[i] for i in range(cnt.value) if tags[i] == 17]
-            if v:
-                us_b = sum(v) / len(v) * 1e3
-                ach_b = roofline['flops_per_launch'] / (us_b * 1e-6) / 1e12
-                bf16_leg = {'what': 'eval-mode forward with attn_dtype=bf16 (token-sized contractions on bf16 MFMA, K/V stored as bf16, bf16 K/V '
-                                    'cross-attention, fp32 softmax/accumulate); '
-                                    'training stays fp32 this round',
-                            'fwd_ms': round(bf_ms, 4), 'fwd_samples_per_s': round(B / (bf_ms * 1e-3), 2),
-                            'mha_fwd_cross_us': round(us_b, 2), 'achieved_tflops': round(ach_b, 1),
-                            'peak_tflops': BF16_MFMA_PEAK_TFLOPS, 'frac': round(ach_b / BF16_MFMA_PEAK_TFLOPS, 4),
-                            'bound': 'softmax instruction stream and LDS/barrier latency, not MFMA (head_dim 32: 4 MFMA per 32x32 '
-                                     'score block; DESIGN.md section 4)'}
+            bf16_leg = {'what': 'same workload with attn_dtype=bf16: token-sized contractions (forward, input- and weight-gradients) '
+                                'on bf16 MFMA with fp32 accumulation, K/V stored as bf16, bf16 cross-attention forward and backward, '
+                                'fp32 softmax / LayerNorm / parameters / gradients; training step (dropout 0.1) and eval forward',
+                        'ms_per_step': round(bt_ms, 4), 'samples_per_s': round(B / (bt_ms * 1e-3), 2),
+                        'fwd_ms': round(bf_ms, 4), 'fwd_samples_per_s': round(B / (bf_ms * 1e-3), 2),
+                        'peak_tflops': BF16_MFMA_PEAK_TFLOPS}
+            for nm, mult in (('mha_fwd_cross', 4.0), ('mha_bwd_cross', 10.0)):
+                if nm in kb:
+                    us_b = kb[nm]['mean_us']
+                    ach_b = mult * B * Q * Ltok * 256 / (us_b * 1e-6) / 1e12
+                    bf16_leg[nm] = {'mean_launch_us': us_b, 'achieved_tflops': round(ach_b, 1),
+                                    'frac': round(ach_b / BF16_MFMA_PEAK_TFLOPS, 4)}
+            bf16_leg['bound'] = ('softmax instruction stream and LDS/barrier latency, not MFMA (head_dim 32: 4 MFMA per 32x32 '
+                                 'score block in the forward, 10 in the backward; DESIGN.md section 4)')
         if 'mha_bwd_cross' in kernels:
             us = kernels['mha_bwd_cross']['mean_us']
             kernels['mha_bwd_cross']['tflops'] = round(10.0 * B * Q * Ltok * 256 / (us * 1e-6) / 1e12, 2)
+            kernels['mha_bwd_cross']['frac'] = round(kernels['mha_bwd_cross']['tflops'] / peak, 4)
         if 'coords3d' in kernels:
             us = kernels['coords3d']['mean_us']
-            kernels['coords3d']['gbs'] = round(B * Ltok * 192 * 4 / (us * 1e-6) / 1e9, 1)   # volume bytes (SURVEY §8(d))
+            kernels['coords3d']['gbs'] = round(B * Ltok * 192 * 4 / (us * 1e-6) / 1e9, 1)   # volume bytes (SURVEY 8(d))
             kernels['coords3d']['hbm_frac'] = round(kernels['coords3d']['gbs'] / HBM_PEAK_GBS, 4)
 
     # ---- the full training step of the reference: forward -> PETRHead.loss -> backward ----
@@ -390,27 +530,46 @@ def main():
                             '6 levels, 40 ground-truth boxes per sample) -> backward'}
     if rank == 0:
         log('kernel timing done')
+
+    # ---- the other BASELINE single-GPU workloads (configs[2] p4_1408, configs[3] per-GPU p4_1600, configs[4] per-GPU
+    #      v2_800), fp32 and bf16, same step / same timing method, fewer steps; no CPU baselines for these ----
+    workloads = None
+    if rank == 0 and world == 1 and not args.fwd_only and not args.no_extra_workloads and args.workload == 'c5' \
+            and args.batch == 1 and not args.eval_mode:
+        del head, feats, g_cls, g_box
+        torch.cuda.empty_cache()
+        workloads = {}
+        for name in ('p4_1408', 'p4_1600', 'v2_800'):
+            workloads[name] = extra_workload(name, dev, Q, steps=min(args.steps, 20), warmup=min(max(args.warmup, 3), 5))
+            log(f'workload {name}: fp32 {workloads[name]["fp32"]["ms_per_step"]} ms/step, '
+                f'bf16 {workloads[name]["bf16"]["ms_per_step"]} ms/step')
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, B, Q, train=was_training)
 
     if rank == 0:
         samples = world * B * args.steps
+        ms_step = elapsed / args.steps * 1e3
+        prec = 'bf16 operands / fp32 accumulate' if args.dtype == 'bf16' else 'fp32'
         out = {
             'metric': 'samples/sec PETRHead fwd+bwd' if not args.fwd_only else 'samples/sec PETRHead fwd',
             'value': round(samples / elapsed, 3), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{desc}, {Q} queries, 6 decoder layers, fp32 (BASELINE configs[1])'
-                       if args.workload == 'c5' else f'{desc}, {Q} queries, 6 decoder layers, fp32',
+            'warmup': args.warmup, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.dtype == 'bf16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{desc}, {Q} queries, 6 decoder layers, {prec}'
+                                   + (' (BASELINE configs[1])' if args.workload == 'c5' and args.dtype == 'fp32' else ''),
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world}',
                        'dropout': ('0.1 at all six sites of every decoder layer (training mode; the CPU baseline too)'
                                    if was_training else 'off (eval mode, as the CPU baseline)'),
                        'fwd_only_leg': 'eval mode (inference forward)'},
             'fwd_ms': round(fwd_ms, 4) if fwd_ms is not None else None,
             'fwd_samples_per_s': round(B / (fwd_ms * 1e-3), 2) if fwd_ms else None,
+            # whole-step fraction of the matrix peak next to the kernel fraction in `roofline` (algorithmic FLOP of fwd + bwd)
+            'step_tflops': None if args.fwd_only else round(step_gflop(args.workload, B) * world / ms_step, 1),
+            'step_frac_of_peak': None if args.fwd_only else round(step_gflop(args.workload, B) / ms_step / peak, 4),
+            'sustained': sustained,
             'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu, 'with_loss': loss_leg,
-            'bf16_attention_inference': bf16_leg,
+            'bf16': bf16_leg, 'workloads': workloads,
         }
         if cpu and fwd_ms:
             out['fwd_speedup_vs_cpu'] = round((B / (fwd_ms * 1e-3)) / cpu['fwd_value'], 1)

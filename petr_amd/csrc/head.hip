@@ -692,6 +692,28 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   uint16_t* k16 = reinterpret_cast<uint16_t*>(Wm + W.k_all);
   uint16_t* v16 = reinterpret_cast<uint16_t*>(Wm + W.v_all);
 
+  // The K / V projections of all layers are layer-invariant in their input, but only layer 0's are needed before the first
+  // cross-attention: with side streams they are issued as [layer 0] + [layers 1..NL-1], the main stream waits for the
+  // first part only and the second one runs beside decoder layer 0 (whose 900-row kernels leave most CUs idle).
+  hipEvent_t ev_k0 = nullptr, ev_v0 = nullptr;
+  auto kv_project = [&](petr_gemm_args g, void* side, hipEvent_t* ev0) -> int {
+    // opt-in (PETR_KV_FWD_SPLIT=1): same-box A/B on MI355X (scripts/ab_overlap.sh) was neutral at c5 and p4-1600, fp32
+    // and bf16 (within 0.3 %), so the single batched contraction stays the default
+    static const bool split = getenv("PETR_KV_FWD_SPLIT") && atoi(getenv("PETR_KV_FWD_SPLIT")) != 0;
+    if (!ln.ctx || d.NL < 2 || !split) return petr_gemm(&g, side);
+    const bool st16 = (g.flags & PETR_GEMM_STORE_BF16) != 0;     // bf16 store: c strides count 2-byte elements
+    petr_gemm_args g0 = g;
+    g0.nb1 = 1;
+    RUN(petr_gemm(&g0, side));
+    *ev0 = ln.next();
+    (void)hipEventRecord(*ev0, (hipStream_t)side);
+    petr_gemm_args g1 = g;
+    g1.nb1 = d.NL - 1;
+    g1.b = g.b + g.b_bs1;
+    g1.bias = g.bias + g.bias_bs1;
+    g1.c = st16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(g.c) + g.c_bs1) : g.c + g.c_bs1;
+    return petr_gemm(&g1, side);
+  };
   ln.fork(0);
   ln.fork(1);
   // ---- side 2: input_proj (petr_head.py:390) + sine 3D (positional_encoding.py:58-100) + adapt_pos3d hidden ----
@@ -766,7 +788,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.c = Wm + W.k_all; g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
     g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
     if (attn_bf16) { g.c = reinterpret_cast<float*>(k16); g.flags |= PETR_GEMM_STORE_BF16 | PETR_GEMM_BF16; }   // bf16 MFMA, bf16 store
-    RUN(petr_gemm(&g, s1));
+    RUN(kv_project(g, s1, &ev_k0));
   }
   {
     // V_l = mem Wv_l^T + bv_l on side 2 (memory was produced there)
@@ -777,7 +799,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.c = Wm + W.v_all; g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
     g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
     if (attn_bf16) { g.c = reinterpret_cast<float*>(v16); g.flags |= PETR_GEMM_STORE_BF16 | PETR_GEMM_BF16; }
-    RUN(petr_gemm(&g, s2));
+    RUN(kv_project(g, s2, &ev_v0));
   }
 
   // ---- main: query embedding pos2posemb3d + MLP (petr_head.py:422-423) ----
@@ -832,7 +854,15 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     // cross-attention: q = x1 + query_pos, k = mem + pos, v = mem (petr_transformer.py:341-362)
     g = lin_fwd(Wm + lw.xe1, Pm + lp.ca_in_w, Pm + lp.ca_in_b, Wm + lw.qc, d.BQ, C, C);
     RUN(petr_gemm(&g, s));
-    if (l == 0) {          // K/V of all layers come from the side streams
+    if (l == 0) {          // K/V come from the side streams: layer 0's now, the other layers' before layer 1
+      if (ev_k0) {
+        (void)hipStreamWaitEvent(ln.main, ev_k0, 0);
+        (void)hipStreamWaitEvent(ln.main, ev_v0, 0);
+      } else {
+        ln.join(0);
+        ln.join(1);
+      }
+    } else if (l == 1 && ev_k0) {
       ln.join(0);
       ln.join(1);
     }
@@ -971,6 +1001,12 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   // PETRv2's feature-guided PE) and the cross-attention backward run on the bf16 matrix cores, like their forwards
   const bool bf16 = io->attn_bf16 != 0;
   auto L16 = [&](const petr_gemm_args& g) { return bf16 ? to_bf16(g) : g; };
+  // PETR_KV_BWD_OVERLAP=1 (opt-in): the K/V projection backward per layer on the side streams beside the decoder chain
+  // instead of two batched contractions in the final stage.  Measured and rejected as a default (same-box A/B,
+  // scripts/ab_overlap.sh, two rounds): c5 fp32 5.09 -> 5.21 ms, p4-1600 bf16 6.98 -> 7.52 ms, p4-1600 fp32 neutral - the
+  // main queue is ~85 % busy already, so token-sized work beside it takes CUs from the critical chain.
+  static const bool kv_overlap_env = getenv("PETR_KV_BWD_OVERLAP") && atoi(getenv("PETR_KV_BWD_OVERLAP")) != 0;
+  const bool kv_overlap = kv_overlap_env && ln.ctx != nullptr;
   const uint16_t* k16 = reinterpret_cast<const uint16_t*>(Wm + W.k_all);
   const uint16_t* v16 = reinterpret_cast<const uint16_t*>(Wm + W.v_all);
 
@@ -1126,6 +1162,35 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
                 Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, d_ao, Wm + lw.lse_c, kpm, d_qc,
                 Wm + W.dk_all + (long)l * d.L * C, Wm + W.dv_all + (long)l * d.L * C, d, (int)d.L, mws, W.mha_ws_bytes, s,
                 training ? &dr[2] : nullptr));
+      // K / V projection backward of THIS layer (token-sized: the largest contractions of the backward) leaves the
+      // critical path: dW_l and d_src (+)= dKV_l W_l go to the side streams right behind the attention backward that
+      // produced dK_l / dV_l and run beside the 900-row chain of the remaining layers; the final stage only joins.
+      // K path on side 0, V path on side 1 (each accumulates into one buffer, so each stays on one in-order stream).
+      for (int kv = 0; kv < 2 && kv_overlap; ++kv) {
+        const float* dkv = Wm + (kv == 0 ? W.dk_all : W.dv_all) + (long)l * d.L * C;
+        const float* src = kv == 0 ? Wm + W.mempos : Wm + W.mem;
+        void* sd = ln.side(kv);
+        ln.fork(kv);
+        petr_gemm_args g2 = gemm0();      // dW_l[C,C] += sum_{b,t} dKV[b][l][t][o] * src[b][t][c]
+        g2.a = dkv; g2.lda = C; g2.a_kcontig = 0;
+        g2.b = src; g2.ldb = C; g2.b_kcontig = 0;
+        g2.c = Gp + lp.ca_in_w + (long)(kv + 1) * C * C; g2.ldc = C;
+        g2.a_colsum = Gp + lp.ca_in_b + (kv + 1) * C;
+        g2.M = C; g2.N = C; g2.K = (int)d.BL;
+        g2.k_seg = (int)d.L; g2.a_seg_stride = (long)d.NL * d.L * C; g2.b_seg_stride = d.L * C;
+        g2.flags = PETR_GEMM_ATOMIC;
+        g2.split_k = 32;
+        g2 = L16(g2);
+        RUN(petr_gemm(&g2, sd));
+        g2 = gemm0();      // d_src[b][t][c] (+)= sum_o dKV[b][l][t][o] * W_l[o][c]   (first layer processed overwrites)
+        g2.a = dkv; g2.lda = C; g2.a_kcontig = 1; g2.a_bs0 = (long)d.NL * d.L * C;
+        g2.b = Pm + lp.ca_in_w + (long)(kv + 1) * C * C; g2.ldb = C; g2.b_kcontig = 0;
+        g2.c = Wm + (kv == 0 ? W.d_mempos : W.d_mem); g2.ldc = C; g2.c_bs0 = d.L * C;
+        g2.M = (int)d.L; g2.N = C; g2.K = C; g2.nb0 = d.B;
+        if (l != d.NL - 1) g2.flags = PETR_GEMM_ACCUMULATE;
+        g2 = L16(g2);
+        RUN(petr_gemm(&g2, sd));
+      }
       // q projection of the cross-attention (rows 0..C of in_proj): weight grads live in the final block
       RUN(wgrad(lin_wgrad(d_qc, C, Wm + lw.xe1, C, Gp + lp.ca_in_w, Gp + lp.ca_in_b, d.BQ, C, C)));
       float* d_x1 = Wm + lg.d_x1;
@@ -1160,8 +1225,10 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
     } else {
       // ================= final stage =================
       const int V = d.B * d.N;
-      // K/V projections of all layers (need every layer's dK/dV): input gradients on main, weights on the sides
-      for (int kv = 0; kv < 2; ++kv) {
+      // the K/V projection backward of every layer ran on the side streams behind its layer (see there): wait for it
+      ln.join(0);
+      ln.join(1);
+      for (int kv = 0; kv < 2 && !kv_overlap; ++kv) {     // single-stream / opt-out schedule: all layers in one contraction each
         const float* dkv = Wm + (kv == 0 ? W.dk_all : W.dv_all);
         const float* src = kv == 0 ? Wm + W.mempos : Wm + W.mem;
         petr_gemm_args g = gemm0();      // dW_l[C,C] += sum_{b,t} dKV[b][l][t][o] * src[b][t][c]

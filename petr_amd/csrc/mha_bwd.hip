@@ -245,6 +245,16 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
     float* dk = a.dk + (long)b * a.dk_bs + (long)hd * a.dk_hs;
     float* dv = a.dv + (long)b * a.dv_bs + (long)hd * a.dv_hs;
     const bool use_atomic = p.q_splits > 1;
+    // += with ALL loads of the old values issued before the first store (a load-add-store per element serialises
+    // sixteen dependent memory round trips at the end of every workgroup)
+    float oldk[16], oldv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int idx = j * 64 + lane;
+      const int kg = min(key0 + (idx >> 5), a.L - 1);
+      oldk[j] = use_atomic ? 0.f : dk[(long)kg * a.dk_rs + (idx & 31)];
+      oldv[j] = use_atomic ? 0.f : dv[(long)kg * a.dv_rs + (idx & 31)];
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int idx = j * 64 + lane;
@@ -258,8 +268,8 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
           atomicAdd(pk, gk);
           atomicAdd(pv, gv);
         } else {
-          *pk += gk;
-          *pv += gv;
+          *pk = oldk[j] + gk;
+          *pv = oldv[j] + gv;
         }
       }
     }

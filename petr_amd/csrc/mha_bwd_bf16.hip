@@ -145,54 +145,51 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
   const int qt_end = min(qtiles, qt_begin + p.qtiles_per_split);
   const float sc2 = a.scale * LOG2E;
 
-  // ---- staging of a query tile: threads 0..255 move Q (and LSE), threads 256..511 move dO and O (-> delta) ----
-  const bool is_q = t < 256;
+  // ---- roles: waves 0..3 stage the query tiles (global loads -> LDS images), waves 4..7 sum the partial dQ tiles and
+  //      issue the float atomics.  A wave that did both would wait for its loads with s_waitcnt vmcnt(0) (hipcc cannot
+  //      count a wait across the loop's back edge) and so drain the atomics it has just issued - ~3 000 cycles under
+  //      load, once per query tile (first version: 228 us at L = 24 000; the ISA showed vmcnt(0) right behind the atomics).
+  const bool stager = __builtin_amdgcn_readfirstlane(t >> 6) < 4;          // wave-uniform, provably
   const int srow = (t & 255) >> 3, sc4 = t & 7;
-  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+  float4 rq = make_float4(0.f, 0.f, 0.f, 0.f), rg = rq, ro = rq;
   float lreg = 0.f;
   auto gload = [&](int qt) {
     const int row = min(qt * 32 + srow, a.Q - 1);        // rows beyond Q re-read row Q-1 (zeroed at the LDS store)
-    if (is_q) {
-      r0 = *reinterpret_cast<const float4*>(qp + (long)row * a.q_rs + 4 * sc4);
-      lreg = a.lse[(long)bh * a.Q + min(qt * 32 + (t & 31), a.Q - 1)];
-    } else {
-      r0 = *reinterpret_cast<const float4*>(gp + (long)row * a.do_rs + 4 * sc4);
-      r1 = *reinterpret_cast<const float4*>(op + (long)row * a.o_rs + 4 * sc4);
-    }
+    rq = *reinterpret_cast<const float4*>(qp + (long)row * a.q_rs + 4 * sc4);
+    rg = *reinterpret_cast<const float4*>(gp + (long)row * a.do_rs + 4 * sc4);
+    ro = *reinterpret_cast<const float4*>(op + (long)row * a.o_rs + 4 * sc4);
+    lreg = a.lse[(long)bh * a.Q + min(qt * 32 + (t & 31), a.Q - 1)];
   };
   auto stage = [&](int qt, int buf) {
     const bool ok = qt * 32 + srow < a.Q;
     float* rw = rows_s + buf * 96;
-    if (is_q) {
-      const uint2 v = pack4f(ok ? r0.x * sc2 : 0.f, ok ? r0.y * sc2 : 0.f, ok ? r0.z * sc2 : 0.f, ok ? r0.w * sc2 : 0.f);
-      *reinterpret_cast<uint2*>(img + (buf * 2 + 0) * 32 * QP + srow * QP + 4 * sc4) = v;
-      if (t < 32) {
-        const bool rok = qt * 32 + t < a.Q;
-        rw[t] = rok ? -lreg * LOG2E : -INFINITY;         // rows beyond Q: p = exp2(-inf) = 0
-        if (DROP) reinterpret_cast<uint32_t*>(rw)[64 + t] = drop_row_key(p.drop, (uint32_t)(bh * a.Q + min(qt * 32 + t, a.Q - 1)));
-      }
-    } else {
-      const uint2 v = pack4f(ok ? r0.x : 0.f, ok ? r0.y : 0.f, ok ? r0.z : 0.f, ok ? r0.w : 0.f);
-      *reinterpret_cast<uint2*>(img + (buf * 2 + 1) * 32 * QP + srow * QP + 4 * sc4) = v;
-      // delta from the ROUNDED dO, the one the dP' product multiplies: sum_k ds[q][k] = sum_k p (dP' - delta) must vanish
-      // (softmax shift invariance), and with near-uniform attention over thousands of keys dQ = sum_k ds K is the small
-      // residual of that cancellation - a delta formed from the unrounded dO leaves a coherent 2^-9 * |dO||O| offset on
-      // every ds of the row that the sum over keys amplifies by sqrt(L) (measured: 5-8 % L2 error of the query-side
-      // gradients at L = 16 896 with the fp32 delta)
-      const bf16x4 rb = __builtin_bit_cast(bf16x4, v);
-      float dl = ((float)rb[0] * r1.x + (float)rb[1] * r1.y) + ((float)rb[2] * r1.z + (float)rb[3] * r1.w);   // 8 lanes share a row
-      dl += __shfl_xor(dl, 1, 64);
-      dl += __shfl_xor(dl, 2, 64);
-      dl += __shfl_xor(dl, 4, 64);
-      if (sc4 == 0) rw[32 + srow] = ok ? -dl : 0.f;
+    const uint2 vq = pack4f(ok ? rq.x * sc2 : 0.f, ok ? rq.y * sc2 : 0.f, ok ? rq.z * sc2 : 0.f, ok ? rq.w * sc2 : 0.f);
+    *reinterpret_cast<uint2*>(img + (buf * 2 + 0) * 32 * QP + srow * QP + 4 * sc4) = vq;
+    const uint2 vg = pack4f(ok ? rg.x : 0.f, ok ? rg.y : 0.f, ok ? rg.z : 0.f, ok ? rg.w : 0.f);
+    *reinterpret_cast<uint2*>(img + (buf * 2 + 1) * 32 * QP + srow * QP + 4 * sc4) = vg;
+    // delta from the ROUNDED dO, the one the dP' product multiplies: sum_k ds[q][k] = sum_k p (dP' - delta) must vanish
+    // (softmax shift invariance), and with near-uniform attention over thousands of keys dQ = sum_k ds K is the small
+    // residual of that cancellation - a delta formed from the unrounded dO would leave a coherent 2^-9 |dO||O| offset on
+    // every ds of the row
+    const bf16x4 rb = __builtin_bit_cast(bf16x4, vg);
+    float dl = ((float)rb[0] * ro.x + (float)rb[1] * ro.y) + ((float)rb[2] * ro.z + (float)rb[3] * ro.w);   // 8 lanes share a row
+    dl += __shfl_xor(dl, 1, 64);
+    dl += __shfl_xor(dl, 2, 64);
+    dl += __shfl_xor(dl, 4, 64);
+    if (sc4 == 0) rw[32 + srow] = ok ? -dl : 0.f;
+    if (t < 32) {
+      const bool rok = qt * 32 + t < a.Q;
+      rw[t] = rok ? -lreg * LOG2E : -INFINITY;         // rows beyond Q: p = exp2(-inf) = 0
+      if (DROP) reinterpret_cast<uint32_t*>(rw)[64 + t] = drop_row_key(p.drop, (uint32_t)(bh * a.Q + min(qt * 32 + t, a.Q - 1)));
     }
   };
-  // sum the eight waves' dQ partial tiles of query tile qt and add them to global dQ (two 128-byte rows per instruction)
+  // sum the eight waves' dQ partial tiles of query tile qt and add them to global dQ (two 128-byte rows per instruction);
+  // called by waves 4..7: thread u = t - 256 owns elements u + 256 j
   auto flush = [&](const float* rb, int qt) {
     float* dq = a.dq + (long)b * a.dq_bs + (long)hd * a.dq_hs + (long)qt * 32 * a.dq_rs;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int idx = t + 512 * j;
+    for (int j = 0; j < 4; ++j) {
+      const int idx = (t - 256) + 256 * j;
       const int q = idx >> 5, d = idx & 31;
       const float* s = rb + q * RP + d;
       const float v = ((s[0] + s[RED_SLAB]) + (s[2 * RED_SLAB] + s[3 * RED_SLAB])) +
@@ -207,7 +204,7 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
   const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   uint16_t* dsw = ds_all + wave * 32 * DSP;
 
-  if (qt_begin < qt_end) {
+  if (stager && qt_begin < qt_end) {
     gload(qt_begin);
     stage(qt_begin, 0);
     if (qt_begin + 1 < qt_end) gload(qt_begin + 1);
@@ -215,10 +212,13 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
   for (int qt = qt_begin; qt < qt_end; ++qt) {
     const int buf = (qt - qt_begin) & 1;
     __syncthreads();     // images / row constants of tile qt complete; every dQ partial of tile qt-1 written
-    if (qt > qt_begin) flush(red + (buf ^ 1) * 8 * RED_SLAB, qt - 1);
-    if (qt + 1 < qt_end) {
-      stage(qt + 1, buf ^ 1);
-      if (qt + 2 < qt_end) gload(qt + 2);
+    if (stager) {
+      if (qt + 1 < qt_end) {
+        stage(qt + 1, buf ^ 1);
+        if (qt + 2 < qt_end) gload(qt + 2);
+      }
+    } else if (qt > qt_begin) {
+      flush(red + (buf ^ 1) * 8 * RED_SLAB, qt - 1);
     }
     const uint16_t* Qi = img + (buf * 2 + 0) * 32 * QP;
     const uint16_t* Gi = img + (buf * 2 + 1) * 32 * QP;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
     for (int r = 0; r < 16; ++r) rb[mfma32_row(r, h) * RP + c] = dQp[r];
   }
   __syncthreads();
-  if (qt_begin < qt_end) flush(red + ((qt_end - 1 - qt_begin) & 1) * 8 * RED_SLAB, qt_end - 1);
+  if (!stager && qt_begin < qt_end) flush(red + ((qt_end - 1 - qt_begin) & 1) * 8 * RED_SLAB, qt_end - 1);
   __syncthreads();     // every wave is done reading the partial tiles: the slabs become transposition scratch
 
   // ---- dK / dV: transpose each wave's 32 x 32 accumulators through LDS, then row-major adds ----
@@ -337,6 +337,16 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
         tk[c * RP + mfma32_row(r, h)] = dKt[i][r] * LN2;      // Q2 carried scale*log2e: dK = scale * ds^T Q = ln2 * ds^T Q2
         tv[c * RP + mfma32_row(r, h)] = dVt[i][r];
       }
+      // += with ALL loads of the old values issued before the first store (a load-add-store per element serialises
+      // sixteen dependent memory round trips at the end of every workgroup)
+      float oldk[16], oldv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int idx = j * 64 + lane;
+        const int kg = min(key_base + 32 * i + (idx >> 5), a.L - 1);
+        oldk[j] = use_atomic ? 0.f : dk[(long)kg * a.dk_rs + (idx & 31)];
+        oldv[j] = use_atomic ? 0.f : dv[(long)kg * a.dv_rs + (idx & 31)];
+      }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int idx = j * 64 + lane;
@@ -350,8 +360,8 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
             atomicAdd(pk, gk);
             atomicAdd(pv, gv);
           } else {
-            *pk += gk;
-            *pv += gv;
+            *pk = oldk[j] + gk;
+            *pv = oldv[j] + gv;
           }
         }
       }

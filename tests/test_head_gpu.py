@@ -381,7 +381,8 @@ def test_head_p4_1408_forward_bf16_attention(pa):
 # 8-20 % while the outputs move by 2e-4 ... 5e-4 of their range; the gradients inherit a 3-9 % L2 deviation (cosine
 # >= 0.995 per tensor at c5 / p4-1408; the small 12-view PETRv2 branch tensors reach 17 %).  Bars: outputs 1e-3 of the
 # range (REL_BF16); per tensor L2 <= 0.25 and cosine >= 0.97; whole flat gradient L2 <= 0.10; tensors whose true gradient
-# is identically zero (softmax shift invariance) <= 1e-3 of the largest gradient entry.
+# is identically zero (softmax shift invariance) or below 1e-3 of the largest gradient entry: absolute error <= 1e-3 of
+# that entry.
 def _bf16_grad_case(pa, head, oracle, feats, metas, g_cls, g_box, masks=None, l2_bar=0.25, cos_bar=0.97, flat_bar=0.10,
                     out_bar=REL_BF16):
     want, wgrads, wfeat = _oracle_grads(oracle, feats, metas, g_cls, g_box, torch.float64, masks)
@@ -400,9 +401,11 @@ def _bf16_grad_case(pa, head, oracle, feats, metas, g_cls, g_box, masks=None, l2
     stats, bad, num, den = {}, {}, 0.0, 0.0
     for name, (a, b) in pairs.items():
         a, b = a.detach().double().cpu().flatten(), b.double().flatten()
-        if b.abs().max().item() < 1e-7 * gmax:          # identically-zero gradient: absolute check
-            if a.abs().max().item() > 1e-3 * gmax:
-                bad[name] = ('zero-gradient tensor', a.abs().max().item() / gmax)
+        if b.abs().max().item() < 1e-3 * gmax:          # (near-)zero gradient: absolute check against the largest entry
+            if (a - b).abs().max().item() > 1e-3 * gmax:
+                bad[name] = ('small-gradient tensor', (a - b).abs().max().item() / gmax)
+            num += (a - b).pow(2).sum().item()
+            den += b.pow(2).sum().item()
             continue
         l2 = ((a - b).norm() / b.norm()).item()
         cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
@@ -562,11 +565,22 @@ def test_bench_contract(extra):
     assert 'workload' in d['config'] and 'model' not in d['config']
     rf = d['roofline']
     assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
-    assert 0.2 < rf['frac'] < 1.0 and rf['traffic'] > 9.5e6
+    assert 0.2 < rf['frac'] < 1.0
+    assert (rf['traffic'] is None and rf['traffic_source'] is None) or (rf['traffic'] > 9.5e6 and 'profiles/' in rf['traffic_source'])
     assert abs(d['value'] - 1000.0 / d['ms_per_step']) < 0.02 * d['value']
+    assert d['sustained']['steps'] >= 3 and d['sustained']['ms_per_step'] > 0
+    assert 0.0 < d['step_frac_of_peak'] < 1.0
+    # the bf16 leg of the headline workload and every other BASELINE single-GPU workload, fp32 and bf16, in the same line
+    assert d['bf16']['ms_per_step'] > 0 and d['bf16']['mha_bwd_cross']['mean_launch_us'] > 0
+    assert set(d['workloads']) == {'p4_1408', 'p4_1600', 'v2_800'}
+    for w in d['workloads'].values():
+        for mode in ('fp32', 'bf16'):
+            assert w[mode]['ms_per_step'] > 0 and 0.0 < w[mode]['roofline']['frac'] < 1.0
+        assert w['bf16']['ms_per_step'] < w['fp32']['ms_per_step']
 
 
-def test_bench_two_rank_control_flow_on_one_gpu():
+@pytest.mark.parametrize('launcher', ['torch.distributed.run', 'self'])
+def test_bench_two_rank_control_flow_on_one_gpu(launcher):
     """The N > 1 launch of bench.py (torch.distributed.run, one rank per process) rehearsed on this one-GPU box: both
     ranks on card 0, gloo instead of RCCL (PETR_BENCH_DEVICE / PETR_BENCH_BACKEND).  Guards the rule that nothing
     behind the timed region issues a collective on rank 0 only (cpu baseline, loss and bf16 legs are single-process
@@ -581,8 +595,12 @@ def test_bench_two_rank_control_flow_on_one_gpu():
         port = so.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1']
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=root,
-                       env=dict(os.environ, PETR_BENCH_DEVICE='0', PETR_BENCH_BACKEND='gloo'))
+    env = dict(os.environ, PETR_BENCH_DEVICE='0', PETR_BENCH_BACKEND='gloo')
+    if launcher == 'self':     # `python bench.py --gpus 2` with no launcher: bench.py starts its own two ranks
+        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1']
+        for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+            env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith('{')]
     assert len(lines) == 1, r.stdout[-1000:]

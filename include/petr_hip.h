@@ -360,7 +360,9 @@ int petr_reduce_batch(const float* x, int B, long rows, int C, float* out, int a
  *     avg_factors (optional, DEVICE, 2 floats) = (cls_avg_factor, num_total_pos) BEFORE their max(., 1) clamps, as
  *     left by the caller's cross-rank reduce_mean (petr_head.py:620-622 with sync_cls_avg_factor, :630-631 always);
  *     read by the kernels, so the caller's all-reduce needs no host round trip.  NULL: the single-process values
- *     derived from num_pos. */
+ *     derived from num_pos.
+ *     gt_labels outside [0, NC) never become addresses: such a box costs 100 for every query, its query matches no
+ *     class in the focal loss, and the 32-bit word at ws + (NL*max(Gtot,1)*Q + 2*NL) * 8 bytes is set non-zero. */
 typedef struct {
   const float* cls; const float* box;
   const float* gt_boxes; const int64_t* gt_labels; const int* gt_offsets;

@@ -65,6 +65,14 @@ __global__ __launch_bounds__(256) void loss_cost_kernel(const LossParams p) {
   const float* cls = a.cls + (((long)lvl * a.B + b) * a.Q + q) * a.NC;
   const float* box = a.box + (((long)lvl * a.B + b) * a.Q + q) * a.CS;
   const long label = a.gt_labels[g];
+  // A label outside [0, NC) (mmdet3d yields -1 for classes missing from CLASSES when ObjectNameFilter is absent) must
+  // not become an address: the cost of such a box is the nan_to_num value 100 for every query, the loss kernel treats
+  // its query as matching no class, and a flag word behind the level sums reports it (losses.loss_label_errors()).
+  if (label < 0 || label >= a.NC) {
+    if (q == 0 && lvl == 0) atomicOr(reinterpret_cast<int*>(p.sums + 2 * a.NL), 1);
+    p.cost[((long)lvl * a.Gtot + g) * a.Q + q] = 100.0;
+    return;
+  }
   float n[10];
   normalize_gt(a.gt_boxes + (long)g * 9, n);
   // FocalLossCost (mmdet): logits in, eps 1e-12
@@ -236,7 +244,8 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossParams p) {
     const int b = (int)((idx / a.Q) % a.B);
     const int asg = a.assigned[idx];
     const int g = asg > 0 ? p.offs[b] + asg - 1 : -1;
-    const long label = g >= 0 ? a.gt_labels[g] : a.NC;      // num_classes = background (petr_head.py:507-510)
+    long label = g >= 0 ? a.gt_labels[g] : a.NC;            // num_classes = background (petr_head.py:507-510)
+    if (label < 0 || label > a.NC) label = a.NC;            // out-of-range label (flagged by loss_cost_kernel): no positive class
     const float* cls = a.cls + idx * a.NC;
     float* dc = a.d_cls ? a.d_cls + idx * a.NC : nullptr;
     for (int c = 0; c < a.NC; ++c) {
@@ -369,7 +378,7 @@ extern "C" int petr_loss_fwd_bwd(const petr_loss_args* ap, void* stream) {
   p.cls_norm = (float)((double)ap->cls_weight / (cls_avg + eps));
   p.box_norm = (float)((double)ap->bbox_weight / (box_avg + eps));
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(p.sums, 0, 2 * (size_t)ap->NL * sizeof(double), s);
+  hipError_t e = hipMemsetAsync(p.sums, 0, (2 * (size_t)ap->NL + 1) * sizeof(double), s);   // level sums + the label-error flag word
   PETR_CHECK(e == hipSuccess, PETR_ERR_LAUNCH, "loss: memset failed: %s", hipGetErrorString(e));
   if (ap->Gtot > 0) {
     hipLaunchKernelGGL(loss_cost_kernel, dim3((unsigned)cdiv(ap->Q, 256), (unsigned)ap->Gtot, (unsigned)ap->NL), dim3(256), 0, s, p);

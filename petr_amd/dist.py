@@ -22,12 +22,19 @@ class BucketedGradAllReduce:
     ``merge`` consecutive backward stages form one bucket (xGMI is point-to-point: fewer, larger
     collectives amortise the per-collective latency better than many small ones)."""
 
-    def __init__(self, head, group=None, merge=2, average=True, force=False):
+    def __init__(self, head, group=None, merge=2, average=True, force=False, broadcast_parameters=True):
         self.head = head
         self.group = group
         self.average = average
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = force          # issue the collectives even for a single rank (tests the stream/event path)
+        self._sync = True           # False inside no_sync(): gradient accumulation, no exchange
+        if self.world > 1 and broadcast_parameters:
+            # every rank starts from rank 0's parameters, as DDP (the thing this replaces) does at construction: ONE
+            # broadcast of the flat buffer.  Without it identical weights would rest on every rank seeding the same
+            # RNG, and a checkpoint loaded on rank 0 only would silently diverge.
+            dist.broadcast(head.flat_parameters(), src=dist.get_global_rank(group, 0) if group is not None else 0,
+                           group=group)
         stages = head.gradient_buckets()
         self.n_stages = len(stages)
         self.buckets = []           # (last_stage, begin, end)
@@ -43,9 +50,24 @@ class BucketedGradAllReduce:
         head._stage_hook = self._on_stage
         head._stage_hook_stages = sorted(self._by_stage)     # the backward is cut only where a bucket ends
 
+    def no_sync(self):
+        """Context manager for gradient accumulation (DDP's ``no_sync``): backward passes inside it add into the flat
+        gradient buffer without any exchange; the first backward OUTSIDE it all-reduces the accumulated sum.  (Calling
+        the exchange on every micro-step instead would average gradients that were already averaged.)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, self._sync = self._sync, False
+            try:
+                yield
+            finally:
+                self._sync = prev
+        return ctx()
+
     def _on_stage(self, stage):
         b = self._by_stage.get(stage)
-        if b is None or (self.world == 1 and not self.force):
+        if b is None or not self._sync or (self.world == 1 and not self.force):
             return
         flat = self.head._flat_grad[b[1]:b[2]]
         if self._cuda:

@@ -55,6 +55,18 @@ def synced_avg_factors(num_pos, num_queries_total, cfg, device, group=None):
     return t
 
 
+_last_flag = None
+
+
+def loss_label_errors():
+    """True if the most recent ``PETRHead.loss`` call saw a ground-truth label outside [0, num_classes) (the kernels
+    guard such labels instead of indexing with them; reading the flag synchronises with the device, so it is a
+    separate, optional call - e.g. once per epoch or in a debugging run)."""
+    if _last_flag is None:
+        return False
+    return bool(_last_flag.view(torch.int32)[0].item() != 0)
+
+
 class _LossFn(torch.autograd.Function):
     """[NL, 2] losses; the kernels already produced the gradients of their sum, backward only weights the level
     slices by the incoming gradient."""
@@ -86,6 +98,9 @@ class _LossFn(torch.autograd.Function):
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 8
         a.avg_factors = avg.data_ptr() if avg is not None else None
         _C.check(L.petr_loss_fwd_bwd(C.byref(a), _stream()), 'petr_loss_fwd_bwd')
+        # the label-error flag word sits behind the cost matrix and the level sums (petr_hip.h); kept for loss_label_errors()
+        global _last_flag
+        _last_flag = ws[NL * max(gtot, 1) * Q + 2 * NL:NL * max(gtot, 1) * Q + 2 * NL + 1]
         ctx.save_for_backward(d_cls, d_box)
         ctx.mark_non_differentiable(assigned)
         ctx.n_levels = NL

@@ -94,18 +94,27 @@ class _HeadFn(torch.autograd.Function):
         ctx.head, ctx.run = head, run
         ctx.feats_requires_grad = feats.requires_grad
         cls, bbox = head._launch_forward(run, feats)
+        # the box backward recomputes the sigmoid derivative from the OUTPUT buffer (petr_bbox_epilogue_bwd), so an
+        # in-place edit of all_bbox_preds between forward and backward (the reference edits it in place) must trip
+        # autograd's version check instead of silently corrupting the gradients
+        ctx.save_for_backward(bbox)
         return cls, bbox
 
     @staticmethod
     def backward(ctx, d_cls, d_bbox):
         head, run = ctx.head, ctx.run
+        _ = ctx.saved_tensors            # raises if all_bbox_preds was modified in place
+        if run.consumed:
+            raise _C.PetrHipError('this forward has already been backpropagated: its workspace went back to the pool '
+                                  '(retain_graph / a second backward is not supported; run the forward again)')
+        run.consumed = True
         d_feats = head._launch_backward(run, d_cls.contiguous(), d_bbox.contiguous(), ctx.feats_requires_grad)
         return None, d_feats, None, None
 
 
 class _Run:
     """Everything one forward needs to keep alive until its backward: workspace, outputs, host inputs."""
-    __slots__ = ('cfg', 'io', 'ws', 'feats', 'img2lidar', 'mask', 'cls', 'bbox', 'key', 'time_div')
+    __slots__ = ('cfg', 'io', 'ws', 'feats', 'img2lidar', 'mask', 'cls', 'bbox', 'key', 'time_div', 'consumed')
 
 
 @register('HEADS')
@@ -149,7 +158,6 @@ class PETRHead(nn.Module):
         num_feats = positional_encoding['num_feats']
         assert num_feats * 2 == self.embed_dims, \
             f'embed_dims should be exactly 2 times of num_feats. Found {self.embed_dims} and {num_feats}.'
-        assert self.position_level == 0 or True
         assert num_reg_fcs == 2, 'the fused branches kernel chain is built for num_reg_fcs=2 (every reference config)'
         assert not normedlinear, 'normedlinear=True is not used by any reference config'
         assert with_position and with_multiview, \
@@ -330,7 +338,11 @@ class PETRHead(nn.Module):
         return out
 
     def _attach_grads(self, zero_if_detached=True):
-        sentinel = self._grad_views[0]
+        # sentinel = the first parameter that takes a gradient (a frozen first parameter never gets .grad, which would
+        # re-zero the flat buffer on every backward and break gradient accumulation)
+        sentinel = next(((p, gv) for p, gv in self._grad_views if p.requires_grad), None)
+        if sentinel is None:
+            return
         if sentinel[0].grad is None or sentinel[0].grad.data_ptr() != sentinel[1].data_ptr():
             if zero_if_detached:
                 self._flat_grad.zero_()
@@ -359,7 +371,7 @@ class PETRHead(nn.Module):
             self._free_ws[key] = []
         cfg, ws_bytes = self._runs[key]
         run = _Run()
-        run.key, run.cfg, run.time_div = key, cfg, 0.0
+        run.key, run.cfg, run.time_div, run.consumed = key, cfg, 0.0, False
         pool = self._free_ws[key]
         run.ws = pool.pop() if pool else torch.empty(ws_bytes // 4, dtype=torch.float32, device=feats.device)
         # img2lidar: float64 inverse per view on the host, as the reference (petr_head.py:308-315)
@@ -375,10 +387,23 @@ class PETRHead(nn.Module):
         if n <= 0:
             return None
         if self._ctx is None:
-            h = C.c_void_p()
-            _C.check(_C.lib().petr_ctx_create(C.byref(h), n), 'petr_ctx_create')
+            self._ensure_flat()
+            with torch.cuda.device(self._flat.device):      # the side streams belong to the head's device
+                h = C.c_void_p()
+                _C.check(_C.lib().petr_ctx_create(C.byref(h), n), 'petr_ctx_create')
             self._ctx = h
         return self._ctx
+
+    def __getstate__(self):
+        """pickling / copy.deepcopy: drop the process-local handles (stream context, pooled workspaces, live runs)."""
+        st = self.__dict__.copy()
+        for k in ('_ctx', '_last_run', '_stage_hook', '_stage_hook_stages'):
+            st.pop(k, None)
+        st['_ctx'] = None
+        st['_runs'], st['_free_ws'] = {}, {}
+        st['_flat'] = st['_flat_grad'] = st['_layout'] = st['_anchor'] = None      # re-flattened lazily on first use
+        st.pop('_grad_views', None)
+        return st
 
     def __del__(self):
         ctx = getattr(self, '_ctx', None)
@@ -398,6 +423,10 @@ class PETRHead(nn.Module):
         return float((ts[:, 1, :] - ts[:, 0, :]).mean(-1)[0])
 
     def _launch_forward(self, run, feats):
+        with torch.cuda.device(self._flat.device):       # streams / side streams of the head's own device
+            return self._launch_forward_impl(run, feats)
+
+    def _launch_forward_impl(self, run, feats):
         L = _C.lib()
         B, N = run.cfg.B, run.cfg.N
         run.feats = feats.contiguous()
@@ -465,6 +494,10 @@ class PETRHead(nn.Module):
         return rates.pop()
 
     def _launch_backward(self, run, d_cls, d_bbox, want_dfeats, stage_hook=None):
+        with torch.cuda.device(self._flat.device):
+            return self._launch_backward_impl(run, d_cls, d_bbox, want_dfeats, stage_hook)
+
+    def _launch_backward_impl(self, run, d_cls, d_bbox, want_dfeats, stage_hook=None):
         L = _C.lib()
         self._attach_grads()
         g = _C.HeadGrads()

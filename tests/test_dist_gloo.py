@@ -31,8 +31,16 @@ def _worker(rank, world, port, n, stages, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from petr_amd.dist import BucketedGradAllReduce
     head = _FakeHead(n, stages, seed=100 + rank)
+    head._flat += float(rank + 1)          # ranks start from DIFFERENT parameters ...
     red = BucketedGradAllReduce(head, merge=2, average=True)
+    assert torch.equal(head._flat, torch.full((n,), 1.0))      # ... and leave the constructor with rank 0's (broadcast)
     assert [b[0] for b in red.buckets] == [1, 3, 4]
+    before = head._flat_grad.clone()
+    with red.no_sync():                    # gradient accumulation: stage hooks inside no_sync() exchange nothing
+        for s in range(len(stages)):
+            head._stage_hook(s)
+        red.finish()
+    assert torch.equal(head._flat_grad, before)
     tail = head._flat_grad[stages[-1][1]:].clone()
     for s in range(len(stages)):          # what PETRHead._launch_backward does after each stage
         head._stage_hook(s)

@@ -608,3 +608,125 @@ def test_bench_two_rank_control_flow_on_one_gpu(launcher):
     assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak'
     assert d['config']['global_batch'] == 2 if 'global_batch' in d['config'] else True
     assert d['cpu_baseline'] is None and d['with_loss'] is None        # single-process legs are skipped
+
+
+# ------------------------------------------------------------------ data parallel: the REAL head on two ranks
+def _dp_worker(rank, world, port, out_dir):
+    """one data-parallel rank on card 0 (gloo stands in for RCCL on a one-GPU box): real PETRHead, its own sample,
+    staged backward + BucketedGradAllReduce; rank 1 starts from perturbed weights to prove the constructor's broadcast."""
+    import torch.distributed as dist
+    import petr_amd
+    from petr_amd.dist import BucketedGradAllReduce
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    head = petr_amd.build_head(petr_amd.petr_head_cfg(num_query=64))
+    head.init_weights()
+    head = head.cuda().eval()
+    head._context()                              # side streams before the process group (DESIGN.md section 6)
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    if rank == 1:
+        with torch.no_grad():
+            head.flat_parameters().mul_(1.5)
+    red = BucketedGradAllReduce(head, merge=2)
+    metas = O.synthetic_img_metas(2, 2, (128, 192), (100, 150), seed=5)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(2, 2, 256, 4, 6, generator=g)
+    g_cls, g_box = torch.randn(6, 2, 64, 10, generator=g), torch.randn(6, 2, 64, 10, generator=g)
+    x = feats[rank:rank + 1].cuda().requires_grad_(True)
+    head.zero_grad_flat()
+    out = head([x], metas[rank:rank + 1])
+    torch.autograd.backward([out['all_cls_scores'], out['all_bbox_preds']],
+                            [g_cls[:, rank:rank + 1].cuda().contiguous(), g_box[:, rank:rank + 1].cuda().contiguous()])
+    red.finish()
+    torch.cuda.synchronize()
+    torch.save({'grad': head.flat_gradients().cpu(), 'params': head.flat_parameters().cpu(), 'd_feats': x.grad.cpu()},
+               os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_real_head_two_ranks_equal_batch2(pa, tmp_path):
+    """two ranks, one sample each, real head + staged backward + bucketed all-reduce (AVG) == 1/2 x the
+    gradient of ONE process running both samples as a batch of 2 (the upstream gradient is given per sample, so the
+    batch-2 gradient is the sum over the samples).  Both ranks on card 0, gloo instead of RCCL."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f'rank{r}.pt')) for r in range(2))
+    assert torch.equal(r0['params'], r1['params'])                    # broadcast: rank 1's perturbation is gone
+    torch.manual_seed(0)
+    head = pa.build_head(pa.petr_head_cfg(num_query=64))
+    head.init_weights()
+    head = head.cuda().eval()
+    assert torch.equal(head.flat_parameters().cpu(), r0['params'])
+    metas = O.synthetic_img_metas(2, 2, (128, 192), (100, 150), seed=5)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(2, 2, 256, 4, 6, generator=g)
+    g_cls, g_box = torch.randn(6, 2, 64, 10, generator=g), torch.randn(6, 2, 64, 10, generator=g)
+    x = feats.cuda().requires_grad_(True)
+    head.zero_grad_flat()
+    out = head([x], metas)
+    torch.autograd.backward([out['all_cls_scores'], out['all_bbox_preds']], [g_cls.cuda(), g_box.cuda()])
+    want = 0.5 * head.flat_gradients().cpu().double()
+    n = head.gradient_buckets()[-1][1]                                # code_weights beyond it carry no gradient
+    for r in (r0, r1):
+        got = r['grad'].double()
+        err = (got[:n] - want[:n]).abs().max().item() / want[:n].abs().max().item()
+        assert err < 2e-5, err                                        # float-atomic ordering + batch-2 vs batch-1 tiling
+    assert torch.equal(r0['grad'], r1['grad'])                        # both ranks hold the same averaged gradient
+    assert (torch.cat([r0['d_feats'], r1['d_feats']]).double() - x.grad.cpu().double()).abs().max().item() < 1e-4 * \
+        x.grad.abs().max().item()
+
+
+def test_head_autograd_guards_and_deepcopy(pa):
+    """(i) an in-place edit of all_bbox_preds between forward and backward trips autograd's version check (the
+    box backward reads that buffer); (ii) a second backward of one forward is refused (its workspace is back in the pool);
+    (iii) a frozen first parameter does not re-zero the flat gradient on every backward (gradient accumulation);
+    (iv) copy.deepcopy of a head that has already run gives an independent, working head."""
+    import copy
+    oracle = O.seeded_head(2, 1234, num_query=16)
+    head = make_pair(pa, oracle, num_query=16)
+    metas = O.synthetic_img_metas(1, 2, (128, 192), (100, 150), seed=3)
+    feats = torch.randn(1, 2, 256, 4, 6, generator=torch.Generator().manual_seed(0)).cuda()
+    out = head([feats.clone().requires_grad_(True)], metas)
+    out['all_bbox_preds'][..., 0] += 1.0
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        (out['all_cls_scores'].sum() + out['all_bbox_preds'].sum()).backward()
+    out = head([feats.clone().requires_grad_(True)], metas)
+    loss = out['all_cls_scores'].sum() + out['all_bbox_preds'].sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match='already been backpropagated'):
+        loss.backward()
+    # (iii) accumulation with the first flat parameter frozen
+    first = head._grad_views[0][0]
+    first.requires_grad_(False)
+    head.zero_grad_flat()
+    for _ in range(2):
+        o2 = head([feats], metas)
+        (o2['all_cls_scores'].sum() + o2['all_bbox_preds'].sum()).backward()
+    twice = head.flat_gradients().clone()
+    head.zero_grad_flat()
+    o2 = head([feats], metas)
+    (o2['all_cls_scores'].sum() + o2['all_bbox_preds'].sum()).backward()
+    once = head.flat_gradients().clone()
+    assert (twice - 2 * once).abs().max().item() < 1e-4 * once.abs().max().item()
+    first.requires_grad_(True)
+    # (iv) deepcopy after use
+    twin = copy.deepcopy(head)
+    with torch.no_grad():
+        a, b = head([feats], metas), twin([feats], metas)
+    assert torch.equal(a['all_cls_scores'], b['all_cls_scores'])
+    with torch.no_grad():
+        twin.input_proj.weight.mul_(2.0)                      # independent storage
+        c = head([feats], metas)
+    assert torch.equal(a['all_cls_scores'], c['all_cls_scores'])

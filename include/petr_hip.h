@@ -390,6 +390,21 @@ typedef struct {
 } petr_decode_args;
 int petr_decode_boxes(const petr_decode_args* a, void* stream);
 
+/* NMSFreeCoder.decode_single COMPLETE on the device (core/bbox/coders/nms_free_coder.py:48-97 + petr_head.py:730-751), one
+ * launch for all samples of a batch: scores = sigmoid(cls_scores[b]) ; top-k of the flattened [Q*num_classes] scores
+ * (sorted, descending: torch.topk) ; labels = index % num_classes ; boxes = denormalised bbox_preds[b][index / num_classes]
+ * (z at the bottom centre if bottom_center) ; keep = centre inside post_center_range (and score > score_threshold if > 0).
+ *     cls_scores [B,Q,num_classes] LOGITS, bbox_preds [B,Q,code]; outputs [B,k,...]; k <= 1024; if Q*num_classes < k the
+ *     tail entries have keep = 0 and index = -1.  index = the flat index torch.topk would return.                      */
+typedef struct {
+  const float* cls_scores; const float* bbox_preds;
+  float* boxes; float* scores; int64_t* labels; uint8_t* keep; int64_t* index;
+  int B, Q, num_classes, code, k;
+  float post_center_range[6]; float score_threshold;
+  int bottom_center;
+} petr_decode_topk_args;
+int petr_decode_topk(const petr_decode_topk_args* a, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Whole-path executor: PETRHead.forward (petr_head.py:366-468) / PETRv2Head.forward
  * (petrv2_head.py:429-540) and its gradient as ONE call each, all kernels enqueued on `stream`.

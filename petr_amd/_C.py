@@ -130,6 +130,13 @@ class DecodeArgs(C.Structure):       # petr_decode_args
                        ('bottom_center', C.c_int))
 
 
+class DecodeTopkArgs(C.Structure):   # petr_decode_topk_args
+    _fields_ = _fields(('cls_scores', C.c_void_p), ('bbox_preds', C.c_void_p), ('boxes', C.c_void_p), ('scores', C.c_void_p),
+                       ('labels', C.c_void_p), ('keep', C.c_void_p), ('index', C.c_void_p),
+                       ('B', C.c_int), ('Q', C.c_int), ('num_classes', C.c_int), ('code', C.c_int), ('k', C.c_int),
+                       ('post_center_range', C.c_float * 6), ('score_threshold', C.c_float), ('bottom_center', C.c_int))
+
+
 class HeadConfig(C.Structure):
     _fields_ = _fields(
         ('B', C.c_int), ('N', C.c_int), ('C_in', C.c_int), ('H', C.c_int), ('W', C.c_int),
@@ -247,7 +254,7 @@ EXPORTS = [
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
     'petr_ctx_create', 'petr_ctx_destroy', 'petr_ctx_join_into', 'petr_dropout_mask', 'petr_loss_workspace_bytes', 'petr_loss_fwd_bwd',
-    'petr_decode_boxes',
+    'petr_decode_boxes', 'petr_decode_topk',
 ]
 
 

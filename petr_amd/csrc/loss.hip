@@ -340,6 +340,142 @@ __global__ __launch_bounds__(256) void decode_boxes_kernel(petr_decode_args a) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// NMSFreeCoder.decode_single with the selection on the device (nms_free_coder.py:62-97): sigmoid + top-k of the Q*NC
+// class scores + gather + box denormalisation + range filter as ONE launch, one workgroup per sample.
+//   selection: 4-pass radix select (8 bits per pass, MSB first, histogram in LDS) over the order-preserving integer image
+//   of the LOGITS (sigmoid is monotonic: the top-k of the scores is the top-k of the logits; the score is taken
+//   afterwards from the selected logits only), then compaction of everything above the k-th key plus the lowest-index
+//   ties, then a bitonic sort of the <= 1024 selected (key descending, index ascending) - torch.topk's sorted order.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TOPK_MAX = 1024;
+
+__device__ __forceinline__ uint32_t ordered_key(float f) {      // larger float <=> larger unsigned key (NaN above +inf)
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void decode_topk_kernel(petr_decode_topk_args a) {
+  __shared__ uint32_t hist[256];
+  __shared__ unsigned long long sel[TOPK_MAX];
+  __shared__ uint32_t sh_prefix, sh_need, sh_count, sh_ties;
+  const int t = threadIdx.x;
+  const int smp = blockIdx.x;
+  const int n = a.Q * a.num_classes;
+  const float* logits = a.cls_scores + (long)smp * n;
+  const int k = a.k < n ? a.k : n;
+
+  // ---- radix select of the k-th largest key ----
+  uint32_t prefix = 0, need = (uint32_t)k;        // need: how many elements we still take among those matching `prefix`
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    const uint32_t himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int i = t; i < n; i += 1024) {
+      const uint32_t key = ordered_key(logits[i]);
+      if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (t == 0) {
+      uint32_t acc = 0;
+      int bin = 255;
+      for (; bin > 0; --bin) {                   // from the top: the bin in which the need-th largest element lies
+        if (acc + hist[bin] >= need) break;
+        acc += hist[bin];
+      }
+      sh_prefix = prefix | ((uint32_t)bin << shift);
+      sh_need = need - acc;
+    }
+    __syncthreads();
+    prefix = sh_prefix;
+    need = sh_need;
+    __syncthreads();
+  }
+  // prefix = the k-th largest key T; `need` of the elements equal to T are taken (lowest indices first)
+  if (t == 0) { sh_count = 0; sh_ties = 0; }
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {         // index order, so that the ties taken are the lowest indices
+    const int i = i0 + t;
+    const uint32_t key = i < n ? ordered_key(logits[i]) : 0u;
+    const bool gt = i < n && key > prefix;
+    const bool eq = i < n && key == prefix;
+    if (gt) sel[atomicAdd(&sh_count, 1u)] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)i);
+    // ties: rank inside this 1024-chunk by ballot-free counting through an LDS counter would lose the index order, so
+    // one wave-ordered pass: lanes take their tie in index order with a prefix count over the wave
+    const unsigned long long m = __ballot(eq);
+    __shared__ uint32_t wave_base[16];
+    const int wv = t >> 6, ln = t & 63;
+    if (ln == 0) wave_base[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (t == 0) {
+      uint32_t run = sh_ties;
+      for (int w2 = 0; w2 < 16; ++w2) { const uint32_t c = wave_base[w2]; wave_base[w2] = run; run += c; }
+      sh_ties = run;
+    }
+    __syncthreads();
+    if (eq) {
+      const uint32_t rank = wave_base[wv] + (uint32_t)__popcll(m & ((1ull << ln) - 1ull));
+      if (rank < need) sel[atomicAdd(&sh_count, 1u)] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)i);
+    }
+    __syncthreads();
+  }
+  // ---- pad to a power of two and sort descending by (key, -index) ----
+  int np2 = 1;
+  while (np2 < k) np2 <<= 1;
+  for (int i = k + t; i < np2; i += 1024) sel[i] = 0ull;
+  __syncthreads();
+  for (int size = 2; size <= np2; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = t; i < np2; i += 1024) {
+        const int j = i ^ stride;
+        if (j > i) {
+          const bool desc = (i & size) == 0;
+          const unsigned long long x = sel[i], y = sel[j];
+          if ((x < y) == desc) { sel[i] = y; sel[j] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  // ---- gather + decode (denormalize_bbox util.py:60-87, gravity -> bottom centre petr_head.py:745, range filter) ----
+  for (int i = t; i < a.k; i += 1024) {
+    const long o_i = (long)smp * a.k + i;
+    float* o = a.boxes + o_i * 9;
+    if (i >= k) {                                  // fewer candidates than k: padded, never kept
+      for (int d = 0; d < 9; ++d) o[d] = 0.f;
+      a.scores[o_i] = 0.f; a.labels[o_i] = 0; a.keep[o_i] = 0; a.index[o_i] = -1;
+      continue;
+    }
+    const uint32_t idx = ~(uint32_t)(sel[i] & 0xFFFFFFFFull);
+    const float logit = logits[idx];
+    const float score = 1.f / (1.f + expf(-logit));
+    const long q = idx / a.num_classes;
+    const float* s = a.bbox_preds + ((long)smp * a.Q + q) * a.code;
+    const float w = expf(s[2]), l = expf(s[3]), h = expf(s[5]);
+    const float cx = s[0], cy = s[1], cz = s[4];
+    o[0] = cx; o[1] = cy; o[2] = a.bottom_center ? cz - h * 0.5f : cz; o[3] = w; o[4] = l; o[5] = h; o[6] = atan2f(s[6], s[7]);
+    o[7] = a.code > 8 ? s[8] : 0.f; o[8] = a.code > 9 ? s[9] : 0.f;
+    bool keep = cx >= a.post_center_range[0] && cy >= a.post_center_range[1] && cz >= a.post_center_range[2] &&
+                cx <= a.post_center_range[3] && cy <= a.post_center_range[4] && cz <= a.post_center_range[5];
+    if (a.score_threshold > 0.f) keep = keep && score > a.score_threshold;
+    a.scores[o_i] = score;
+    a.labels[o_i] = idx % a.num_classes;
+    a.index[o_i] = idx;
+    a.keep[o_i] = keep ? 1 : 0;
+  }
+}
+
+extern "C" int petr_decode_topk(const petr_decode_topk_args* a, void* stream) {
+  PETR_CHECK(a && a->cls_scores && a->bbox_preds && a->boxes && a->scores && a->labels && a->keep && a->index, PETR_ERR_INVALID,
+             "decode_topk: null pointer");
+  PETR_CHECK(a->B > 0 && a->Q > 0 && a->num_classes > 0 && a->code >= 8 && a->k > 0, PETR_ERR_INVALID, "decode_topk: bad shape");
+  PETR_CHECK(a->k <= TOPK_MAX, PETR_ERR_UNSUPPORTED, "decode_topk: at most %d boxes per sample (max_num)", TOPK_MAX);
+  PETR_CHECK((long)a->Q * a->num_classes < (1L << 31), PETR_ERR_UNSUPPORTED, "decode_topk: Q * num_classes too large");
+  hipLaunchKernelGGL(decode_topk_kernel, dim3((unsigned)a->B), dim3(1024), 0, (hipStream_t)stream, *a);
+  PETR_LAUNCH_CHECK("decode_topk");
+  return PETR_OK;
+}
+
 extern "C" size_t petr_loss_workspace_bytes(int NL, int B, int Q, int Gtot) {
   (void)B;
   return ((size_t)NL * (Gtot > 0 ? Gtot : 1) * Q + 2 * (size_t)NL + 2) * sizeof(double);

@@ -33,14 +33,19 @@ struct Coords3dParams {
 __device__ __forceinline__ void frustum_point(const float* __restrict__ m, float u, float v, float dv, float eps,
                                               const float lo[3], const float span[3], float nrm[3]) {
   const float s = fmaxf(dv, eps);
-  const float p0 = u * s, p1 = v * s, p2 = dv;
+  const float p0 = __fmul_rn(u, s), p1 = __fmul_rn(v, s), p2 = dv;
+  // The reference multiplies [4x4] by [4x1] with torch.matmul (petr_head.py:317-319): a k-ordered sum of individually
+  // rounded fp32 products, no fused multiply-add (bmm's small-matrix path).  The same sequence here - every product and
+  // every sum rounded on its own - makes the normalised coordinates, and with them the > 1 / < 0 tests behind
+  // coords_mask (:327-328), come out bit for bit like the reference's; a contracted fma chain flipped 1-2 mask pixels per
+  // sample whose coordinate sits within an ulp of the range border.
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    float x = m[4 * a + 0] * p0;
-    x = fmaf(m[4 * a + 1], p1, x);
-    x = fmaf(m[4 * a + 2], p2, x);
-    x = x + m[4 * a + 3];
-    nrm[a] = (x - lo[a]) / span[a];
+    float x = __fmul_rn(m[4 * a + 0], p0);
+    x = __fadd_rn(x, __fmul_rn(m[4 * a + 1], p1));
+    x = __fadd_rn(x, __fmul_rn(m[4 * a + 2], p2));
+    x = __fadd_rn(x, m[4 * a + 3]);             // p3 = 1: the product is exact
+    nrm[a] = __fdiv_rn(__fsub_rn(x, lo[a]), span[a]);
   }
 }
 
@@ -59,8 +64,8 @@ __global__ __launch_bounds__(256) void coords3d_kernel(Coords3dParams p) {
   for (int j = 0; j < 4; ++j) {
     const int hw = quad * 4 + j;
     const int h = hw / p.W, w = hw - h * p.W;
-    const float u = ((float)w * p.pad_w) / (float)p.W;
-    const float v = ((float)h * p.pad_h) / (float)p.H;
+    const float u = __fdiv_rn(__fmul_rn((float)w, p.pad_w), (float)p.W);
+    const float v = __fdiv_rn(__fmul_rn((float)h, p.pad_h), (float)p.H);
     float nrm[3];
     frustum_point(m, u, v, dv, p.eps, p.lo, p.span, nrm);
 #pragma unroll
@@ -83,8 +88,8 @@ __global__ __launch_bounds__(256) void coords3d_scalar_kernel(Coords3dParams p) 
   const int h = hw / p.W, w = hw - h * p.W;
   const float* __restrict__ m = p.img2lidar + (size_t)bn * 16;
   float nrm[3];
-  frustum_point(m, ((float)w * p.pad_w) / (float)p.W, ((float)h * p.pad_h) / (float)p.H, p.depth[d], p.eps, p.lo,
-                p.span, nrm);
+  frustum_point(m, __fdiv_rn(__fmul_rn((float)w, p.pad_w), (float)p.W), __fdiv_rn(__fmul_rn((float)h, p.pad_h), (float)p.H),
+                p.depth[d], p.eps, p.lo, p.span, nrm);
   float* base = p.out + ((size_t)bn * 3 * p.D + 3 * d) * HW + hw;
 #pragma unroll
   for (int a = 0; a < 3; ++a) base[(size_t)a * HW] = logit_clamped(nrm[a], p.eps);
@@ -99,8 +104,8 @@ __global__ __launch_bounds__(256) void coords3d_mask_kernel(Coords3dParams p) {
   if (hw >= HW) return;
   const int h = hw / p.W, w = hw - h * p.W;
   const float* __restrict__ m = p.img2lidar + (size_t)bn * 16;
-  const float u = ((float)w * p.pad_w) / (float)p.W;
-  const float v = ((float)h * p.pad_h) / (float)p.H;
+  const float u = __fdiv_rn(__fmul_rn((float)w, p.pad_w), (float)p.W);
+  const float v = __fdiv_rn(__fmul_rn((float)h, p.pad_h), (float)p.H);
   int cnt = 0;
   for (int d = 0; d < p.D; ++d) {
     float nrm[3];

@@ -56,6 +56,7 @@ def synced_avg_factors(num_pos, num_queries_total, cfg, device, group=None):
 
 
 _last_flag = None
+_last_cost = None
 
 
 def loss_label_errors():
@@ -99,7 +100,8 @@ class _LossFn(torch.autograd.Function):
         a.avg_factors = avg.data_ptr() if avg is not None else None
         _C.check(L.petr_loss_fwd_bwd(C.byref(a), _stream()), 'petr_loss_fwd_bwd')
         # the label-error flag word sits behind the cost matrix and the level sums (petr_hip.h); kept for loss_label_errors()
-        global _last_flag
+        global _last_flag, _last_cost
+        _last_cost = ws[:NL * max(gtot, 1) * Q].view(NL, max(gtot, 1), Q)      # the kernels' own cost matrix (tests)
         _last_flag = ws[NL * max(gtot, 1) * Q + 2 * NL:NL * max(gtot, 1) * Q + 2 * NL + 1]
         ctx.save_for_backward(d_cls, d_box)
         ctx.mark_non_differentiable(assigned)
@@ -191,8 +193,32 @@ class NMSFreeCoder:
         return {'bboxes': boxes[mask], 'scores': scores[mask], 'labels': labels[mask]}
 
     def decode(self, preds_dicts, bottom_center=False):
+        """All samples of the batch in ONE launch (petr_decode_topk): sigmoid, top-``max_num`` selection, gather, box
+        denormalisation and the range filter run on the device; torch only allocates the outputs and applies the keep
+        mask (a boolean index: the number of kept boxes is data dependent, as in the reference)."""
         cls, box = preds_dicts['all_cls_scores'][-1], preds_dicts['all_bbox_preds'][-1]
-        return [self.decode_single(cls[i], box[i], bottom_center) for i in range(cls.size(0))]
+        if self.post_center_range is None:
+            raise NotImplementedError('Need to reorganize output as a batch, only support post_center_range is not None for now!')
+        L = _C.lib()
+        B, Q, NC = cls.shape
+        k = int(self.max_num)
+        cls, box = cls.contiguous().float(), box.contiguous().float()
+        dev = cls.device
+        boxes = torch.empty((B, k, 9), dtype=torch.float32, device=dev)
+        scores = torch.empty((B, k), dtype=torch.float32, device=dev)
+        labels = torch.empty((B, k), dtype=torch.long, device=dev)
+        index = torch.empty((B, k), dtype=torch.long, device=dev)
+        keep = torch.empty((B, k), dtype=torch.uint8, device=dev)
+        a = _C.DecodeTopkArgs(_ptr(cls), _ptr(box), _ptr(boxes), _ptr(scores), _ptr(labels), _ptr(keep), _ptr(index), B, Q, NC,
+                              box.shape[-1], k, (C.c_float * 6)(*[float(v) for v in self.post_center_range]),
+                              float(self.score_threshold) if self.score_threshold else 0.0, int(bottom_center))
+        _C.check(L.petr_decode_topk(C.byref(a), _stream()), 'petr_decode_topk')
+        self._last_index = index
+        out = []
+        for i in range(B):
+            m = keep[i].bool()
+            out.append({'bboxes': boxes[i][m], 'scores': scores[i][m], 'labels': labels[i][m]})
+        return out
 
 
 def get_bboxes(coder, preds_dicts, img_metas, rescale=False):

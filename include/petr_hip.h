@@ -129,7 +129,10 @@ int petr_dropout_mask(const petr_dropout* d, long rows, long cols, uint8_t* keep
  *         belongs to a weight-gradient contraction dW = dC^T X (A = dC^T), at no extra launch.
  * ------------------------------------------------------------------------------------------ */
 enum { PETR_GEMM_RELU = 1, PETR_GEMM_ACCUMULATE = 2, PETR_GEMM_RELU_MASK = 4, PETR_GEMM_SIGMOID_MUL = 8,
-       PETR_GEMM_ATOMIC = 16, PETR_GEMM_STORE_BF16 = 32, PETR_GEMM_BF16 = 64 };
+       PETR_GEMM_ATOMIC = 16, PETR_GEMM_STORE_BF16 = 32, PETR_GEMM_BF16 = 64, PETR_GEMM_BIAS_M = 128 };
+/* PETR_GEMM_BIAS_M: bias is indexed by the output ROW m (bias[m]) instead of the column: a convolution written with the
+ * weights as the A operand, so that its result lands channel-major (NCHW) - the CPFPN neck boundary (petr_fpn.h part
+ * below).  fp32 tiled kernel only. */
 /* PETR_GEMM_STORE_BF16: `c` points to bf16 storage (uint16_t bits, round to nearest even) and ldc / c_bs0 / c_bs1 /
  * c_nblk_stride count bf16 elements: the K/V projections feeding petr_mha_fwd_bf16.  Tiled kernel only; excludes
  * ACCUMULATE, ATOMIC and split_k > 1.
@@ -329,6 +332,13 @@ int petr_bbox_epilogue_bwd(const petr_bbox_args* a, const float* dout, float* dr
  * petr_prof_end synchronises them and returns elapsed milliseconds per record.                 */
 int petr_prof_begin(int capacity);
 int petr_prof_end(float* ms, int* tags, int cap, int* n_out);
+
+/* Top-down step of the FPN neck (models/necks/cp_fpn.py:175-186): dst[v, c, h, w] += src[v, c, hs, ws] with the nearest
+ * source pixel of F.interpolate(mode='nearest') (hs = min(floor(h * Hs / H), Hs - 1) in fp32, as torch); src is NCHW
+ * [V, C, Hs, Ws], dst is addressed through element strides (dst + v*sv + c*sc + h*sh + w*sw), so it may be NCHW or the
+ * interior of a zero-padded channels-last map. */
+int petr_fpn_upsample_add(float* dst, long sv, long sc, long sh, long sw, const float* src, int V, int C, int H, int W,
+                          int Hs, int Ws, void* stream);
 
 /* small helpers used by the host executor */
 /* SELayer gate of PETRv2 (petrv2_head.py:55-60): out = x * sigmoid(u); bwd: dx = dout*sig, du = dout*x*sig*(1-sig) */

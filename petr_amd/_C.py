@@ -61,6 +61,7 @@ class GemmArgs(C.Structure):
 
 
 GEMM_RELU, GEMM_ACCUMULATE, GEMM_RELU_MASK, GEMM_SIGMOID_MUL, GEMM_ATOMIC, GEMM_STORE_BF16, GEMM_BF16 = 1, 2, 4, 8, 16, 32, 64
+GEMM_BIAS_M = 128
 LN_RELU, LN_NAN_TO_NUM = 1, 2
 
 
@@ -219,6 +220,7 @@ def lib():
     L.petr_gate_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.petr_gate_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.petr_fill.argtypes = [C.c_void_p, C.c_float, C.c_long, C.c_void_p]
+    L.petr_fpn_upsample_add.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
     L.petr_axpy.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_long, C.c_void_p]
     L.petr_reduce_partials.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                        C.c_int, C.c_void_p]
@@ -254,7 +256,7 @@ EXPORTS = [
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
     'petr_ctx_create', 'petr_ctx_destroy', 'petr_ctx_join_into', 'petr_dropout_mask', 'petr_loss_workspace_bytes', 'petr_loss_fwd_bwd',
-    'petr_decode_boxes', 'petr_decode_topk',
+    'petr_decode_boxes', 'petr_decode_topk', 'petr_fpn_upsample_add',
 ]
 
 

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
         const int m = m0 + wm0 + i * 32 + mfma32_row(r, h);
         const int mc = min(m, g.M - 1);
         const bool ok = m < g.M && n < g.N;
-        float v = acc[i][j][r] * g.alpha + bv;
+        float v = acc[i][j][r] * g.alpha + ((flags & PETR_GEMM_BIAS_M) ? (bias ? bias[mc] : 0.f) : bv);
         float* dst = C + (long)mc * g.ldc + ccol;
         const float rv = R ? R[(long)mc * g.ldr + nc] : 0.f;      // R is kernel-uniform: no exec-masked load
         const float old = (flags & PETR_GEMM_ACCUMULATE) ? *dst : 0.f;
@@ -891,10 +891,12 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
     if (simple) return launch_bf16(g, s);
     return petr_gemm_bf16_general(g, s);
   }
+  PETR_CHECK(!((g.flags & PETR_GEMM_BIAS_M) && (g.flags & PETR_GEMM_BF16)), PETR_ERR_UNSUPPORTED,
+             "gemm: PETR_GEMM_BIAS_M (bias per output row) is implemented by the fp32 tiled kernel only");
   const long tiles32 = cdiv(g.M, 32) * cdiv(g.N, 32) * (long)g.nb0 * g.nb1;
   const bool slabs = g.split_k > 1 && !(g.flags & PETR_GEMM_ATOMIC);
   if (!slabs && tiles32 <= 256 && g.K >= 256 && g.a_kcontig && g.b_kcontig &&
-      !(g.flags & (PETR_GEMM_ATOMIC | PETR_GEMM_STORE_BF16))) {
+      !(g.flags & (PETR_GEMM_ATOMIC | PETR_GEMM_STORE_BF16 | PETR_GEMM_BIAS_M)) && g.k_seg <= 0) {
     petr_gemm_args q = g;
     q.split_k = 1;
     return vec ? launch_skinny<true>(q, s) : launch_skinny<false>(q, s);

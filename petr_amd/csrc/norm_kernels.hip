@@ -518,3 +518,32 @@ extern "C" int petr_reduce_batch(const float* x, int B, long rows, int C, float*
   PETR_LAUNCH_CHECK("reduce_batch");
   return PETR_OK;
 }
+
+
+// ---- FPN top-down step (reference models/necks/cp_fpn.py:175-186): dst += nearest-upsampled src ----
+__global__ __launch_bounds__(256) void fpn_upsample_add_kernel(float* dst, long sv, long sc, long sh, long sw, const float* src,
+                                                              int V, int C, int H, int W, int Hs, int Ws, int c_fast) {
+  const long n = (long)V * C * H * W;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  int v, c, h, w;
+  if (c_fast) {      // channels-last destination: consecutive threads = consecutive channels
+    c = (int)(idx % C); long r = idx / C; w = (int)(r % W); r /= W; h = (int)(r % H); v = (int)(r / H);
+  } else {
+    w = (int)(idx % W); long r = idx / W; h = (int)(r % H); r /= H; c = (int)(r % C); v = (int)(r / C);
+  }
+  // torch nearest: src = min(int(floorf(dst * scale)), in - 1), scale = float(in) / out
+  const float sch = (float)Hs / (float)H, scw = (float)Ws / (float)W;
+  const int hs = min((int)floorf((float)h * sch), Hs - 1), ws = min((int)floorf((float)w * scw), Ws - 1);
+  dst[(long)v * sv + (long)c * sc + (long)h * sh + (long)w * sw] += src[(((long)v * C + c) * Hs + hs) * Ws + ws];
+}
+
+extern "C" int petr_fpn_upsample_add(float* dst, long sv, long sc, long sh, long sw, const float* src, int V, int C, int H,
+                                     int W, int Hs, int Ws, void* stream) {
+  PETR_CHECK(dst && src && V > 0 && C > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0, PETR_ERR_INVALID, "fpn_upsample_add: bad arguments");
+  const long n = (long)V * C * H * W;
+  hipLaunchKernelGGL(fpn_upsample_add_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dst, sv, sc, sh,
+                     sw, src, V, C, H, W, Hs, Ws, sc == 1 ? 1 : 0);
+  PETR_LAUNCH_CHECK("fpn_upsample_add");
+  return PETR_OK;
+}

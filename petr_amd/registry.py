@@ -48,15 +48,16 @@ ATTENTION = Registry('attention')
 TRANSFORMER_LAYER = Registry('transformerLayer')
 TRANSFORMER_LAYER_SEQUENCE = Registry('transformer-layers sequence')
 POSITIONAL_ENCODING = Registry('position encoding')
+NECKS = Registry('neck')          # reference: @NECKS.register_module() class CPFPN (models/necks/cp_fpn.py:17-18)
 
 _MM = {}
 try:  # pragma: no cover - mm* stack is absent in this image
     from mmcv.cnn.bricks.registry import (ATTENTION as _A, POSITIONAL_ENCODING as _P, TRANSFORMER_LAYER as _TL,
                                           TRANSFORMER_LAYER_SEQUENCE as _TLS)
-    from mmdet.models import HEADS as _H
+    from mmdet.models import HEADS as _H, NECKS as _N
     from mmdet.models.utils.builder import TRANSFORMER as _T
     _MM = {'HEADS': _H, 'TRANSFORMER': _T, 'ATTENTION': _A, 'TRANSFORMER_LAYER': _TL,
-           'TRANSFORMER_LAYER_SEQUENCE': _TLS, 'POSITIONAL_ENCODING': _P}
+           'TRANSFORMER_LAYER_SEQUENCE': _TLS, 'POSITIONAL_ENCODING': _P, 'NECKS': _N}
 except Exception:  # noqa: BLE001
     _MM = {}
 
@@ -84,3 +85,7 @@ def build_positional_encoding(cfg):
 
 def build_head(cfg):
     return HEADS.build(cfg)
+
+
+def build_neck(cfg):
+    return NECKS.build(cfg)

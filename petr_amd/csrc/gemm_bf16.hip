@@ -19,6 +19,8 @@
 //   K segments (k_seg), K slices over workgroups (split_k: slabs or float atomics), two batch dims, epilogue: bias,
 //   residual, ReLU, ReLU-mask, accumulate, bf16 store; a_colsum (bias gradient) from the fp32 staging registers of a
 //   K-major A, i.e. the exact fp32 column sums, not sums of rounded values.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -41,7 +43,7 @@ struct Stage16 {
   int off[4];             // KC: element offset of float4 i from the tile origin (row clamped); KM: off[0] = clamped row
   unsigned rowok;         // KC: bit i = row i valid; KM: bit 0
   __device__ __forceinline__ void init(long ld, int row0, int rows) {
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 255;        // the staging role is played by 256 threads (all of them, or waves 4..7)
     rowok = 0;
     if (KC) {
 #pragma unroll
@@ -59,7 +61,7 @@ struct Stage16 {
   }
   // base = operand + batch + segment; k0 = first k of the tile inside the segment, kend = segment length
   __device__ __forceinline__ void load(const float* base, long ld, int k0, int kend) {
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 255;
     if (KC) {
       const int kc = min(k0 + 4 * (t & 7), kend - 4) - 4 * (t & 7);    // clamp keeps the float4 inside the row
 #pragma unroll
@@ -81,7 +83,7 @@ struct Stage16 {
   }
   // round to bf16 and write the [row][k] image; `ragged`: the tile crosses the operand's row or K bound (uniform)
   __device__ __forceinline__ void store(uint16_t* img, bool ragged, int k0, int kend) {
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 255;
     if (KC) {
       if (ragged) {
         const bool kok = k0 + 4 * (t & 7) < kend;       // K % 4 == 0: a float4 is entirely inside or outside
@@ -247,6 +249,173 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_gen_kernel(const petr_gemm_a
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Producer / consumer version of the kernel above (same tiles, same LDS images, same epilogue): 8 waves per workgroup,
+// waves 0..3 multiply (64 x 64 outputs each), waves 4..7 only move operands: global memory -> registers -> bf16 LDS image,
+// with THREE tiles in flight in their registers.  Why: the one-tile register prefetch above leaves every K step waiting
+// for one exposed memory latency (~2.4 us per step per workgroup measured on the K/V projections, 0.21 us of MFMA work),
+// and a deeper ring in the multiplying waves does not fit beside 64 accumulator registers; loader waves hold no
+// accumulators, so three stages (96 registers) fit, and the multiplying waves never wait for global memory at all.
+// The ring is unrolled by hand (three named stages) and its loads are unconditional from clamped tile indices so that
+// hipcc keeps counted vmcnt waits.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(512) void gemm_bf16_pc_kernel(const petr_gemm_args g, const int tiles_m, const int tiles_n) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2][(GB_BM + GB_BN) * GB_PITCH];
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm_i = tile / tiles_n, tn_i = tile - tm_i * tiles_n;
+  const int m0 = tm_i * GB_BM, n0 = tn_i * GB_BN;
+  int z = blockIdx.z;
+  const int ks = z % g.split_k;
+  z /= g.split_k;
+  const int z1 = z % g.nb1, z0 = z / g.nb1;
+  const int kseg = g.k_seg > 0 ? g.k_seg : g.K;
+  const int nseg = g.k_seg > 0 ? g.K / g.k_seg : 1;
+  const int tps = (kseg + GB_BK - 1) / GB_BK;
+  const int ktiles = nseg * tps;
+  const int kt_per = (ktiles + g.split_k - 1) / g.split_k;
+  const int kt_begin = ks * kt_per;
+  const int kt_end = min(ktiles, kt_begin + kt_per);
+  const int nk = kt_end - kt_begin;
+  const bool loader = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4;      // wave-uniform, provably
+
+  if (loader) {
+    // ---------------- operand movers: thread u = threadIdx.x - 256 plays the staging role of the kernel above ----------------
+    const float* Ab = g.a + z0 * g.a_bs0 + z1 * g.a_bs1;
+    const float* Bb = g.b + z0 * g.b_bs0 + z1 * g.b_bs1;
+    Stage16<AKC> sa[3];
+    Stage16<BKC> sb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      sa[i].init(g.lda, m0, g.M);
+      sb[i].init(g.ldb, n0, g.N);
+    }
+    const bool rows_ragged_a = m0 + GB_BM > g.M, rows_ragged_b = n0 + GB_BN > g.N;
+    const bool do_colsum = g.a_colsum != nullptr && tn_i == 0;
+    float colacc = 0.f;
+    const int u = threadIdx.x - 256;
+    auto gload = [&](int i_tile, Stage16<AKC>& ra, Stage16<BKC>& rb) {       // i_tile: index inside this K slice, clamped
+      const int kt = kt_begin + min(i_tile, max(nk - 1, 0));
+      const int seg = kt / tps;
+      const int k0 = (kt - seg * tps) * GB_BK;
+      ra.load(Ab + (long)seg * g.a_seg_stride, g.lda, k0, kseg);
+      rb.load(Bb + (long)seg * g.b_seg_stride, g.ldb, k0, kseg);
+    };
+    auto lstore = [&](int i_tile, Stage16<AKC>& ra, Stage16<BKC>& rb) {
+      const int kt = kt_begin + i_tile;
+      const int seg = kt / tps;
+      const int k0 = (kt - seg * tps) * GB_BK;
+      const bool kr = k0 + GB_BK > kseg;
+      if (!AKC && do_colsum) {
+        const int kb = k0 + 16 * (u >> 7);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += (kb + e < kseg) ? ra.v[e] : 0.f;
+        colacc += s;
+      }
+      uint16_t* img = lds[i_tile & 1];
+      ra.store(img, rows_ragged_a || kr, k0, kseg);
+      rb.store(img + GB_BM * GB_PITCH, rows_ragged_b || kr, k0, kseg);
+    };
+    if (nk > 0) {
+      gload(0, sa[0], sb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      gload(1, sa[1], sb[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      gload(2, sa[2], sb[2]);
+      __builtin_amdgcn_sched_barrier(0);
+      lstore(0, sa[0], sb[0]);
+      gload(3, sa[0], sb[0]);
+    }
+    // iteration `it`: the multiplying waves read image it & 1; tile it+1 goes from its stage into the other image and the
+    // stage is re-issued for tile it+4.  Stage of tile j = j % 3.
+    auto step = [&](int it, Stage16<AKC>& ra, Stage16<BKC>& rb) -> bool {
+      __syncthreads();
+      if (it + 1 < nk) lstore(it + 1, ra, rb);
+      gload(it + 4, ra, rb);
+      return it + 1 >= nk;
+    };
+    if (nk > 0) {
+      for (int it = 0;; it += 3) {
+        if (step(it, sa[1], sb[1])) break;
+        if (step(it + 1, sa[2], sb[2])) break;
+        if (step(it + 2, sa[0], sb[0])) break;
+      }
+    }
+    if (!AKC && do_colsum && m0 + (u & 127) < g.M)
+      atomicAdd(g.a_colsum + z0 * g.cs_bs0 + z1 * g.cs_bs1 + m0 + (u & 127), colacc);
+    return;
+  }
+
+  // ---------------- multiplying waves ----------------
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int h = lane >> 5, c = lane & 31;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int it = 0; it < nk; ++it) {
+    __syncthreads();                       // image it & 1 complete (written one iteration ago by the movers)
+    const uint16_t* As = lds[it & 1];
+    const uint16_t* Bs = As + GB_BM * GB_PITCH;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      uint4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const uint4*>(As + (wm + 32 * i + c) * GB_PITCH + 16 * j + 8 * h);
+        fb[i] = *reinterpret_cast<const uint4*>(Bs + (wn + 32 * i + c) * GB_PITCH + 16 * j + 8 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, fa[i]),
+                                                               __builtin_bit_cast(hbf16x8, fb[jn]), acc[i][jn], 0, 0, 0);
+    }
+  }
+  const bool atomic = (g.flags & PETR_GEMM_ATOMIC) != 0;
+  const bool plain = g.split_k > 1 && !atomic;
+  float* C = g.c + z0 * g.c_bs0 + z1 * g.c_bs1 + (atomic ? 0 : (long)ks * g.c_split_stride);
+  const float* bias = (!plain && g.bias) ? g.bias + z0 * g.bias_bs0 + z1 * g.bias_bs1 : nullptr;
+  const float* R = (!plain && g.r) ? g.r + z0 * g.r_bs0 + z1 * g.r_bs1 : nullptr;
+  const int flags = plain ? 0 : g.flags;
+#pragma unroll
+  for (int jn = 0; jn < 2; ++jn) {
+    const int n = n0 + wn + 32 * jn + c;
+    const int nc = min(n, g.N - 1);
+    const float bv = bias ? bias[nc] : 0.f;
+    const long ccol = g.c_nblk > 0 ? (long)(nc / g.c_nblk) * g.c_nblk_stride + (nc % g.c_nblk) : (long)nc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + 32 * i + mfma32_row(r, h);
+        const int mc = min(m, g.M - 1);
+        const bool ok = m < g.M && n < g.N;
+        float v = acc[i][jn][r] * g.alpha + bv;
+        float* dst = C + (long)mc * g.ldc + ccol;
+        const float rv = R ? R[(long)mc * g.ldr + nc] : 0.f;
+        const float old = (flags & PETR_GEMM_ACCUMULATE) ? *dst : 0.f;
+        if (flags & PETR_GEMM_RELU_MASK) v = rv > 0.f ? v : 0.f;
+        else v += rv;
+        if (flags & PETR_GEMM_RELU) v = fmaxf(v, 0.f);
+        v += old;
+        if (ok) {
+          if (flags & PETR_GEMM_STORE_BF16)
+            reinterpret_cast<uint16_t*>(g.c)[z0 * g.c_bs0 + z1 * g.c_bs1 + (long)mc * g.ldc + ccol] =
+                __builtin_bit_cast(uint16_t, (__bf16)v);
+          else if (atomic) atomicAdd(dst, v);
+          else *dst = v;
+        }
+      }
+  }
+}
+
 }  // namespace
 
 // called by petr_gemm() for PETR_GEMM_BF16 requests that gemm.hip's plain-epilogue kernels do not take
@@ -266,6 +435,20 @@ int petr_gemm_bf16_general(const petr_gemm_args& g, hipStream_t s) {
                  (long)(g.b_kcontig ? g.N : kseg) * g.ldb + (g.b_kcontig ? kseg : g.N) < (1L << 31),
              PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_BF16 operand batch/segment must span < 2^31 elements");
   const int tm = (int)cdiv(g.M, GB_BM), tn = (int)cdiv(g.N, GB_BN);
+  // opt-in (PETR_GEMM16_PC=1).  Measured and rejected as the default (scripts/gemm16_time.py, same box, L = 24 000):
+  // d_src dgrad 70 us (general) vs 93 us (producer/consumer), dW_kv 89 vs 130, pe2 dgrad 141 vs 243, pe2 wgrad 72 vs 101.
+  // These contractions move fp32 operands and already run at 4.5-6.5 TB/s of HBM traffic with two 4-wave workgroups per
+  // CU; one 8-wave workgroup per CU with four multiplying waves loses more than the deeper ring gains.
+  static const bool use_pc = getenv("PETR_GEMM16_PC") && atoi(getenv("PETR_GEMM16_PC")) != 0;
+  if (use_pc) {
+    dim3 grid2(tm * tn, 1, g.nb0 * g.nb1 * g.split_k), block2(512);
+    if (g.a_kcontig && g.b_kcontig) hipLaunchKernelGGL((gemm_bf16_pc_kernel<true, true>), grid2, block2, 0, s, g, tm, tn);
+    else if (g.a_kcontig) hipLaunchKernelGGL((gemm_bf16_pc_kernel<true, false>), grid2, block2, 0, s, g, tm, tn);
+    else if (g.b_kcontig) hipLaunchKernelGGL((gemm_bf16_pc_kernel<false, true>), grid2, block2, 0, s, g, tm, tn);
+    else hipLaunchKernelGGL((gemm_bf16_pc_kernel<false, false>), grid2, block2, 0, s, g, tm, tn);
+    PETR_LAUNCH_CHECK("gemm_bf16_pc");
+    return PETR_OK;
+  }
   dim3 grid(tm * tn, 1, g.nb0 * g.nb1 * g.split_k), block(256);
   if (g.a_kcontig && g.b_kcontig) hipLaunchKernelGGL((gemm_bf16_gen_kernel<true, true>), grid, block, 0, s, g, tm, tn);
   else if (g.a_kcontig) hipLaunchKernelGGL((gemm_bf16_gen_kernel<true, false>), grid, block, 0, s, g, tm, tn);

@@ -8,10 +8,10 @@
 // forward does, so the recomputed probabilities are the forward's.
 //
 // Structure (cdna guide, Appendix B "Attention backward"):
-//   workgroup = 8 waves = 256*KT keys of one (batch, head) x a slice of the query tiles; a wave owns KT tiles of 32
-//   keys: their K / V rows (three register fragments: K and V as B operands of the score products, K^T as B operand of
-//   the dQ product) and their dK^T / dV^T accumulators stay in registers for the whole sweep, so dK / dV need no
-//   cross-wave sum.  Per 32-query tile, KEY ON THE LANE:
+//   workgroup = NW waves = 256 keys of one (batch, head) x a slice of the query tiles; a wave owns KT = 256/(32 NW) tiles of
+//   32 keys: their dK^T / dV^T accumulators and their V fragments stay in registers for the whole sweep (so dK / dV need
+//   no cross-wave sum), the workgroup's K rows sit in one LDS image that serves both K fragments (row reads for S',
+//   transposed reads for dQ).  Per 32-query tile, KEY ON THE LANE:
 //     S'  = Q2 K^T  (accumulator initialised to -LSE*log2e + key bias)   -> p  = exp2(S')
 //     dP' = dO V^T  (accumulator initialised to -delta)                  -> ds = p * dP'
 //     dV^T += dO^T p , dK^T += Q2^T ds : the p / ds accumulators, rounded to bf16, ARE the B operands (k order of the
@@ -22,7 +22,7 @@
 //                   with 128-byte-segment float atomics.
 //   ONE barrier per query tile: the partial tiles of tile t are summed right after the barrier that opens tile t+1
 //   (double-buffered), the images of tile t+1 are written behind it from registers loaded one tile earlier.
-//   256*KT keys per workgroup (fp32 kernel: 128) cut the dQ atomic traffic (0.92 MB per adder and layer) 2-4x.
+//   256 keys per workgroup (fp32 kernel: 128) halve the dQ atomic traffic (0.92 MB per adder and layer).
 // Outputs are ACCUMULATED (+=): the caller zero-fills them.  dQ (and dK / dV when the query range is split over
 // workgroups) use float atomics, so their low-order bits depend on arrival order.
 #include <stdlib.h>
@@ -31,6 +31,9 @@
 
 namespace {
 
+#ifndef PETR_BWD16_DIAG
+#define PETR_BWD16_DIAG 0      // timing-only ablations (results wrong): 1 no atomics, 2 no flush, 4 no dQ path, 8 no exp,
+#endif                         // 16 no dV/dK products, 32 no staging, 64 no S/dP products
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -41,13 +44,19 @@ constexpr int QP = 40;        // bf16 elements per row of a [32 q][32 d] tile im
 constexpr int DSP = 40;       // bf16 elements per row of a wave's [32 keys][32 q] dS image
 constexpr int RP = 33;        // fp32 pitch of a [32][32] partial tile
 constexpr int RED_SLAB = 32 * RP;
-constexpr int OFF_IMG = 0;                                   // [2 buffers][Q2, dO][32 * QP] bf16
-constexpr int OFF_ROWS = OFF_IMG + 2 * 2 * 32 * QP * 2;      // [2 buffers][-lse2, -delta, row key][32] 4-byte words
-constexpr int OFF_DS = OFF_ROWS + 2 * 3 * 32 * 4;            // [8 waves][32 * DSP] bf16
-constexpr int OFF_RED = OFF_DS + 8 * 32 * DSP * 2;           // [2 buffers][8 waves][RED_SLAB] fp32
-constexpr int SMEM_BYTES = OFF_RED + 2 * 8 * RED_SLAB * 4;
-static_assert(OFF_ROWS % 16 == 0 && OFF_DS % 16 == 0 && OFF_RED % 16 == 0, "LDS regions must stay 16-byte aligned");
-static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
+// LDS layout for NW waves per workgroup (byte offsets):
+//   [2 buffers][Q2, dO][32 * QP] bf16 | [2 buffers][-lse2, -delta, row key][32] words | [NW waves][32 * DSP] bf16 (ds images)
+//   | [2 buffers][NW waves][RED_SLAB] fp32 (dQ partial tiles; dK / dV transposition scratch at the end)
+//   | [NW * KT * 32 keys][QP] bf16 (the workgroup's K rows)
+constexpr int OFF_IMG = 0;
+constexpr int OFF_ROWS = OFF_IMG + 2 * 2 * 32 * QP * 2;
+constexpr int OFF_DS = OFF_ROWS + 2 * 3 * 32 * 4;
+constexpr int off_red(int nw) { return OFF_DS + nw * 32 * DSP * 2; }
+constexpr int off_kimg(int nw) { return off_red(nw) + 2 * nw * RED_SLAB * 4; }
+constexpr int smem_bytes(int nw, int kt) { return off_kimg(nw) + nw * kt * 32 * QP * 2; }
+static_assert(OFF_ROWS % 16 == 0 && OFF_DS % 16 == 0 && off_red(8) % 16 == 0 && off_red(4) % 16 == 0 && off_kimg(8) % 16 == 0 &&
+                  off_kimg(4) % 16 == 0, "LDS regions must stay 16-byte aligned");
+static_assert(smem_bytes(8, 2) <= 160 * 1024 && 2 * smem_bytes(4, 2) <= 160 * 1024, "LDS budget");
 
 struct MhaBwd16Params {
   petr_mha_bwd_bf16_args a;
@@ -71,13 +80,22 @@ __device__ __forceinline__ uint2 pack4f(float a, float b, float c, float d) {
 // DROP: the forward multiplied the probabilities by keep/(1-p) after the softmax, so with m = keep/(1-p)
 //   dV += dO^T (p*m) ,  dP = m * (dO V^T) ,  ds = p * (dP - delta)   (delta = rowsum(dO*O) of the DROPPED output)
 // and the masks are regenerated from (seed, site, row, key), row = (b*H+h)*Q + q.
-template <int KT, bool HAS_MASK, bool DROP>
-__global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+// NW waves per workgroup, KT key tiles per wave: (8, 1) = eight waves in lock step on one CU, (4, 2) = four waves with
+// twice the keys each, two workgroups per CU (75 KB of LDS, <= 256 registers).  The loop is bound by the LDS pipe, not
+// by MFMA (ablations: removing any single stage changes the time by < 8 %; ~70 LDS instructions per wave and tile):
+// with (4, 2) the Q2 / dO fragments are fetched once per 64 keys instead of once per 32 and four partial dQ tiles are
+// summed instead of eight, i.e. a third less LDS traffic for the same products, and the two co-resident workgroups are
+// not tied to each other's barrier.
+template <int NW, int KT, bool HAS_MASK, bool DROP>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mha_bwd_bf16_kernel(const MhaBwd16Params p) {
+  constexpr int NT = NW * 64;            // threads
+  constexpr int NS = NW * 32;            // stager threads (waves 0 .. NW/2-1) = flusher threads (the other half)
+  constexpr int NP = 256 / NS;           // (row, 4 columns) pieces of a 32 x 32 tile per stager thread
+  __shared__ __attribute__((aligned(16))) unsigned char smem[smem_bytes(NW, KT)];
   uint16_t* img = reinterpret_cast<uint16_t*>(smem + OFF_IMG);
   float* rows_s = reinterpret_cast<float*>(smem + OFF_ROWS);
   uint16_t* ds_all = reinterpret_cast<uint16_t*>(smem + OFF_DS);
-  float* red = reinterpret_cast<float*>(smem + OFF_RED);
+  float* red = reinterpret_cast<float*>(smem + off_red(NW));
 
   const petr_mha_bwd_bf16_args& a = p.a;
   const int total = p.nkb * a.B * a.H * p.q_splits;
@@ -90,7 +108,7 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int h = lane >> 5, c = lane & 31;
-  const int key_base = kb * (256 * KT) + wave * (32 * KT);
+  const int key_base = kb * (NW * 32 * KT) + wave * (32 * KT);
 
   const float* qp = a.q + (long)b * a.q_bs + (long)hd * a.q_hs;
   const float* gp = a.d_o + (long)b * a.do_bs + (long)hd * a.do_hs;
@@ -98,10 +116,31 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
   const uint16_t* kp = a.k + (long)b * a.k_bs + (long)hd * a.k_hs;
   const uint16_t* vp = a.v + (long)b * a.v_bs + (long)hd * a.v_hs;
 
-  // ---- this wave's keys: three register fragments per 32-key tile ----
-  //   kB / vB [i][s]: B operand of S' / dP' (lane (c,h): row key c, d = 16 s + 8 h .. + 7, one 16-byte load)
-  //   kT [i][s]     : B operand of dQ     (lane (c,h): column d = c, keys 16 s + 8 h .. + 7 of the tile)
-  bf16x8 kB[KT][2], vB[KT][2], kT[KT][2];
+  // ---- this workgroup's keys ----
+  //   K: one LDS image [256*KT keys][32 d] (80-byte pitch), filled once; per query tile a wave reads from it
+  //        kB[s]: B operand of S'  (lane (c,h): row key c, d = 16 s + 8 h .. + 7: one 16-byte read)
+  //        kT[s]: B operand of dQ  (lane (c,h): column d = c, keys 16 s + 8 h .. + 7: two transposed 8-byte reads)
+  //      (in registers these two fragments cost 16 per key tile; with them there KT = 2 spilled 25-42 registers)
+  //   V: vB[i][s], B operand of dP', in registers (8 per key tile)
+  uint16_t* kimg = reinterpret_cast<uint16_t*>(smem + off_kimg(NW));
+  {
+    const int wg_key0 = kb * (NW * 32 * KT);
+#pragma unroll
+    for (int j = 0; j < 2 * KT; ++j) {
+      const int idx = t + NT * j;                   // 16-byte piece: key idx >> 2, d = 8 * (idx & 3)
+      const int kl = idx >> 2, pc = idx & 3;
+      const int kg = wg_key0 + kl;
+      uint4 x = *reinterpret_cast<const uint4*>(kp + (long)min(kg, a.L - 1) * a.k_rs + 8 * pc);
+      if (kg >= a.L) x = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(kimg + kl * QP + 8 * pc) = x;
+    }
+  }
+  const uint16_t* kw = kimg + wave * (32 * KT) * QP;      // this wave's 32*KT key rows
+  // KT == 1 (the default 8-wave shape): the two K fragments stay in registers, filled once from the image (180 vs 192 us
+  // at L = 24 000 against re-reading them per query tile); KT == 2 reads them from the image (register budget)
+  constexpr bool KREG = KT == 1;
+  bf16x8 kBr[2], kTr[2];
+  bf16x8 vB[KT][2];
   float kbias[KT];
   bool tile_dead[KT];
 #pragma unroll
@@ -109,24 +148,12 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
     const int key = key_base + 32 * i + c;
     const bool ok = key < a.L;
     const int key_ld = min(key, a.L - 1);
-    const uint16_t* kr = kp + (long)key_ld * a.k_rs + 8 * h;
     const uint16_t* vr = vp + (long)key_ld * a.v_rs + 8 * h;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      uint4 kx = *reinterpret_cast<const uint4*>(kr + 16 * s);
       uint4 vx = *reinterpret_cast<const uint4*>(vr + 16 * s);
-      if (!ok) kx = vx = make_uint4(0, 0, 0, 0);
-      kB[i][s] = __builtin_bit_cast(bf16x8, kx);
+      if (!ok) vx = make_uint4(0, 0, 0, 0);
       vB[i][s] = __builtin_bit_cast(bf16x8, vx);
-      typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-      u16x8 tt;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int kk = key_base + 32 * i + 16 * s + 8 * h + j;
-        const uint16_t x = kp[(long)min(kk, a.L - 1) * a.k_rs + c];
-        tt[j] = kk < a.L ? x : (uint16_t)0;
-      }
-      kT[i][s] = __builtin_bit_cast(bf16x8, tt);
     }
     float kbv = ok ? 0.f : -INFINITY;
     if (HAS_MASK && ok && a.kpm[(long)b * a.L + key]) kbv = -INFINITY;
@@ -134,6 +161,15 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
     tile_dead[i] = __builtin_amdgcn_ballot_w64(kbv != 0.f) != 0;     // wave-uniform
   }
 
+  if (KREG) {
+    __syncthreads();                 // the image is complete
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      kBr[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kw + c * QP + 16 * s + 8 * h));
+      kTr[s] = cat8(tr16(kw + (16 * s + 8 * h + ((lane & 15) >> 2)) * QP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)),
+                    tr16(kw + (16 * s + 8 * h + 4 + ((lane & 15) >> 2)) * QP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)));
+    }
+  }
   f32x16 dKt[KT], dVt[KT];
 #pragma unroll
   for (int i = 0; i < KT; ++i)
@@ -149,52 +185,65 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
   //      issue the float atomics.  A wave that did both would wait for its loads with s_waitcnt vmcnt(0) (hipcc cannot
   //      count a wait across the loop's back edge) and so drain the atomics it has just issued - ~3 000 cycles under
   //      load, once per query tile (first version: 228 us at L = 24 000; the ISA showed vmcnt(0) right behind the atomics).
-  const bool stager = __builtin_amdgcn_readfirstlane(t >> 6) < 4;          // wave-uniform, provably
-  const int srow = (t & 255) >> 3, sc4 = t & 7;
-  float4 rq = make_float4(0.f, 0.f, 0.f, 0.f), rg = rq, ro = rq;
+  const bool stager = __builtin_amdgcn_readfirstlane(t >> 6) < NW / 2;     // wave-uniform, provably
+  float4 rq[NP], rg[NP], ro[NP];
   float lreg = 0.f;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) rq[j] = rg[j] = ro[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto gload = [&](int qt) {
-    const int row = min(qt * 32 + srow, a.Q - 1);        // rows beyond Q re-read row Q-1 (zeroed at the LDS store)
-    rq = *reinterpret_cast<const float4*>(qp + (long)row * a.q_rs + 4 * sc4);
-    rg = *reinterpret_cast<const float4*>(gp + (long)row * a.do_rs + 4 * sc4);
-    ro = *reinterpret_cast<const float4*>(op + (long)row * a.o_rs + 4 * sc4);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int pc = (t & (NS - 1)) + NS * j;              // piece: row pc >> 3, columns 4 (pc & 7) ..
+      const int row = min(qt * 32 + (pc >> 3), a.Q - 1);   // rows beyond Q re-read row Q-1 (zeroed at the LDS store)
+      const int c4 = pc & 7;
+      rq[j] = *reinterpret_cast<const float4*>(qp + (long)row * a.q_rs + 4 * c4);
+      rg[j] = *reinterpret_cast<const float4*>(gp + (long)row * a.do_rs + 4 * c4);
+      ro[j] = *reinterpret_cast<const float4*>(op + (long)row * a.o_rs + 4 * c4);
+    }
     lreg = a.lse[(long)bh * a.Q + min(qt * 32 + (t & 31), a.Q - 1)];
   };
   auto stage = [&](int qt, int buf) {
-    const bool ok = qt * 32 + srow < a.Q;
     float* rw = rows_s + buf * 96;
-    const uint2 vq = pack4f(ok ? rq.x * sc2 : 0.f, ok ? rq.y * sc2 : 0.f, ok ? rq.z * sc2 : 0.f, ok ? rq.w * sc2 : 0.f);
-    *reinterpret_cast<uint2*>(img + (buf * 2 + 0) * 32 * QP + srow * QP + 4 * sc4) = vq;
-    const uint2 vg = pack4f(ok ? rg.x : 0.f, ok ? rg.y : 0.f, ok ? rg.z : 0.f, ok ? rg.w : 0.f);
-    *reinterpret_cast<uint2*>(img + (buf * 2 + 1) * 32 * QP + srow * QP + 4 * sc4) = vg;
-    // delta from the ROUNDED dO, the one the dP' product multiplies: sum_k ds[q][k] = sum_k p (dP' - delta) must vanish
-    // (softmax shift invariance), and with near-uniform attention over thousands of keys dQ = sum_k ds K is the small
-    // residual of that cancellation - a delta formed from the unrounded dO would leave a coherent 2^-9 |dO||O| offset on
-    // every ds of the row
-    const bf16x4 rb = __builtin_bit_cast(bf16x4, vg);
-    float dl = ((float)rb[0] * ro.x + (float)rb[1] * ro.y) + ((float)rb[2] * ro.z + (float)rb[3] * ro.w);   // 8 lanes share a row
-    dl += __shfl_xor(dl, 1, 64);
-    dl += __shfl_xor(dl, 2, 64);
-    dl += __shfl_xor(dl, 4, 64);
-    if (sc4 == 0) rw[32 + srow] = ok ? -dl : 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int pc = (t & (NS - 1)) + NS * j;
+      const int srow = pc >> 3, sc4 = pc & 7;
+      const bool ok = qt * 32 + srow < a.Q;
+      const uint2 vq = pack4f(ok ? rq[j].x * sc2 : 0.f, ok ? rq[j].y * sc2 : 0.f, ok ? rq[j].z * sc2 : 0.f, ok ? rq[j].w * sc2 : 0.f);
+      *reinterpret_cast<uint2*>(img + (buf * 2 + 0) * 32 * QP + srow * QP + 4 * sc4) = vq;
+      const uint2 vg = pack4f(ok ? rg[j].x : 0.f, ok ? rg[j].y : 0.f, ok ? rg[j].z : 0.f, ok ? rg[j].w : 0.f);
+      *reinterpret_cast<uint2*>(img + (buf * 2 + 1) * 32 * QP + srow * QP + 4 * sc4) = vg;
+      // delta from the ROUNDED dO, the one the dP' product multiplies: sum_k ds[q][k] = sum_k p (dP' - delta) must vanish
+      // (softmax shift invariance), and with near-uniform attention over thousands of keys dQ = sum_k ds K is the small
+      // residual of that cancellation - a delta formed from the unrounded dO would leave a coherent 2^-9 |dO||O| offset
+      // on every ds of the row
+      const bf16x4 rb = __builtin_bit_cast(bf16x4, vg);
+      float dl = ((float)rb[0] * ro[j].x + (float)rb[1] * ro[j].y) + ((float)rb[2] * ro[j].z + (float)rb[3] * ro[j].w);
+      dl += __shfl_xor(dl, 1, 64);       // 8 lanes share a row
+      dl += __shfl_xor(dl, 2, 64);
+      dl += __shfl_xor(dl, 4, 64);
+      if (sc4 == 0) rw[32 + srow] = ok ? -dl : 0.f;
+    }
     if (t < 32) {
       const bool rok = qt * 32 + t < a.Q;
       rw[t] = rok ? -lreg * LOG2E : -INFINITY;         // rows beyond Q: p = exp2(-inf) = 0
       if (DROP) reinterpret_cast<uint32_t*>(rw)[64 + t] = drop_row_key(p.drop, (uint32_t)(bh * a.Q + min(qt * 32 + t, a.Q - 1)));
     }
   };
-  // sum the eight waves' dQ partial tiles of query tile qt and add them to global dQ (two 128-byte rows per instruction);
-  // called by waves 4..7: thread u = t - 256 owns elements u + 256 j
+  // sum the NW waves' dQ partial tiles of query tile qt and add them to global dQ (two 128-byte rows per instruction);
+  // called by the flusher waves: thread u = t - NS owns elements u + NS j
   auto flush = [&](const float* rb, int qt) {
     float* dq = a.dq + (long)b * a.dq_bs + (long)hd * a.dq_hs + (long)qt * 32 * a.dq_rs;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = (t - 256) + 256 * j;
+    for (int j = 0; j < 1024 / NS; ++j) {
+      const int idx = (t - NS) + NS * j;
       const int q = idx >> 5, d = idx & 31;
       const float* s = rb + q * RP + d;
-      const float v = ((s[0] + s[RED_SLAB]) + (s[2 * RED_SLAB] + s[3 * RED_SLAB])) +
-                      ((s[4 * RED_SLAB] + s[5 * RED_SLAB]) + (s[6 * RED_SLAB] + s[7 * RED_SLAB]));
-      if (qt * 32 + q < a.Q) atomicAdd(dq + (long)q * a.dq_rs + d, v * a.scale);
+      float v = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; w2 += 2) v += s[w2 * RED_SLAB] + s[(w2 + 1) * RED_SLAB];
+      if (PETR_BWD16_DIAG & 1) { if (v == 123.456f) dq[q] = v; }
+      else if (qt * 32 + q < a.Q) atomicAdd(dq + (long)q * a.dq_rs + d, v * a.scale);
     }
   };
 
@@ -213,12 +262,12 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
     const int buf = (qt - qt_begin) & 1;
     __syncthreads();     // images / row constants of tile qt complete; every dQ partial of tile qt-1 written
     if (stager) {
-      if (qt + 1 < qt_end) {
+      if (qt + 1 < qt_end && !(PETR_BWD16_DIAG & 32)) {
         stage(qt + 1, buf ^ 1);
         if (qt + 2 < qt_end) gload(qt + 2);
       }
-    } else if (qt > qt_begin) {
-      flush(red + (buf ^ 1) * 8 * RED_SLAB, qt - 1);
+    } else if (qt > qt_begin && !(PETR_BWD16_DIAG & 2)) {
+      flush(red + (buf ^ 1) * NW * RED_SLAB, qt - 1);
     }
     const uint16_t* Qi = img + (buf * 2 + 0) * 32 * QP;
     const uint16_t* Gi = img + (buf * 2 + 1) * 32 * QP;
@@ -241,13 +290,15 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
 #pragma unroll
     for (int i = 0; i < KT; ++i) {
       if (key_base + 32 * i >= a.L) continue;          // wave-uniform: this key tile lies beyond L
-      f32x16 S, dP, nd;
+      f32x16 S, dP;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 x = *reinterpret_cast<const float4*>(rw + 8 * g + 4 * h);        // -lse2 of rows 8g + 4h .. + 3
-        const float4 y = *reinterpret_cast<const float4*>(rw + 32 + 8 * g + 4 * h);   // -delta
         S[4 * g] = x.x; S[4 * g + 1] = x.y; S[4 * g + 2] = x.z; S[4 * g + 3] = x.w;
-        nd[4 * g] = y.x; nd[4 * g + 1] = y.y; nd[4 * g + 2] = y.z; nd[4 * g + 3] = y.w;
+        if (!DROP) {                                                                  // -delta: the dP' accumulator's start
+          const float4 y = *reinterpret_cast<const float4*>(rw + 32 + 8 * g + 4 * h);
+          dP[4 * g] = y.x; dP[4 * g + 1] = y.y; dP[4 * g + 2] = y.z; dP[4 * g + 3] = y.w;
+        }
       }
       if (tile_dead[i]) {
 #pragma unroll
@@ -256,13 +307,20 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
       if (DROP) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dP[r] = 0.f;
-      } else {
-        dP = nd;
       }
-      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], kB[i][0], S, 0, 0, 0);
-      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], kB[i][1], S, 0, 0, 0);
+      {
+        const uint16_t* kr = kw + (32 * i + c) * QP + 8 * h;
+        const bf16x8 kb0 = KREG ? kBr[0] : __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kr));
+        const bf16x8 kb1 = KREG ? kBr[1] : __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kr + 16));
+        if (!(PETR_BWD16_DIAG & 64)) {
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], kb0, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], kb1, S, 0, 0, 0);
+        } else { S[0] += (float)kb0[0] + (float)qa[0][0] + (float)kb1[1] + (float)qa[1][1]; }
+      }
+      if (!(PETR_BWD16_DIAG & 64)) {
       dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], vB[i][0], dP, 0, 0, 0);
       dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], vB[i][1], dP, 0, 0, 0);
+      } else { dP[0] += (float)ga[0][0] + (float)vB[i][0][0] + (float)ga[1][1] + (float)vB[i][1][1]; }
       if (DROP) {
         const uint32_t key = (uint32_t)(key_base + 32 * i + c);
         const uint32_t* rk = reinterpret_cast<const uint32_t*>(rw) + 64;
@@ -270,19 +328,21 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
         for (int g = 0; g < 4; ++g) {
           const uint4 kx = *reinterpret_cast<const uint4*>(rk + 8 * g + 4 * h);
           const uint32_t kk[4] = {kx.x, kx.y, kx.z, kx.w};
+          const float4 y = *reinterpret_cast<const float4*>(rw + 32 + 8 * g + 4 * h);   // -delta, read where it is used
+          const float nd4[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
             const float pr = __builtin_amdgcn_exp2f(S[r]);
             const float m = drop_keep(kk[e], key, p.drop.thr) ? p.drop.scale : 0.f;
-            dP[r] = pr * (dP[r] * m + nd[r]);      // ds = p * (m * dO.V - delta)
+            dP[r] = pr * (dP[r] * m + nd4[e]);     // ds = p * (m * dO.V - delta)
             S[r] = pr * m;                         // dropped probability: B operand of dV
           }
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          S[r] = __builtin_amdgcn_exp2f(S[r]);     // p
+          S[r] = (PETR_BWD16_DIAG & 8) ? S[r] * 0.5f : __builtin_amdgcn_exp2f(S[r]);     // p
           dP[r] = S[r] * dP[r];                    // ds (without the softmax scale)
         }
       }
@@ -296,10 +356,12 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
         }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
+        if (PETR_BWD16_DIAG & 16) { dVt[i][s] += (float)gT[s][0] + (float)pb[s][0]; dKt[i][s] += (float)qT[s][0] + (float)sb[s][1]; continue; }
         dVt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gT[s], pb[s], dVt[i], 0, 0, 0);
         dKt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[s], sb[s], dKt[i], 0, 0, 0);
       }
       // ds -> this wave's [key][q] image: registers 4g .. 4g+3 are queries 8g + 4h .. + 3 of key c (one 8-byte store)
+      if (PETR_BWD16_DIAG & 4) { dQp[0] += (float)sb[0][0] + (float)sb[1][1]; continue; }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const uint4 bits = __builtin_bit_cast(uint4, sb[s]);
@@ -312,21 +374,24 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
       for (int s = 0; s < 2; ++s) {
         const bf16x8 da = cat8(tr16(dsw + (16 * s + 8 * h + tr_q) * DSP + tr_col),
                                tr16(dsw + (16 * s + 8 * h + 4 + tr_q) * DSP + tr_col));
-        dQp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, kT[i][s], dQp, 0, 0, 0);
+        const bf16x8 kt = KREG ? kTr[s]
+                               : cat8(tr16(kw + (32 * i + 16 * s + 8 * h + tr_q) * QP + tr_col),
+                                      tr16(kw + (32 * i + 16 * s + 8 * h + 4 + tr_q) * QP + tr_col));
+        dQp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, kt, dQp, 0, 0, 0);
       }
     }
-    float* rb = red + (buf * 8 + wave) * RED_SLAB;
+    float* rb = red + (buf * NW + wave) * RED_SLAB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) rb[mfma32_row(r, h) * RP + c] = dQp[r];
   }
   __syncthreads();
-  if (!stager && qt_begin < qt_end) flush(red + ((qt_end - 1 - qt_begin) & 1) * 8 * RED_SLAB, qt_end - 1);
+  if (!stager && qt_begin < qt_end) flush(red + ((qt_end - 1 - qt_begin) & 1) * NW * RED_SLAB, qt_end - 1);
   __syncthreads();     // every wave is done reading the partial tiles: the slabs become transposition scratch
 
   // ---- dK / dV: transpose each wave's 32 x 32 accumulators through LDS, then row-major adds ----
   {
     float* tk = red + wave * RED_SLAB;
-    float* tv = red + (8 + wave) * RED_SLAB;
+    float* tv = red + (NW + wave) * RED_SLAB;
     float* dk = a.dk + (long)b * a.dk_bs + (long)hd * a.dk_hs;
     float* dv = a.dv + (long)b * a.dv_bs + (long)hd * a.dv_hs;
     const bool use_atomic = p.q_splits > 1;
@@ -369,24 +434,24 @@ __global__ __launch_bounds__(512) void mha_bwd_bf16_kernel(const MhaBwd16Params 
   }
 }
 
-// KT (32-key tiles per wave) and the number of query-range splits: workgroups come in rounds of one per CU (99 KB of
-// LDS), a round costs per-tile work ~ KT + a fixed part (barrier, partial-tile sum), and every adder of dQ (one per key
-// block) / of dK, dV (one per query split beyond the first) pays float-atomic bytes at ~1.3 TB/s chip-wide
-void choose_cfg(int B, int H, int Q, int L, int kt_max, int& kt_out, int& qs_out) {
+// Number of query-range splits: every workgroup covers 256 keys; workgroups come in rounds of `per_cu` per CU, a round
+// costs a fixed part (~10 us: K image, first tile, dK / dV epilogue) plus ~1.4 us per query tile, and every adder of dQ
+// (one per key block) / of dK, dV (one per query split beyond the first) pays float-atomic bytes at ~1.3 TB/s chip-wide
+int choose_qsplits(int B, int H, int Q, int L, int per_cu) {
   const int qtiles = (int)cdiv(Q, 32);
   double best = 1e30;
-  kt_out = 1; qs_out = 1;
-  for (int kt = 1; kt <= kt_max; ++kt)
-    for (int s = 1; s <= qtiles && s <= 8; ++s) {
-      const int per = (int)cdiv(qtiles, s);
-      if ((long)(s - 1) * per >= qtiles) continue;
-      const long nkb = cdiv(L, 256 * kt);
-      const long wgs = nkb * B * H * s;
-      const double compute_us = (double)cdiv(wgs, 256) * per * (0.7 * kt + 0.4);
-      const double atomic_mb = (double)B * H * Q * 128e-6 * nkb + (s > 1 ? 2.0 * B * H * (double)L * 128e-6 * s : 0.0);
-      const double cost = compute_us + 0.5 * atomic_mb / 1.3;
-      if (cost < best - 1e-9) { best = cost; kt_out = kt; qs_out = s; }
-    }
+  int qs_out = 1;
+  for (int s = 1; s <= qtiles && s <= 8; ++s) {
+    const int per = (int)cdiv(qtiles, s);
+    if ((long)(s - 1) * per >= qtiles) continue;
+    const long nkb = cdiv(L, 256);
+    const long wgs = nkb * B * H * s;
+    const double compute_us = (double)cdiv(wgs, 256L * per_cu) * (10.0 + 1.4 * per * per_cu);
+    const double atomic_mb = (double)B * H * Q * 128e-6 * nkb + (s > 1 ? 2.0 * B * H * (double)L * 128e-6 * s : 0.0);
+    const double cost = compute_us + 0.5 * atomic_mb / 1.3;
+    if (cost < best - 1e-9) { best = cost; qs_out = s; }
+  }
+  return qs_out;
 }
 
 }  // namespace
@@ -412,20 +477,21 @@ extern "C" int petr_mha_bwd_bf16(const petr_mha_bwd_bf16_args* ap, void* stream)
   PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "mha_bwd_bf16: dropout p=%g outside [0,1)", (double)a.drop.p);
   PETR_CHECK((long)a.B * a.H * a.Q < (1L << 32), PETR_ERR_UNSUPPORTED, "mha_bwd_bf16: dropout row index needs B*H*Q < 2^32");
   p.drop = make_drop(a.drop);
-  // KT = 2 needs 260+ registers as written (hipcc spills 20-42 of them into the tile loop); until its K fragments
-  // move to an LDS image it is an opt-in (PETR_MHA_BWD16_KT=2) and the default is one key tile per wave
-  int kt = 1, qsp = 1, kt_max = 1;
-  if (const char* e = getenv("PETR_MHA_BWD16_KT")) kt_max = atoi(e) == 2 ? 2 : 1;
-  choose_cfg(a.B, a.H, a.Q, a.L, kt_max, kt, qsp);
-  if (const char* e = getenv("PETR_MHA_BWD16_KT")) {        // tuning overrides
+  // two shapes of the same kernel, 256 keys per workgroup either way: (NW, KT) = (8, 1) - eight waves with one key tile
+  // each, one workgroup per CU - is the default; (4, 2) - four waves with two key tiles each, two workgroups per CU,
+  // PETR_MHA_BWD16_SHAPE=42 - was built to cut the LDS traffic per product by a third, but hipcc spills 27-40 registers of
+  // it into the tile loop and it measures 1.5-2x SLOWER (L = 24 000: 356 vs 192 us), so it stays an opt-in
+  int shape = 81;
+  if (const char* e = getenv("PETR_MHA_BWD16_SHAPE")) {
     const int v = atoi(e);
-    if (v == 1 || v == 2) kt = v;
+    if (v == 81 || v == 42) shape = v;
   }
+  int qsp = choose_qsplits(a.B, a.H, a.Q, a.L, shape == 42 ? 2 : 1);
   if (const char* e = getenv("PETR_MHA_BWD16_QSPLITS")) {
     const int v = atoi(e);
     if (v >= 1 && v <= (int)cdiv(a.Q, 32)) qsp = v;
   }
-  p.nkb = (int)cdiv(a.L, 256 * kt);
+  p.nkb = (int)cdiv(a.L, 256);
   p.q_splits = qsp;
   p.qtiles_per_split = (int)cdiv(cdiv(a.Q, 32), qsp);
   if ((long)(qsp - 1) * p.qtiles_per_split >= cdiv(a.Q, 32)) {     // an override that would leave an empty split
@@ -436,17 +502,18 @@ extern "C" int petr_mha_bwd_bf16(const petr_mha_bwd_bf16_args* ap, void* stream)
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t ev0, ev1;   // null unless bench.py's profiler is on
   petr_prof_claim(PETR_PROF_MHA_BWD + 16 * (a.L > a.Q ? 1 : 0), &ev0, &ev1);
-  auto launch = [&](auto kern) { hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), 0, s, ev0, ev1, 0, p); };
-  const int variant = (kt == 2 ? 4 : 0) | (p.drop.thr ? 2 : 0) | (a.kpm ? 1 : 0);
+  const unsigned threads = shape == 42 ? 256u : 512u;
+  auto launch = [&](auto kern) { hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(threads), 0, s, ev0, ev1, 0, p); };
+  const int variant = (shape == 42 ? 4 : 0) | (p.drop.thr ? 2 : 0) | (a.kpm ? 1 : 0);
   switch (variant) {
-    case 0: launch(mha_bwd_bf16_kernel<1, false, false>); break;
-    case 1: launch(mha_bwd_bf16_kernel<1, true, false>); break;
-    case 2: launch(mha_bwd_bf16_kernel<1, false, true>); break;
-    case 3: launch(mha_bwd_bf16_kernel<1, true, true>); break;
-    case 4: launch(mha_bwd_bf16_kernel<2, false, false>); break;
-    case 5: launch(mha_bwd_bf16_kernel<2, true, false>); break;
-    case 6: launch(mha_bwd_bf16_kernel<2, false, true>); break;
-    default: launch(mha_bwd_bf16_kernel<2, true, true>); break;
+    case 0: launch(mha_bwd_bf16_kernel<8, 1, false, false>); break;
+    case 1: launch(mha_bwd_bf16_kernel<8, 1, true, false>); break;
+    case 2: launch(mha_bwd_bf16_kernel<8, 1, false, true>); break;
+    case 3: launch(mha_bwd_bf16_kernel<8, 1, true, true>); break;
+    case 4: launch(mha_bwd_bf16_kernel<4, 2, false, false>); break;
+    case 5: launch(mha_bwd_bf16_kernel<4, 2, true, false>); break;
+    case 6: launch(mha_bwd_bf16_kernel<4, 2, false, true>); break;
+    default: launch(mha_bwd_bf16_kernel<4, 2, true, true>); break;
   }
   PETR_LAUNCH_CHECK("mha_bwd_bf16");
   return PETR_OK;

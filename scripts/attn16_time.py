@@ -33,8 +33,8 @@ for drop in (None, (1, 2, 0.1)):
     o, lse = ops.mha_fwd_bf16(q, kb, vb, drop=drop)
     o = o.permute(0, 2, 1, 3).contiguous().view(1, Q, 8, 32).permute(0, 2, 1, 3)
     print(f'L={L} drop={drop is not None}: fwd16 {t(lambda: ops.mha_fwd_bf16(q, kb, vb, drop=drop)):.1f} us (incl. alloc)', end='')
-    for kt in ('1', '2'):
-        os.environ['PETR_MHA_BWD16_KT'] = kt
+    for kt in ('81', '42'):
+        os.environ['PETR_MHA_BWD16_SHAPE'] = kt
         for qs in ('1', '2'):
             os.environ['PETR_MHA_BWD16_QSPLITS'] = qs
             print(f'  bwd16[kt{kt},qs{qs}] {t(lambda: ops.mha_bwd_bf16(q, kb, vb, o, do, lse, drop=drop)):.1f}', end='')

@@ -622,8 +622,8 @@ BF16_BWD_TOL = 2e-2      # max-norm relative error of dq / dk / dv against fp64 
     (1, 8, 900, 4224, False, (3, 2, 0.1), 2), (1, 2, 200, 700, True, None, 2), (1, 8, 900, 12000, False, None, 1)])
 def test_mha_bwd_bf16(ops, B, H, Q, L, masked, drop, kt, monkeypatch):
     """petr_mha_bwd_bf16 (gradient of petr_mha_fwd_bf16) vs fp64 autograd through softmax attention on the same
-    bf16-rounded K / V (and the same exported dropout mask); kt = key tiles per wave (2 is the opt-in variant)."""
-    monkeypatch.setenv('PETR_MHA_BWD16_KT', str(kt))
+    bf16-rounded K / V (and the same exported dropout mask); kt = key tiles per wave: both shapes of the kernel."""
+    monkeypatch.setenv('PETR_MHA_BWD16_SHAPE', '42' if kt == 2 else '81')      # (4 waves x 2 key tiles) / (8 waves x 1)
     g = torch.Generator().manual_seed(Q * 3 + L + kt)
     q, k, v = (torch.randn(B, H, n, 32, generator=g) for n in (Q, L, L))
     do = torch.randn(B, H, Q, 32, generator=g)

@@ -420,7 +420,7 @@ def main():
             for fn in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
-                    ent = pmc[args.workload]['mha_fwd_cross']
+                    ent = (pmc.get(f'{args.workload}_{args.dtype}') or pmc[args.workload])['mha_fwd_cross']
                     if B == 1 and ent.get('dtype', 'fp32') == args.dtype:
                         traffic, traffic_source = ent['traffic_bytes'], f'profiles/{fn} (separate rocprofv3 --pmc passes)'
                         break

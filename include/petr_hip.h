@@ -304,6 +304,8 @@ typedef struct {
   float scale;
   void* ws; size_t ws_bytes;   /* unused (0 bytes needed); kept so that the block mirrors petr_mha_bwd_args */
   petr_dropout drop;           /* must equal the forward's */
+  int dkv_overwrite;           /* 1: dk and dv are STORED (no zero-fill by the caller, no read-modify-write; the query range is
+                                * then never split over workgroups); 0: accumulated like petr_mha_bwd.  dq is always += */
 } petr_mha_bwd_bf16_args;
 size_t petr_mha_bwd_bf16_workspace_bytes(int B, int H, int Q, int L);
 int petr_mha_bwd_bf16(const petr_mha_bwd_bf16_args* a, void* stream);

@@ -107,6 +107,10 @@ class MhaBwdArgs(C.Structure):
         ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('drop', Dropout))
 
 
+class MhaBwdBf16Args(C.Structure):    # petr_mha_bwd_bf16_args = petr_mha_bwd_args (k / v bf16) + dkv_overwrite
+    _fields_ = list(MhaBwdArgs._fields_) + [('dkv_overwrite', C.c_int)]
+
+
 class BboxArgs(C.Structure):
     _fields_ = _fields(('reg', C.c_void_p), ('ref', C.c_void_p), ('out', C.c_void_p),
                        ('rows', C.c_int), ('Q', C.c_int), ('code', C.c_int),
@@ -211,7 +215,7 @@ def lib():
     L.petr_mha_bwd.argtypes = [C.POINTER(MhaBwdArgs), C.c_void_p]
     L.petr_mha_bwd_bf16_workspace_bytes.argtypes = [C.c_int] * 4
     L.petr_mha_bwd_bf16_workspace_bytes.restype = C.c_size_t
-    L.petr_mha_bwd_bf16.argtypes = [C.POINTER(MhaBwdArgs), C.c_void_p]   # same block, k / v are bf16
+    L.petr_mha_bwd_bf16.argtypes = [C.POINTER(MhaBwdBf16Args), C.c_void_p]
     L.petr_bbox_epilogue_fwd.argtypes = [C.POINTER(BboxArgs), C.c_void_p]
     L.petr_bbox_epilogue_bwd.argtypes = [C.POINTER(BboxArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.petr_prof_begin.argtypes = [C.c_int]

@@ -565,6 +565,7 @@ static int mha_b_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, l
   a.dv = dv; a.dv_bs = k_bs; a.dv_hs = 32; a.dv_rs = k_rs;
   a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
   a.scale = 1.0f / sqrtf(32.f);
+  a.dkv_overwrite = 1;       // dK_l / dV_l are stored, not accumulated: the executor does not zero them in this mode
   return petr_mha_bwd_bf16(&a, s);
 }
 
@@ -1012,8 +1013,16 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
 
   for (int stage = stage_begin; stage < stage_end; ++stage) {
     if (stage == 0) {
-      // clear every += / atomic target of this backward pass
-      hipError_t e = hipMemsetAsync(Wm + W.zero_begin, 0, (size_t)(W.zero_end - W.zero_begin) * sizeof(float), ln.main);
+      // clear every += / atomic target of this backward pass; in bf16 mode dK / dV of all layers (the bulk of the range:
+      // 2 x 6 x L x 256 floats) are stored by petr_mha_bwd_bf16 and need no zero-fill
+      hipError_t e;
+      if (io->attn_bf16) {
+        e = hipMemsetAsync(Wm + W.zero_begin, 0, (size_t)(W.dk_all - W.zero_begin) * sizeof(float), ln.main);
+        if (e == hipSuccess)
+          e = hipMemsetAsync(Wm + W.d_ref_tmp, 0, (size_t)(W.zero_end - W.d_ref_tmp) * sizeof(float), ln.main);
+      } else {
+        e = hipMemsetAsync(Wm + W.zero_begin, 0, (size_t)(W.zero_end - W.zero_begin) * sizeof(float), ln.main);
+      }
       PETR_CHECK(e == hipSuccess, PETR_ERR_LAUNCH, "head_bwd: memset failed: %s", hipGetErrorString(e));
       // ---- box epilogue + reg branch ----
       const int G = cfg->shared_branches ? 1 : d.NL;

@@ -395,6 +395,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mha_bwd_bf16_kernel(
     float* dk = a.dk + (long)b * a.dk_bs + (long)hd * a.dk_hs;
     float* dv = a.dv + (long)b * a.dv_bs + (long)hd * a.dv_hs;
     const bool use_atomic = p.q_splits > 1;
+    const bool overwrite = a.dkv_overwrite != 0;          // host guarantees q_splits == 1
 #pragma unroll
     for (int i = 0; i < KT; ++i) {
 #pragma unroll
@@ -409,8 +410,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mha_bwd_bf16_kernel(
       for (int j = 0; j < 16; ++j) {
         const int idx = j * 64 + lane;
         const int kg = min(key_base + 32 * i + (idx >> 5), a.L - 1);
-        oldk[j] = use_atomic ? 0.f : dk[(long)kg * a.dk_rs + (idx & 31)];
-        oldv[j] = use_atomic ? 0.f : dv[(long)kg * a.dv_rs + (idx & 31)];
+        oldk[j] = (use_atomic || overwrite) ? 0.f : dk[(long)kg * a.dk_rs + (idx & 31)];
+        oldv[j] = (use_atomic || overwrite) ? 0.f : dv[(long)kg * a.dv_rs + (idx & 31)];
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -491,6 +492,7 @@ extern "C" int petr_mha_bwd_bf16(const petr_mha_bwd_bf16_args* ap, void* stream)
     const int v = atoi(e);
     if (v >= 1 && v <= (int)cdiv(a.Q, 32)) qsp = v;
   }
+  if (a.dkv_overwrite) qsp = 1;        // a stored dK / dV needs the whole query range in one workgroup per key block
   p.nkb = (int)cdiv(a.L, 256);
   p.q_splits = qsp;
   p.qtiles_per_split = (int)cdiv(cdiv(a.Q, 32), qsp);

@@ -249,20 +249,25 @@ def mha_bwd(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=None):
     return dq, dk, dv
 
 
-def mha_bwd_bf16(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=None):
-    """``mha_bwd`` with bfloat16 K/V ([B,H,L,32] strided views): the gradient of ``mha_fwd_bf16``; fp32 dq, dk, dv."""
+def mha_bwd_bf16(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=None, overwrite=False):
+    """``mha_bwd`` with bfloat16 K/V ([B,H,L,32] strided views): the gradient of ``mha_fwd_bf16``; fp32 dq, dk, dv.
+    ``overwrite``: dk / dv are stored into UNINITIALISED buffers (``dkv_overwrite``) instead of accumulated into zeros."""
     L = _C.lib()
     assert k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16, 'mha_bwd_bf16: K and V must be bfloat16'
     B, H, Q, _ = q.shape
     Lk = k.shape[2]
     scale = float(scale if scale is not None else 32 ** -0.5)
     dq = torch.zeros((B, H, Q, 32), dtype=torch.float32, device=q.device)
-    dk = torch.zeros((B, H, Lk, 32), dtype=torch.float32, device=q.device)
-    dv = torch.zeros_like(dk)
+    if overwrite:
+        dk = torch.full((B, H, Lk, 32), float('nan'), dtype=torch.float32, device=q.device)      # poison: must be overwritten
+        dv = torch.full_like(dk, float('nan'))
+    else:
+        dk = torch.zeros((B, H, Lk, 32), dtype=torch.float32, device=q.device)
+        dv = torch.zeros_like(dk)
     kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
-    a = _C.MhaBwdArgs(_ptr(_f32(q)), *_bhsd(q), _ptr(k), *_bhsd(k), _ptr(v), *_bhsd(v), _ptr(_f32(o)), *_bhsd(o),
-                      _ptr(_f32(do)), *_bhsd(do), _ptr(lse), _ptr(kpm), _ptr(dq), *_bhsd(dq), _ptr(dk), *_bhsd(dk),
-                      _ptr(dv), *_bhsd(dv), B, H, Q, Lk, scale, None, 0, _C.dropout(drop))
+    a = _C.MhaBwdBf16Args(_ptr(_f32(q)), *_bhsd(q), _ptr(k), *_bhsd(k), _ptr(v), *_bhsd(v), _ptr(_f32(o)), *_bhsd(o),
+                          _ptr(_f32(do)), *_bhsd(do), _ptr(lse), _ptr(kpm), _ptr(dq), *_bhsd(dq), _ptr(dk), *_bhsd(dk),
+                          _ptr(dv), *_bhsd(dv), B, H, Q, Lk, scale, None, 0, _C.dropout(drop), int(overwrite))
     _C.check(L.petr_mha_bwd_bf16(C.byref(a), _stream()), 'petr_mha_bwd_bf16')
     return dq, dk, dv
 

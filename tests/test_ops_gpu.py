@@ -635,6 +635,10 @@ def test_mha_bwd_bf16(ops, B, H, Q, L, masked, drop, kt, monkeypatch):
     kb, vb = ops.cast_bf16(dev(k)), ops.cast_bf16(dev(v))
     o, lse = ops.mha_fwd_bf16(dev(q), kb, vb, dev(kpm) if masked else None, drop=drop)
     dq, dk, dv = ops.mha_bwd_bf16(dev(q), kb, vb, o, dev(do), lse, dev(kpm) if masked else None, drop=drop)
+    # the store variant (dkv_overwrite: what the executor uses) into NaN-poisoned buffers gives the same dK / dV
+    _, dk2, dv2 = ops.mha_bwd_bf16(dev(q), kb, vb, o, dev(do), lse, dev(kpm) if masked else None, drop=drop, overwrite=True)
+    assert torch.isfinite(dk2).all() and (dk2 - dk).abs().max().item() <= 1e-6 * (1 + dk.abs().max().item())
+    assert torch.isfinite(dv2).all() and (dv2 - dv).abs().max().item() <= 1e-6 * (1 + dv.abs().max().item())
     keep = 1.0
     if drop is not None:
         p_real = round(drop[2] * 65536) / 65536

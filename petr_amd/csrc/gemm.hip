@@ -14,6 +14,8 @@
 //   * register-staged prefetch of tile t+1 during the MFMAs of tile t (cdna guide T14);
 //   * fused prologue (A + A2: query+query_pos / key+key_pos) and epilogue (bias, residual, ReLU,
 //     ReLU-mask for backward, sigmoid-gate, accumulate, head-split K/V store, split-K slabs).
+#include <stdlib.h>
+
 #include "common.h"
 
 int petr_gemm_bf16_general(const petr_gemm_args& g, hipStream_t s);   // gemm_bf16.hip
@@ -164,7 +166,7 @@ struct Stage {
   }
 };
 
-template <int BM, int BN, int WM, int WN, int BK, bool AKC, bool BKC, bool VEC, bool A2>
+template <int BM, int BN, int WM, int WN, int BK, bool AKC, bool BKC, bool VEC, bool A2, int PD = 2>
 __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const int tiles_m, const int tiles_n) {
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -224,7 +226,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
   // leaves every iteration waiting ~1-2 us on its loads; PD tiles in flight hide it.  Two, not three: the third
   // stage costs ~25 VGPRs, i.e. a wave of occupancy, and lost 4 % of the whole step in a same-box A/B (c5 5.32 ->
   // 5.10 ms, p4-1600 12.0 -> 11.45 ms); PD = 1 ties with 2.
-  constexpr int PD = 2;
+  // PD = 4 (launch_cfg picks it for grids of at most one workgroup per CU: the 900-row contractions of the decoder): there
+  // occupancy is irrelevant, the workgroup is alone on its CU and its 8 serial k-tiles each wait for an exposed share of the
+  // memory latency, so four tiles in flight instead of two halve the chain.
   SA sa[PD];
   SB sb[PD];
   // Tiles past kt_end are loaded from clamped addresses with an all-zero validity mask and multiplied as zeros:
@@ -551,6 +555,14 @@ int launch_cfg(const petr_gemm_args& g, hipStream_t s) {
   const int tiles_m = (int)cdiv(g.M, BM), tiles_n = (int)cdiv(g.N, BN);
   dim3 grid(tiles_m * tiles_n, 1, g.nb0 * g.nb1 * g.split_k);
   dim3 block(256);
+  // small grids with a chain of k-tiles: a deep-prefetch instantiation (four tiles in flight), opt-in with PETR_GEMM_DEEP=1.
+  // Measured and rejected as the default (same-box A/B, scripts/ab_env.sh, two rounds): c5 fp32 5.12 -> 5.20 ms/step,
+  // p4-1600 fp32 11.18 -> 11.24, bf16 6.43 -> 6.51: the 900-row contractions are not waiting for memory (one 32 x 32
+  // accumulator per wave = one dependent MFMA chain of 8 x 16 x 64 cycles), the extra registers only cost.
+  static const bool deep_on = getenv("PETR_GEMM_DEEP") && atoi(getenv("PETR_GEMM_DEEP")) != 0;
+  const int kseg_ = g.k_seg > 0 ? g.k_seg : g.K;
+  const long ktiles_ = (long)(g.k_seg > 0 ? g.K / g.k_seg : 1) * cdiv(kseg_, BK);
+  const bool deep = deep_on && VEC && (long)grid.x * grid.z <= 256 && ktiles_ / g.split_k >= 4;
   // dynamic LDS: two images; beyond 64 KB the per-kernel limit is raised once (host-side attribute, not a launch)
 #define PETR_GEMM_LAUNCH(AKC, BKC, A2)                                                                          \
   do {                                                                                                          \
@@ -562,7 +574,9 @@ int launch_cfg(const petr_gemm_args& g, hipStream_t s) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
       attr_set = true;                                                                                          \
     }                                                                                                           \
-    hipLaunchKernelGGL(kern, grid, block, lds_bytes, s, g, tiles_m, tiles_n);                                   \
+    if (deep) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, AKC, BKC, VEC, A2, 4>), grid, block, lds_bytes, s, g,   \
+                                 tiles_m, tiles_n);                                                              \
+    else hipLaunchKernelGGL(kern, grid, block, lds_bytes, s, g, tiles_m, tiles_n);                              \
   } while (0)
   if (g.a_kcontig && g.b_kcontig) {
     if (g.a2) PETR_GEMM_LAUNCH(true, true, true);

@@ -1,9 +1,7 @@
 #!/bin/bash
-# diagnostic: time the step under different values of one environment variable on ONE box:  ab_env.sh VAR v1 v2 ...
-var=$1; shift
-for round in 1 2; do
-for v in "$@"; do
-  env $var=$v timeout -k 10 100 python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null > /tmp/abe.json || exit 1
-  python3 -c "import json; d=json.load(open('/tmp/abe.json')); k=d['kernels']; print('$var=$v', 'ms/step', d['ms_per_step'], 'fwd_ms', d['fwd_ms'], 'bwd_cross', k['mha_bwd_cross']['mean_us'], 'bwd_self', k['mha_bwd_self']['mean_us'])"
-done
-done
+# same-box A/B of one environment toggle over the timed-only bench: scripts/ab_env.sh VAR "v1 v2" ["wl:dtype ..."]
+VAR=$1; VALS=$2; CFGS=${3:-"c5:fp32 p4_1600:bf16"}
+for round in 1 2; do for v in $VALS; do for cfg in $CFGS; do
+  wl=${cfg%%:*}; dt=${cfg##*:}
+  env $VAR=$v python bench.py --workload $wl --dtype $dt --steps 40 --warmup 8 --timed-only 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$VAR=$v $wl $dt', d['ms_per_step'])"
+done; done; done

@@ -909,6 +909,8 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
              "gemm: PETR_GEMM_BIAS_M (bias per output row) is implemented by the fp32 tiled kernel only");
   const long tiles32 = cdiv(g.M, 32) * cdiv(g.N, 32) * (long)g.nb0 * g.nb1;
   const bool slabs = g.split_k > 1 && !(g.flags & PETR_GEMM_ATOMIC);
+  // (round 2, same-box A/B: routing input gradients (B read K-major) or weight gradients (both K-major) through this kernel as
+  // well lost again - c5 fp32 5.16 -> 5.20 / 5.48 ms per step - so it stays with K-contiguous operands)
   if (!slabs && tiles32 <= 256 && g.K >= 256 && g.a_kcontig && g.b_kcontig &&
       !(g.flags & (PETR_GEMM_ATOMIC | PETR_GEMM_STORE_BF16 | PETR_GEMM_BIAS_M)) && g.k_seg <= 0) {
     petr_gemm_args q = g;

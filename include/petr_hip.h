@@ -129,7 +129,13 @@ int petr_dropout_mask(const petr_dropout* d, long rows, long cols, uint8_t* keep
  *         belongs to a weight-gradient contraction dW = dC^T X (A = dC^T), at no extra launch.
  * ------------------------------------------------------------------------------------------ */
 enum { PETR_GEMM_RELU = 1, PETR_GEMM_ACCUMULATE = 2, PETR_GEMM_RELU_MASK = 4, PETR_GEMM_SIGMOID_MUL = 8,
-       PETR_GEMM_ATOMIC = 16, PETR_GEMM_STORE_BF16 = 32, PETR_GEMM_BF16 = 64, PETR_GEMM_BIAS_M = 128 };
+       PETR_GEMM_ATOMIC = 16, PETR_GEMM_STORE_BF16 = 32, PETR_GEMM_BF16 = 64, PETR_GEMM_BIAS_M = 128,
+       PETR_GEMM_A_BF16 = 256, PETR_GEMM_B_BF16 = 512, PETR_GEMM_R_BF16 = 1024 };
+/* PETR_GEMM_A_BF16 / _B_BF16 / _R_BF16 (with PETR_GEMM_BF16): the operand `a` / `b` / the residual-or-mask operand `r` is
+ * ALREADY bf16 in memory (raw uint16_t bits behind the float pointer; ld / batch / segment strides count bf16 elements;
+ * K-contiguous rows need K % 8 == 0): activations that a producing epilogue stored with PETR_GEMM_STORE_BF16, or the
+ * bf16 dK / dV of petr_mha_bwd_bf16.  Half the operand bytes, no rounding pass; numerically identical to rounding the fp32
+ * value on load.  a_colsum of a bf16 A sums the bf16 values. */
 /* PETR_GEMM_BIAS_M: bias is indexed by the output ROW m (bias[m]) instead of the column: a convolution written with the
  * weights as the A operand, so that its result lands channel-major (NCHW) - the CPFPN neck boundary (petr_fpn.h part
  * below).  fp32 tiled kernel only. */
@@ -306,6 +312,9 @@ typedef struct {
   petr_dropout drop;           /* must equal the forward's */
   int dkv_overwrite;           /* 1: dk and dv are STORED (no zero-fill by the caller, no read-modify-write; the query range is
                                 * then never split over workgroups); 0: accumulated like petr_mha_bwd.  dq is always += */
+  int dkv_bf16;                /* 1 (needs dkv_overwrite): dk / dv point to bf16 storage (uint16_t bits, round to nearest even),
+                                * their strides count bf16 elements: what the bf16 K/V-projection backward reads
+                                * (PETR_GEMM_A_BF16) */
 } petr_mha_bwd_bf16_args;
 size_t petr_mha_bwd_bf16_workspace_bytes(int B, int H, int Q, int L);
 int petr_mha_bwd_bf16(const petr_mha_bwd_bf16_args* a, void* stream);

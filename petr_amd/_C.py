@@ -61,7 +61,7 @@ class GemmArgs(C.Structure):
 
 
 GEMM_RELU, GEMM_ACCUMULATE, GEMM_RELU_MASK, GEMM_SIGMOID_MUL, GEMM_ATOMIC, GEMM_STORE_BF16, GEMM_BF16 = 1, 2, 4, 8, 16, 32, 64
-GEMM_BIAS_M = 128
+GEMM_BIAS_M, GEMM_A_BF16, GEMM_B_BF16, GEMM_R_BF16 = 128, 256, 512, 1024
 LN_RELU, LN_NAN_TO_NUM = 1, 2
 
 
@@ -107,8 +107,8 @@ class MhaBwdArgs(C.Structure):
         ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('drop', Dropout))
 
 
-class MhaBwdBf16Args(C.Structure):    # petr_mha_bwd_bf16_args = petr_mha_bwd_args (k / v bf16) + dkv_overwrite
-    _fields_ = list(MhaBwdArgs._fields_) + [('dkv_overwrite', C.c_int)]
+class MhaBwdBf16Args(C.Structure):    # petr_mha_bwd_bf16_args = petr_mha_bwd_args (k / v bf16) + dkv_overwrite, dkv_bf16
+    _fields_ = list(MhaBwdArgs._fields_) + [('dkv_overwrite', C.c_int), ('dkv_bf16', C.c_int)]
 
 
 class BboxArgs(C.Structure):

@@ -873,7 +873,10 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
              "gemm: mask/mul flag without r operand");
   PETR_CHECK(!(g.split_k > 1 && g.c_split_stride <= 0 && !(g.flags & PETR_GEMM_ATOMIC)), PETR_ERR_INVALID,
              "gemm: split_k needs c_split_stride (or PETR_GEMM_ATOMIC)");
-  PETR_CHECK(!((g.flags & PETR_GEMM_ATOMIC) && (g.bias || g.r || (g.flags & ~(PETR_GEMM_ATOMIC | PETR_GEMM_BF16)))), PETR_ERR_UNSUPPORTED,
+  PETR_CHECK(!((g.flags & (PETR_GEMM_A_BF16 | PETR_GEMM_B_BF16 | PETR_GEMM_R_BF16)) && !(g.flags & PETR_GEMM_BF16)), PETR_ERR_INVALID,
+             "gemm: bf16 source operands need PETR_GEMM_BF16");
+  PETR_CHECK(!((g.flags & PETR_GEMM_ATOMIC) && (g.bias || g.r || (g.flags & ~(PETR_GEMM_ATOMIC | PETR_GEMM_BF16 | PETR_GEMM_A_BF16 |
+                                                                              PETR_GEMM_B_BF16)))), PETR_ERR_UNSUPPORTED,
              "gemm: PETR_GEMM_ATOMIC excludes bias/residual/other flags");
   PETR_CHECK((long)g.nb0 * g.nb1 * g.split_k <= 65535, PETR_ERR_UNSUPPORTED, "gemm: too many batches");
   PETR_CHECK(g.k_seg <= 0 || g.K % g.k_seg == 0, PETR_ERR_INVALID, "gemm: K=%d is not a multiple of k_seg=%d", g.K, g.k_seg);
@@ -900,7 +903,8 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
     // contractions of the bf16 training step - goes to the general kernel of gemm_bf16.hip
     const bool staged = g.K % 32 == 0 && (long)g.M * g.N * g.nb0 * g.nb1 >= 128L * 128 * 64;
     const bool simple = g.b_kcontig && g.K % 16 == 0 && g.split_k == 1 && g.k_seg <= 0 && !g.a_colsum &&
-                        !(g.flags & (PETR_GEMM_ACCUMULATE | PETR_GEMM_ATOMIC | PETR_GEMM_RELU_MASK | PETR_GEMM_SIGMOID_MUL)) && vec &&
+                        !(g.flags & (PETR_GEMM_ACCUMULATE | PETR_GEMM_ATOMIC | PETR_GEMM_RELU_MASK | PETR_GEMM_SIGMOID_MUL |
+                                     PETR_GEMM_A_BF16 | PETR_GEMM_B_BF16 | PETR_GEMM_R_BF16)) && vec &&
                         (!g.a_kcontig || !(g.lda & 3)) && !(g.ldb & 3) && (g.a_kcontig || staged);
     if (simple) return launch_bf16(g, s);
     return petr_gemm_bf16_general(g, s);

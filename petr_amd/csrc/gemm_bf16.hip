@@ -113,7 +113,98 @@ struct Stage16 {
   }
 };
 
-template <bool AKC, bool BKC>
+// the same tile when the operand is ALREADY bf16 in memory (PETR_GEMM_A_BF16 / PETR_GEMM_B_BF16: activations that a
+// producing epilogue stored as bf16 - dK / dV of the attention backward, the position-embedding hidden layers and their
+// gradients): half the bytes, no rounding pass.  Element strides (ld, batch, segment) count bf16 elements.
+//   K-contiguous: 2 pieces of 16 bytes (8 k) per thread, piece = t + 256 i -> row piece >> 2, k = 8 (piece & 3);
+//   K-major: row t & 127, 16 consecutive k as 2-byte loads coalesced across the lanes.
+template <bool KC>
+struct Stage16B {
+  uint4 x[2];
+  int off[2];
+  unsigned rowok;
+  __device__ __forceinline__ void init(long ld, int row0, int rows) {
+    const int t = threadIdx.x & 255;
+    rowok = 0;
+    if (KC) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int pc = t + 256 * i;
+        const int row = row0 + (pc >> 2);
+        off[i] = min(row, rows - 1) * (int)ld + 8 * (pc & 3);
+        rowok |= (row < rows ? 1u : 0u) << i;
+      }
+    } else {
+      const int row = row0 + (t & 127);
+      off[0] = min(row, rows - 1);
+      off[1] = 0;
+      rowok = row < rows ? 1u : 0u;
+    }
+  }
+  __device__ __forceinline__ void load(const float* base_f, long ld, int k0, int kend) {
+    const uint16_t* base = reinterpret_cast<const uint16_t*>(base_f);
+    const int t = threadIdx.x & 255;
+    if (KC) {
+      const int kq = 8 * (t & 3);
+      const int kc = min(k0 + kq, kend - 8) - kq;                     // K % 8 == 0: the piece stays inside the row
+#pragma unroll
+      for (int i = 0; i < 2; ++i) x[i] = *reinterpret_cast<const uint4*>(base + off[i] + kc);
+    } else {
+      const int kb = k0 + 16 * (t >> 7);
+      unsigned short e16[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) e16[e] = base[(long)min(kb + e, kend - 1) * ld + off[0]];
+      x[0] = make_uint4(e16[0] | (e16[1] << 16), e16[2] | (e16[3] << 16), e16[4] | (e16[5] << 16), e16[6] | (e16[7] << 16));
+      x[1] = make_uint4(e16[8] | (e16[9] << 16), e16[10] | (e16[11] << 16), e16[12] | (e16[13] << 16), e16[14] | (e16[15] << 16));
+    }
+  }
+  __device__ __forceinline__ void store(uint16_t* img, bool ragged, int k0, int kend) {
+    const int t = threadIdx.x & 255;
+    if (KC) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int pc = t + 256 * i;
+        uint4 v = x[i];
+        if (ragged && !(((rowok >> i) & 1u) && k0 + 8 * (pc & 3) < kend)) v = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(img + (pc >> 2) * GB_PITCH + 8 * (pc & 3)) = v;
+      }
+    } else {
+      uint4 a = x[0], b = x[1];
+      if (ragged) {
+        const int kb = k0 + 16 * (t >> 7);
+        uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t lo = (rowok && kb + 2 * j < kend) ? (w[j] & 0xFFFFu) : 0u;
+          const uint32_t hi = (rowok && kb + 2 * j + 1 < kend) ? (w[j] & 0xFFFF0000u) : 0u;
+          w[j] = lo | hi;
+        }
+        a = make_uint4(w[0], w[1], w[2], w[3]);
+        b = make_uint4(w[4], w[5], w[6], w[7]);
+      }
+      uint4* d = reinterpret_cast<uint4*>(img + (t & 127) * GB_PITCH + 16 * (t >> 7));
+      d[0] = a;
+      d[1] = b;
+    }
+  }
+  // sum of this thread's 16 k of its row (K-major only): the bias-gradient column sum, from the bf16 values
+  __device__ __forceinline__ float ksum(int k0, int kend) const {
+    const int kb = k0 + 16 * ((threadIdx.x & 255) >> 7);
+    const uint32_t w[8] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w};
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s += (kb + 2 * j < kend) ? __uint_as_float(w[j] << 16) : 0.f;
+      s += (kb + 2 * j + 1 < kend) ? __uint_as_float(w[j] & 0xFFFF0000u) : 0.f;
+    }
+    return s;
+  }
+};
+
+template <bool KC, bool S16> struct StageSel { typedef Stage16<KC> type; };
+template <bool KC> struct StageSel<KC, true> { typedef Stage16B<KC> type; };
+
+template <bool AKC, bool BKC, bool A16 = false, bool B16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_gen_kernel(const petr_gemm_args g, const int tiles_m, const int tiles_n) {
   __shared__ __attribute__((aligned(16))) uint16_t lds[2][(GB_BM + GB_BN) * GB_PITCH];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -126,8 +217,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_gen_kernel(const petr_gemm_a
   const int ks = z % g.split_k;
   z /= g.split_k;
   const int z1 = z % g.nb1, z0 = z / g.nb1;
-  const float* Ab = g.a + z0 * g.a_bs0 + z1 * g.a_bs1;
-  const float* Bb = g.b + z0 * g.b_bs0 + z1 * g.b_bs1;
+  // operand bases as byte addresses: element strides count 4-byte floats or 2-byte bf16 values
+  constexpr int AE = A16 ? 2 : 4, BE = B16 ? 2 : 4;
+  const char* Ab = reinterpret_cast<const char*>(g.a) + (z0 * g.a_bs0 + z1 * g.a_bs1) * AE;
+  const char* Bb = reinterpret_cast<const char*>(g.b) + (z0 * g.b_bs0 + z1 * g.b_bs1) * BE;
 
   const int kseg = g.k_seg > 0 ? g.k_seg : g.K;
   const int nseg = g.k_seg > 0 ? g.K / g.k_seg : 1;
@@ -137,8 +230,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_gen_kernel(const petr_gemm_a
   const int kt_begin = ks * kt_per;
   const int kt_end = min(ktiles, kt_begin + kt_per);
 
-  Stage16<AKC> sa;
-  Stage16<BKC> sb;
+  typename StageSel<AKC, A16>::type sa;
+  typename StageSel<BKC, B16>::type sb;
   sa.init(g.lda, m0, g.M);
   sb.init(g.ldb, n0, g.N);
   const bool rows_ragged_a = m0 + GB_BM > g.M, rows_ragged_b = n0 + GB_BN > g.N;
@@ -159,17 +252,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_gen_kernel(const petr_gemm_a
     const int seg = kt / tps;
     const int k0 = (kt - seg * tps) * GB_BK;
     k0_out = k0;
-    sa.load(Ab + (long)seg * g.a_seg_stride, g.lda, k0, kseg);
-    sb.load(Bb + (long)seg * g.b_seg_stride, g.ldb, k0, kseg);
+    sa.load(reinterpret_cast<const float*>(Ab + (long)seg * g.a_seg_stride * AE), g.lda, k0, kseg);
+    sb.load(reinterpret_cast<const float*>(Bb + (long)seg * g.b_seg_stride * BE), g.ldb, k0, kseg);
   };
   auto lstore = [&](int buf, int k0) {
     const bool kr = k0 + GB_BK > kseg;
-    if (!AKC && do_colsum) {        // exact fp32 column sums of A (= dC^T): the bias gradient of a weight-gradient contraction
-      const int kb = k0 + 16 * (t >> 7);
-      float s = 0.f;
+    if (!AKC && do_colsum) {        // column sums of A (= dC^T): the bias gradient of a weight-gradient contraction,
+      if constexpr (A16) {          // from the fp32 staging values (exact), or from the bf16 values of a bf16 operand
+        colacc += sa.ksum(k0, kseg);
+      } else {
+        const int kb = k0 + 16 * (t >> 7);
+        float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s += (kb + e < kseg) ? sa.v[e] : 0.f;
-      colacc += s;
+        for (int e = 0; e < 16; ++e) s += (kb + e < kseg) ? sa.v[e] : 0.f;
+        colacc += s;
+      }
     }
     sa.store(lds[buf], rows_ragged_a || kr, k0, kseg);
     sb.store(lds[buf] + GB_BM * GB_PITCH, rows_ragged_b || kr, k0, kseg);
@@ -232,7 +329,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_gen_kernel(const petr_gemm_a
         const bool ok = m < g.M && n < g.N;
         float v = acc[i][jn][r] * g.alpha + bv;
         float* dst = C + (long)mc * g.ldc + ccol;
-        const float rv = R ? R[(long)mc * g.ldr + nc] : 0.f;
+        float rv = 0.f;
+        if (R) {
+          if (flags & PETR_GEMM_R_BF16)
+            rv = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(g.r)[z0 * g.r_bs0 + z1 * g.r_bs1 + (long)mc * g.ldr + nc] << 16);
+          else rv = R[(long)mc * g.ldr + nc];
+        }
         const float old = (flags & PETR_GEMM_ACCUMULATE) ? *dst : 0.f;
         if (flags & PETR_GEMM_RELU_MASK) v = rv > 0.f ? v : 0.f;
         else v += rv;
@@ -425,11 +527,17 @@ int petr_gemm_bf16_general(const petr_gemm_args& g, hipStream_t s) {
              "gemm: PETR_GEMM_BF16 (general) has no a2 addend / sigmoid-gate epilogue");
   PETR_CHECK(!g.a_colsum || !g.a_kcontig, PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_BF16 a_colsum needs a K-major A");
   // K-contiguous operands are read as float4 along K, K-major ones as dwords along the rows
-  PETR_CHECK((!g.a_kcontig || (kseg % 4 == 0 && kseg >= 4 && !(g.lda & 3) && !(g.a_bs0 & 3) && !(g.a_bs1 & 3) &&
-                               !(g.a_seg_stride & 3) && aligned16(g.a))) &&
-                 (!g.b_kcontig || (kseg % 4 == 0 && kseg >= 4 && !(g.ldb & 3) && !(g.b_bs0 & 3) && !(g.b_bs1 & 3) &&
-                                   !(g.b_seg_stride & 3) && aligned16(g.b))),
-             PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_BF16 needs 16-byte aligned K-contiguous operands with K %% 4 == 0");
+  {
+    const int am = (g.flags & PETR_GEMM_A_BF16) ? 7 : 3, bm = (g.flags & PETR_GEMM_B_BF16) ? 7 : 3;   // elements per 16 bytes - 1
+    PETR_CHECK((!g.a_kcontig || (!(kseg & am) && kseg > am && !(g.lda & am) && !(g.a_bs0 & am) && !(g.a_bs1 & am) &&
+                                 !(g.a_seg_stride & am) && aligned16(g.a))) &&
+                   (!g.b_kcontig || (!(kseg & bm) && kseg > bm && !(g.ldb & bm) && !(g.b_bs0 & bm) && !(g.b_bs1 & bm) &&
+                                     !(g.b_seg_stride & bm) && aligned16(g.b))),
+               PETR_ERR_UNSUPPORTED,
+               "gemm: PETR_GEMM_BF16 needs 16-byte aligned K-contiguous operands (K %% 4 == 0 for fp32, K %% 8 == 0 for bf16 sources)");
+  }
+  PETR_CHECK(!((g.flags & (PETR_GEMM_A_BF16 | PETR_GEMM_B_BF16 | PETR_GEMM_R_BF16)) && (getenv("PETR_GEMM16_PC") && atoi(getenv("PETR_GEMM16_PC")))),
+             PETR_ERR_UNSUPPORTED, "gemm: the producer/consumer variant takes fp32 sources only");
   // 32-bit element offsets inside one batch / segment
   PETR_CHECK((long)(g.a_kcontig ? g.M : kseg) * g.lda + (g.a_kcontig ? kseg : g.M) < (1L << 31) &&
                  (long)(g.b_kcontig ? g.N : kseg) * g.ldb + (g.b_kcontig ? kseg : g.N) < (1L << 31),
@@ -450,10 +558,19 @@ int petr_gemm_bf16_general(const petr_gemm_args& g, hipStream_t s) {
     return PETR_OK;
   }
   dim3 grid(tm * tn, 1, g.nb0 * g.nb1 * g.split_k), block(256);
-  if (g.a_kcontig && g.b_kcontig) hipLaunchKernelGGL((gemm_bf16_gen_kernel<true, true>), grid, block, 0, s, g, tm, tn);
-  else if (g.a_kcontig) hipLaunchKernelGGL((gemm_bf16_gen_kernel<true, false>), grid, block, 0, s, g, tm, tn);
-  else if (g.b_kcontig) hipLaunchKernelGGL((gemm_bf16_gen_kernel<false, true>), grid, block, 0, s, g, tm, tn);
-  else hipLaunchKernelGGL((gemm_bf16_gen_kernel<false, false>), grid, block, 0, s, g, tm, tn);
+  const bool a16 = (g.flags & PETR_GEMM_A_BF16) != 0, b16 = (g.flags & PETR_GEMM_B_BF16) != 0;
+#define PETR_G16(AKC, BKC)                                                                                              \
+  do {                                                                                                                  \
+    if (a16 && b16) hipLaunchKernelGGL((gemm_bf16_gen_kernel<AKC, BKC, true, true>), grid, block, 0, s, g, tm, tn);     \
+    else if (a16) hipLaunchKernelGGL((gemm_bf16_gen_kernel<AKC, BKC, true, false>), grid, block, 0, s, g, tm, tn);      \
+    else if (b16) hipLaunchKernelGGL((gemm_bf16_gen_kernel<AKC, BKC, false, true>), grid, block, 0, s, g, tm, tn);      \
+    else hipLaunchKernelGGL((gemm_bf16_gen_kernel<AKC, BKC, false, false>), grid, block, 0, s, g, tm, tn);              \
+  } while (0)
+  if (g.a_kcontig && g.b_kcontig) PETR_G16(true, true);
+  else if (g.a_kcontig) PETR_G16(true, false);
+  else if (g.b_kcontig) PETR_G16(false, true);
+  else PETR_G16(false, false);
+#undef PETR_G16
   PETR_LAUNCH_CHECK("gemm_bf16_gen");
   return PETR_OK;
 }

@@ -549,8 +549,8 @@ static int mha_b(const float* q, long q_bs, long q_rs, const float* k, long k_bs
 
 // gradient of mha_f_bf16 (io->attn_bf16 training step)
 static int mha_b_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, long k_bs, long k_rs, const uint16_t* v,
-                      const float* o, const float* d_o, const float* lse, const uint8_t* kpm, float* dq, float* dk, float* dv,
-                      const Dims& d, int L, void* s, const petr_dropout* drop = nullptr) {
+                      const float* o, const float* d_o, const float* lse, const uint8_t* kpm, float* dq, uint16_t* dk,
+                      uint16_t* dv, bool dkv16, const Dims& d, int L, void* s, const petr_dropout* drop = nullptr) {
   petr_mha_bwd_bf16_args a;
   memset(&a, 0, sizeof a);
   if (drop) a.drop = *drop;
@@ -561,12 +561,26 @@ static int mha_b_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, l
   a.d_o = d_o; a.do_bs = (long)d.Q * d.C; a.do_hs = 32; a.do_rs = d.C;
   a.lse = lse; a.kpm = kpm;
   a.dq = dq; a.dq_bs = q_bs; a.dq_hs = 32; a.dq_rs = q_rs;
-  a.dk = dk; a.dk_bs = k_bs; a.dk_hs = 32; a.dk_rs = k_rs;
-  a.dv = dv; a.dv_bs = k_bs; a.dv_hs = 32; a.dv_rs = k_rs;
+  a.dk = reinterpret_cast<float*>(dk); a.dk_bs = k_bs; a.dk_hs = 32; a.dk_rs = k_rs;
+  a.dv = reinterpret_cast<float*>(dv); a.dv_bs = k_bs; a.dv_hs = 32; a.dv_rs = k_rs;
   a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
   a.scale = 1.0f / sqrtf(32.f);
   a.dkv_overwrite = 1;       // dK_l / dV_l are stored, not accumulated: the executor does not zero them in this mode
+  a.dkv_bf16 = dkv16;        // ... and as bf16: the K/V-projection backward rounds them to bf16 anyway (PETR_GEMM_A_BF16)
   return petr_mha_bwd_bf16(&a, s);
+}
+
+// bf16 mode stores the two 4C-wide position-embedding hiddens (relu outputs, the largest activations of the step) and their
+// gradients as bf16 in the front half of their fp32 buffers: every contraction that touches them rounds to bf16 on load
+// anyway, so only the bytes change.  Needs 16-byte K-contiguous rows on the bf16 side (C % 8 == 0 always holds).
+static bool env_on(const char* name) { const char* v = getenv(name); return !v || atoi(v) != 0; }    // default on
+static bool hidden_bf16(const petr_head_io* io) {
+  static const bool on = env_on("PETR_HID16");       // PETR_HID16=0: fp32 storage (the same-box A/B switch)
+  return io->attn_bf16 != 0 && on;
+}
+static bool dkv_bf16(const petr_head_io* io) {       // dK / dV of the cross-attention stored as bf16 (PETR_DKV16=0: fp32)
+  static const bool on = env_on("PETR_DKV16");
+  return io->attn_bf16 != 0 && on;
 }
 
 // route a token-sized gradient contraction to the bf16 matrix cores (gemm_bf16.hip): 128 x 128 output tiles, so the
@@ -686,6 +700,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   // front half of the fp32 K/V buffers, which stay otherwise unwritten, and the cross-attention (forward AND
   // backward: petr_mha_fwd_bf16 / petr_mha_bwd_bf16) reads them; query-sized work (900 rows) stays fp32
   const bool attn_bf16 = io->attn_bf16 != 0;
+  const bool hid16 = hidden_bf16(io);
   // bf16 mode: the 1x1 convolutions over NCHW maps take the K-major variant of the bf16 contraction where it applies
   auto bf16_km = [&](const petr_gemm_args& q) {
     return attn_bf16 && q.K % 32 == 0 && (long)q.M * q.N * (q.nb0 > 0 ? q.nb0 : 1) >= 128L * 128 * 64 && !(q.lda & 3) && !(q.ldb & 3);
@@ -737,6 +752,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.c = Wm + W.h2; g.ldc = 4 * C; g.c_bs0 = (long)d.HW * 4 * C; g.bias = Pm + P.ad_b1;
     g.M = d.HW; g.N = 4 * C; g.K = C * 3 / 2; g.nb0 = V; g.flags = PETR_GEMM_RELU;
     if (bf16_km(g)) g.flags |= PETR_GEMM_BF16;
+    if (hid16) g.flags |= PETR_GEMM_BF16 | PETR_GEMM_STORE_BF16;      // bf16 hidden (same element indexing, 2-byte elements)
     RUN(petr_gemm(&g, s2));
   }
   // ---- side 1: 3D position embedding (petr_head.py:286-334): coords3d, conv 3D->4C, ReLU, conv 4C->C ----
@@ -754,9 +770,11 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.c = Wm + W.h1; g.ldc = 4 * C; g.c_bs0 = (long)d.HW * 4 * C; g.bias = Pm + P.pe_b1;
     g.M = d.HW; g.N = 4 * C; g.K = 3 * d.D; g.nb0 = V; g.flags = PETR_GEMM_RELU;
     if (bf16_km(g)) g.flags |= PETR_GEMM_BF16;
+    if (hid16) g.flags |= PETR_GEMM_BF16 | PETR_GEMM_STORE_BF16;
     RUN(petr_gemm(&g, s1));
     g = lin_fwd(Wm + W.h1, Pm + P.pe_w2, Pm + P.pe_b2, Wm + (cfg->with_fpe ? W.pe1 : W.pos), d.BL, C, 4 * C);
     if (attn_bf16) g.flags |= PETR_GEMM_BF16;      // bf16 mode: the K-contiguous L-sized contractions run on bf16 MFMA
+    if (hid16) g.flags |= PETR_GEMM_A_BF16;
     RUN(petr_gemm(&g, s1));
     // wait for side 2 (memory, sine hidden)
     if (ln.ctx) {
@@ -778,6 +796,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g = lin_fwd(Wm + W.h2, Pm + P.ad_w2, Pm + P.ad_b2, Wm + W.pos, d.BL, C, 4 * C);
     if (attn_bf16) { g.flags = PETR_GEMM_BF16; g.r = Wm + W.pos; g.ldr = C; }   // same sum with pos as the residual operand
     else g.flags = PETR_GEMM_ACCUMULATE;
+    if (hid16) g.flags |= PETR_GEMM_A_BF16;
     RUN(petr_gemm(&g, s1));
     // key = memory + key_pos (petr_transformer.py:343-344), once for all layers
     RUN(petr_add_rows(Wm + W.mem, Wm + W.pos, Wm + W.mempos, d.BL, 0, C, s1));
@@ -1001,6 +1020,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   // io->attn_bf16: the token-sized gradient contractions (K/V projections, position-embedding MLPs, input_proj,
   // PETRv2's feature-guided PE) and the cross-attention backward run on the bf16 matrix cores, like their forwards
   const bool bf16 = io->attn_bf16 != 0;
+  const bool hid16 = hidden_bf16(io);
   auto L16 = [&](const petr_gemm_args& g) { return bf16 ? to_bf16(g) : g; };
   // PETR_KV_BWD_OVERLAP=1 (opt-in): the K/V projection backward per layer on the side streams beside the decoder chain
   // instead of two batched contractions in the final stage.  Measured and rejected as a default (same-box A/B,
@@ -1010,6 +1030,15 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   const bool kv_overlap = kv_overlap_env && ln.ctx != nullptr;
   const uint16_t* k16 = reinterpret_cast<const uint16_t*>(Wm + W.k_all);
   const uint16_t* v16 = reinterpret_cast<const uint16_t*>(Wm + W.v_all);
+  // bf16 mode keeps dK / dV of all layers as bf16 in the front half of their fp32 buffers (same element indexing)
+  const bool dkv16 = dkv_bf16(io);
+  uint16_t* dk16 = reinterpret_cast<uint16_t*>(Wm + W.dk_all);
+  uint16_t* dv16 = reinterpret_cast<uint16_t*>(Wm + W.dv_all);
+  auto dkv_ptr = [&](int kv, long off) -> const float* {      // dK (kv = 0) / dV (1) at element offset off, either storage
+    if (dkv16) return reinterpret_cast<const float*>((kv == 0 ? dk16 : dv16) + off);
+    return Wm + (kv == 0 ? W.dk_all : W.dv_all) + off;
+  };
+  const int dkv_flag = dkv16 ? PETR_GEMM_A_BF16 : 0;
 
   for (int stage = stage_begin; stage < stage_end; ++stage) {
     if (stage == 0) {
@@ -1164,8 +1193,9 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       if (bf16)
         RUN(mha_b_bf16(Wm + lw.qc, (long)d.Q * C, C, k16 + (long)l * d.L * C, (long)d.NL * d.L * C, C,
                        v16 + (long)l * d.L * C, Wm + lw.ao_c, d_ao, Wm + lw.lse_c, kpm, d_qc,
-                       Wm + W.dk_all + (long)l * d.L * C, Wm + W.dv_all + (long)l * d.L * C, d, (int)d.L, s,
-                       training ? &dr[2] : nullptr));
+                       dkv16 ? dk16 + (long)l * d.L * C : reinterpret_cast<uint16_t*>(Wm + W.dk_all + (long)l * d.L * C),
+                       dkv16 ? dv16 + (long)l * d.L * C : reinterpret_cast<uint16_t*>(Wm + W.dv_all + (long)l * d.L * C), dkv16, d,
+                       (int)d.L, s, training ? &dr[2] : nullptr));
       else
       RUN(mha_b(Wm + lw.qc, (long)d.Q * C, C, Wm + W.k_all + (long)l * d.L * C, (long)d.NL * d.L * C, C,
                 Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, d_ao, Wm + lw.lse_c, kpm, d_qc,
@@ -1176,7 +1206,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // produced dK_l / dV_l and run beside the 900-row chain of the remaining layers; the final stage only joins.
       // K path on side 0, V path on side 1 (each accumulates into one buffer, so each stays on one in-order stream).
       for (int kv = 0; kv < 2 && kv_overlap; ++kv) {
-        const float* dkv = Wm + (kv == 0 ? W.dk_all : W.dv_all) + (long)l * d.L * C;
+        const float* dkv = dkv_ptr(kv, (long)l * d.L * C);
         const float* src = kv == 0 ? Wm + W.mempos : Wm + W.mem;
         void* sd = ln.side(kv);
         ln.fork(kv);
@@ -1187,7 +1217,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g2.a_colsum = Gp + lp.ca_in_b + (kv + 1) * C;
         g2.M = C; g2.N = C; g2.K = (int)d.BL;
         g2.k_seg = (int)d.L; g2.a_seg_stride = (long)d.NL * d.L * C; g2.b_seg_stride = d.L * C;
-        g2.flags = PETR_GEMM_ATOMIC;
+        g2.flags = PETR_GEMM_ATOMIC | dkv_flag;
         g2.split_k = 32;
         g2 = L16(g2);
         RUN(petr_gemm(&g2, sd));
@@ -1196,7 +1226,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g2.b = Pm + lp.ca_in_w + (long)(kv + 1) * C * C; g2.ldb = C; g2.b_kcontig = 0;
         g2.c = Wm + (kv == 0 ? W.d_mempos : W.d_mem); g2.ldc = C; g2.c_bs0 = d.L * C;
         g2.M = (int)d.L; g2.N = C; g2.K = C; g2.nb0 = d.B;
-        if (l != d.NL - 1) g2.flags = PETR_GEMM_ACCUMULATE;
+        g2.flags = (l != d.NL - 1 ? PETR_GEMM_ACCUMULATE : 0) | dkv_flag;
         g2 = L16(g2);
         RUN(petr_gemm(&g2, sd));
       }
@@ -1238,7 +1268,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       ln.join(0);
       ln.join(1);
       for (int kv = 0; kv < 2 && !kv_overlap; ++kv) {     // single-stream / opt-out schedule: all layers in one contraction each
-        const float* dkv = Wm + (kv == 0 ? W.dk_all : W.dv_all);
+        const float* dkv = dkv_ptr(kv, 0);
         const float* src = kv == 0 ? Wm + W.mempos : Wm + W.mem;
         petr_gemm_args g = gemm0();      // dW_l[C,C] += sum_{b,t} dKV[b][l][t][o] * src[b][t][c]
         g.a = dkv; g.lda = C; g.a_kcontig = 0; g.a_bs0 = d.L * C;
@@ -1247,7 +1277,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g.a_colsum = Gp + P.lay[0].ca_in_b + (kv + 1) * C; g.cs_bs0 = P.ca_in_stride;
         g.M = C; g.N = C; g.K = (int)d.BL; g.nb0 = d.NL;
         g.k_seg = (int)d.L; g.a_seg_stride = (long)d.NL * d.L * C; g.b_seg_stride = d.L * C;
-        g.flags = PETR_GEMM_ATOMIC;
+        g.flags = PETR_GEMM_ATOMIC | dkv_flag;
         g.split_k = 8;
         RUN(wgrad(L16(g)));
         g = gemm0();      // d_src[b][t][c] = sum_{l,o} dKV[b][l][t][o] * W_l[o][c]
@@ -1256,6 +1286,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g.c = Wm + (kv == 0 ? W.d_mempos : W.d_mem); g.ldc = C; g.c_bs0 = d.L * C;
         g.M = (int)d.L; g.N = C; g.K = d.NL * C; g.nb0 = d.B;
         g.k_seg = C; g.a_seg_stride = d.L * C; g.b_seg_stride = P.ca_in_stride;
+        g.flags = dkv_flag;
         g = L16(g);
         RUN(petr_gemm(&g, s));
       }
@@ -1287,9 +1318,12 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         const int Kin = which == 0 ? 3 * d.D : C * 3 / 2;
         float* d_hpe = Wm + W.d_hpe[which];
         const float* dy = which == 0 ? d_pe : d_pos;
-        RUN(wgrad(L16(lin_wgrad(dy, C, hid, 4 * C, Gp + w2, Gp + b2, d.BL, C, 4 * C))));
-        petr_gemm_args g = lin_dgrad(dy, Pm + w2, d_hpe, d.BL, C, 4 * C);
+        petr_gemm_args g = lin_wgrad(dy, C, hid, 4 * C, Gp + w2, Gp + b2, d.BL, C, 4 * C);
+        if (hid16) g.flags |= PETR_GEMM_B_BF16;
+        RUN(wgrad(L16(g)));
+        g = lin_dgrad(dy, Pm + w2, d_hpe, d.BL, C, 4 * C);
         g.flags = PETR_GEMM_RELU_MASK; g.r = hid; g.ldr = 4 * C;
+        if (hid16) g.flags |= PETR_GEMM_R_BF16 | PETR_GEMM_STORE_BF16;       // bf16 mask operand, bf16 hidden gradient
         g = L16(g);
         RUN(petr_gemm(&g, s));
         g = gemm0();      // dW1[4C, Kin] += sum_{view, hw} d_h[view*HW+hw][f] * feat[view][c][hw]
@@ -1298,7 +1332,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g.c = Gp + w1; g.ldc = Kin; g.a_colsum = Gp + b1;
         g.M = 4 * C; g.N = Kin; g.K = V * d.HW;
         g.k_seg = d.HW; g.a_seg_stride = (long)d.HW * 4 * C; g.b_seg_stride = (long)Kin * d.HW;
-        g.flags = PETR_GEMM_ATOMIC; g.split_k = 8;
+        g.flags = PETR_GEMM_ATOMIC | (hid16 ? PETR_GEMM_A_BF16 : 0); g.split_k = 8;
         RUN(wgrad(L16(g)));
       }
       // input_proj

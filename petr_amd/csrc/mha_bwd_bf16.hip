@@ -392,8 +392,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mha_bwd_bf16_kernel(
   {
     float* tk = red + wave * RED_SLAB;
     float* tv = red + (NW + wave) * RED_SLAB;
-    float* dk = a.dk + (long)b * a.dk_bs + (long)hd * a.dk_hs;
-    float* dv = a.dv + (long)b * a.dv_bs + (long)hd * a.dv_hs;
+    // element strides count floats, or bf16 values with dkv_bf16: the base offset is applied in the matching unit
+    float* dk = a.dkv_bf16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.dk) + (long)b * a.dk_bs + (long)hd * a.dk_hs)
+                           : a.dk + (long)b * a.dk_bs + (long)hd * a.dk_hs;
+    float* dv = a.dkv_bf16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(a.dv) + (long)b * a.dv_bs + (long)hd * a.dv_hs)
+                           : a.dv + (long)b * a.dv_bs + (long)hd * a.dv_hs;
     const bool use_atomic = p.q_splits > 1;
     const bool overwrite = a.dkv_overwrite != 0;          // host guarantees q_splits == 1
 #pragma unroll
@@ -422,7 +425,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mha_bwd_bf16_kernel(
         if (kg < a.L) {
           float* pk = dk + (long)kg * a.dk_rs + d;
           float* pv = dv + (long)kg * a.dv_rs + d;
-          if (use_atomic) {
+          if (a.dkv_bf16) {          // bf16 stores: same element offsets on 2-byte elements
+            reinterpret_cast<uint16_t*>(dk)[(long)kg * a.dk_rs + d] = __builtin_bit_cast(uint16_t, (__bf16)gk);
+            reinterpret_cast<uint16_t*>(dv)[(long)kg * a.dv_rs + d] = __builtin_bit_cast(uint16_t, (__bf16)gv);
+          } else if (use_atomic) {
             atomicAdd(pk, gk);
             atomicAdd(pv, gv);
           } else {
@@ -492,6 +498,7 @@ extern "C" int petr_mha_bwd_bf16(const petr_mha_bwd_bf16_args* ap, void* stream)
     const int v = atoi(e);
     if (v >= 1 && v <= (int)cdiv(a.Q, 32)) qsp = v;
   }
+  PETR_CHECK(!a.dkv_bf16 || a.dkv_overwrite, PETR_ERR_INVALID, "mha_bwd_bf16: dkv_bf16 needs dkv_overwrite");
   if (a.dkv_overwrite) qsp = 1;        // a stored dK / dV needs the whole query range in one workgroup per key block
   p.nkb = (int)cdiv(a.L, 256);
   p.q_splits = qsp;

@@ -249,7 +249,7 @@ def mha_bwd(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=None):
     return dq, dk, dv
 
 
-def mha_bwd_bf16(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=None, overwrite=False):
+def mha_bwd_bf16(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=None, overwrite=False, dkv_bf16=False):
     """``mha_bwd`` with bfloat16 K/V ([B,H,L,32] strided views): the gradient of ``mha_fwd_bf16``; fp32 dq, dk, dv.
     ``overwrite``: dk / dv are stored into UNINITIALISED buffers (``dkv_overwrite``) instead of accumulated into zeros."""
     L = _C.lib()
@@ -259,7 +259,8 @@ def mha_bwd_bf16(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=No
     scale = float(scale if scale is not None else 32 ** -0.5)
     dq = torch.zeros((B, H, Q, 32), dtype=torch.float32, device=q.device)
     if overwrite:
-        dk = torch.full((B, H, Lk, 32), float('nan'), dtype=torch.float32, device=q.device)      # poison: must be overwritten
+        dt = torch.bfloat16 if dkv_bf16 else torch.float32          # dkv_bf16: the kernel stores bf16 (needs overwrite)
+        dk = torch.full((B, H, Lk, 32), float('nan'), dtype=dt, device=q.device)      # poison: must be overwritten
         dv = torch.full_like(dk, float('nan'))
     else:
         dk = torch.zeros((B, H, Lk, 32), dtype=torch.float32, device=q.device)
@@ -267,7 +268,7 @@ def mha_bwd_bf16(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=No
     kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
     a = _C.MhaBwdBf16Args(_ptr(_f32(q)), *_bhsd(q), _ptr(k), *_bhsd(k), _ptr(v), *_bhsd(v), _ptr(_f32(o)), *_bhsd(o),
                           _ptr(_f32(do)), *_bhsd(do), _ptr(lse), _ptr(kpm), _ptr(dq), *_bhsd(dq), _ptr(dk), *_bhsd(dk),
-                          _ptr(dv), *_bhsd(dv), B, H, Q, Lk, scale, None, 0, _C.dropout(drop), int(overwrite))
+                          _ptr(dv), *_bhsd(dv), B, H, Q, Lk, scale, None, 0, _C.dropout(drop), int(overwrite), int(dkv_bf16))
     _C.check(L.petr_mha_bwd_bf16(C.byref(a), _stream()), 'petr_mha_bwd_bf16')
     return dq, dk, dv
 

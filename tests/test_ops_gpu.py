@@ -639,6 +639,10 @@ def test_mha_bwd_bf16(ops, B, H, Q, L, masked, drop, kt, monkeypatch):
     _, dk2, dv2 = ops.mha_bwd_bf16(dev(q), kb, vb, o, dev(do), lse, dev(kpm) if masked else None, drop=drop, overwrite=True)
     assert torch.isfinite(dk2).all() and (dk2 - dk).abs().max().item() <= 1e-6 * (1 + dk.abs().max().item())
     assert torch.isfinite(dv2).all() and (dv2 - dv).abs().max().item() <= 1e-6 * (1 + dv.abs().max().item())
+    # ... and with bf16 stores (dkv_bf16): exactly the round-to-nearest-even image of the fp32 result
+    _, dk3, dv3 = ops.mha_bwd_bf16(dev(q), kb, vb, o, dev(do), lse, dev(kpm) if masked else None, drop=drop, overwrite=True,
+                                   dkv_bf16=True)
+    assert dk3.dtype == torch.bfloat16 and torch.equal(dk3, dk2.to(torch.bfloat16)) and torch.equal(dv3, dv2.to(torch.bfloat16))
     keep = 1.0
     if drop is not None:
         p_real = round(drop[2] * 65536) / 65536
@@ -658,3 +662,40 @@ def test_mha_bwd_bf16(ops, B, H, Q, L, masked, drop, kt, monkeypatch):
     assert max(e) < BF16_BWD_TOL, e
     # size-independent identities: sum_k dV = sum_q (P*keep)^T dO has column sums equal to ... checked in test_properties
     assert torch.isfinite(dq).all() and torch.isfinite(dk).all() and torch.isfinite(dv).all()
+
+
+def test_gemm_bf16_sources(ops):
+    """PETR_GEMM_A_BF16 / _B_BF16 / _R_BF16: operands already stored as bf16 (the activations a producing epilogue wrote with
+    PETR_GEMM_STORE_BF16, the bf16 dK / dV of the attention backward).  Bit-for-bit the same product as rounding the fp32
+    values on load (same rounding, same accumulation order): compared with the fp32-source run of the same kernel."""
+    from petr_amd import _C
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 1000, 384, 520                      # ragged rows, K % 8 == 0 but not % 32
+    A, Bm, r = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(M, N, generator=g)
+    for akc in (True, False):
+        for bkc in (True, False):
+            a32 = (A if akc else A.t().contiguous()).cuda()
+            b32 = (Bm if bkc else Bm.t().contiguous()).cuda()
+            base = dict(lda=K if akc else M, a_kcontig=int(akc), ldb=K if bkc else N, b_kcontig=int(bkc), ldc=N, M=M, N=N, K=K,
+                        alpha=1.0, nb0=1, nb1=1, r=r.cuda(), ldr=N)
+            ref = torch.empty(M, N, device='cuda')
+            ops.gemm_raw(a=a32, b=b32, c=ref, flags=_C.GEMM_BF16 | _C.GEMM_RELU_MASK, **base)
+            for fl, aa, bb in ((_C.GEMM_A_BF16, a32.bfloat16(), b32), (_C.GEMM_B_BF16, a32, b32.bfloat16()),
+                               (_C.GEMM_A_BF16 | _C.GEMM_B_BF16, a32.bfloat16(), b32.bfloat16())):
+                out = torch.empty(M, N, device='cuda')
+                ops.gemm_raw(a=aa, b=bb, c=out, flags=_C.GEMM_BF16 | _C.GEMM_RELU_MASK | fl, **base)
+                assert torch.equal(out, ref), (akc, bkc, fl)
+    # bf16 mask operand + bf16 store + weight-gradient form with the column sums of a bf16 A
+    base.pop('r'); base.pop('ldr')
+    out16 = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
+    ops.gemm_raw(a=a32, b=b32, c=out16, r=r.cuda().bfloat16(), ldr=N,
+                 flags=_C.GEMM_BF16 | _C.GEMM_RELU_MASK | _C.GEMM_R_BF16 | _C.GEMM_STORE_BF16, **base)
+    want = (_bf(A) @ _bf(Bm).T) * (r.bfloat16().double() > 0)
+    assert relerr(out16.float(), want) < 4e-3
+    dy, x = torch.randn(3000, 256, generator=g), torch.randn(3000, 192, generator=g)
+    dw, db = torch.zeros(256, 192, device='cuda'), torch.zeros(256, device='cuda')
+    ops.gemm_raw(a=dy.cuda().bfloat16(), lda=256, a_kcontig=0, b=x.cuda().bfloat16(), ldb=192, b_kcontig=0, c=dw, ldc=192, M=256,
+                 N=192, K=3000, split_k=7, a_colsum=db, flags=_C.GEMM_BF16 | _C.GEMM_ATOMIC | _C.GEMM_A_BF16 | _C.GEMM_B_BF16,
+                 alpha=1.0, nb0=1, nb1=1)
+    assert relerr(dw, _bf(dy).T @ _bf(x)) < 3e-5
+    assert relerr(db, _bf(dy).sum(0)) < 1e-5

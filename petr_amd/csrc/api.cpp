@@ -46,7 +46,7 @@ int petr_prof_open_record(int tag, void* stream) {
   if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
   const int i = g_prof.n++;
   g_prof.tag[i] = tag;
-  hipEventRecord(g_prof.ev[2 * i], (hipStream_t)stream);
+  (void)hipEventRecord(g_prof.ev[2 * i], (hipStream_t)stream);
   return i;
 }
 
@@ -62,13 +62,13 @@ int petr_prof_claim(int tag, hipEvent_t* start, hipEvent_t* stop) {
 }
 
 void petr_prof_close_record(int i, void* stream) {
-  if (i >= 0) hipEventRecord(g_prof.ev[2 * i + 1], (hipStream_t)stream);
+  if (i >= 0) (void)hipEventRecord(g_prof.ev[2 * i + 1], (hipStream_t)stream);
 }
 
 extern "C" int petr_prof_begin(int capacity) {
   PETR_CHECK(capacity > 0 && capacity <= (1 << 20), PETR_ERR_INVALID, "prof_begin: bad capacity");
   if (g_prof.cap < capacity) {
-    for (int i = 0; i < 2 * g_prof.cap; ++i) hipEventDestroy(g_prof.ev[i]);
+    for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
     delete[] g_prof.ev;
     delete[] g_prof.tag;
     g_prof.ev = new hipEvent_t[2 * capacity];
@@ -92,7 +92,7 @@ extern "C" int petr_prof_end(float* ms, int* tags, int cap, int* n_out) {
     hipError_t e = hipEventSynchronize(g_prof.ev[2 * i + 1]);
     PETR_CHECK(e == hipSuccess, PETR_ERR_LAUNCH, "prof_end: %s", hipGetErrorString(e));
     float t = 0.f;
-    hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+    (void)hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
     ms[i] = t;
     tags[i] = g_prof.tag[i];
   }

@@ -49,6 +49,14 @@ struct Lanes {
     (void)hipEventRecord(e, main);
     (void)hipStreamWaitEvent(ctx->side[i % ctx->n_side], e, 0);
   }
+  // side streams 0..n-1 start after everything enqueued on main so far: ONE event record on main (each record is a
+  // barrier packet in main's queue and costs it ~7 us on MI355X), n waits
+  void fork_first(int n) const {
+    if (!ctx) return;
+    hipEvent_t e = next();
+    (void)hipEventRecord(e, main);
+    for (int i = 0; i < n && i < ctx->n_side; ++i) (void)hipStreamWaitEvent(ctx->side[i], e, 0);
+  }
   // main continues after everything enqueued on side stream i so far
   void join(int i) const {
     if (!ctx) return;

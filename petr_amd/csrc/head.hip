@@ -266,8 +266,10 @@ struct WOff {
   long d_outs, d_xs, d_mempos, d_mem, d_hpe[2], d_e_slab, d_e, d_qe_h, d_posemb;
   // private gradient scratch (never reused inside one backward, so weight-gradient contractions can run on
   // side streams long after the critical path has moved on)
-  long s0_raw, s0_r2, s0_r1, s0_c2n, s0_c2, s0_c1n, s0_c1;
+  long s0_raw, s0_r2, s0_r1, s0_c2n, s0_c2, s0_c1n, s0_c1, s0_outs_c;
   struct LayerG { long d_z2, d_h, d_x2, d_z1, d_ao, d_x1, d_z0, d_ao_s, d_zd[3]; } lg[8];
+  // transposed copies of the decoder weights for the 900-row input-gradient contractions (see transpose_batch_kernel)
+  struct LayerT { long f2, f1, ca_out, ca_q, sa_out, sa_in; } wt[8];
   long total;
 };
 
@@ -387,6 +389,7 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
   W.s0_c2 = wb.add("s0_c2", d.R * C);
   W.s0_c1n = wb.add("s0_c1n", d.R * C);
   W.s0_c1 = wb.add("s0_c1", d.R * C);
+  W.s0_outs_c = wb.add("s0_outs_c", d.R * C);
   for (int l = 0; l < d.NL; ++l) {
     WOff::LayerG& g = W.lg[l];
     g.d_z2 = wb.add("g_d_z2", d.BQ * C);
@@ -399,11 +402,20 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
     g.d_ao_s = wb.add("g_d_ao_s", d.BQ * C);
     for (int i = 0; i < 3; ++i) g.d_zd[i] = wb.add("g_d_z_dropped", d.BQ * C);   // training mode only
   }
+  for (int l = 0; l < d.NL; ++l) {
+    WOff::LayerT& t = W.wt[l];
+    t.f2 = wb.add("wT_ffn2", (long)d.F * C);
+    t.f1 = wb.add("wT_ffn1", (long)C * d.F);
+    t.ca_out = wb.add("wT_ca_out", (long)C * C);
+    t.ca_q = wb.add("wT_ca_q", (long)C * C);
+    t.sa_out = wb.add("wT_sa_out", (long)C * C);
+    t.sa_in = wb.add("wT_sa_in", (long)C * 3 * C);
+  }
   W.d_mempos = wb.add("d_mempos", d.BL * C);
   W.d_mem = wb.add("d_mem", d.BL * C);
   W.d_hpe[0] = wb.add("d_hpe", d.BL * 4 * C);
   W.d_hpe[1] = wb.add("d_hpe", d.BL * 4 * C);
-  W.d_e_slab = wb.add("d_e_slab", (long)d.NL * d.BQ * C);
+  W.d_e_slab = wb.add("d_e_slab", (long)2 * d.NL * d.BQ * C);      // [2][NL][BQ, C]: cross-attention q rows, self-attention q/k rows
   W.d_e = wb.add("d_e", (long)d.Q * C);
   W.d_qe_h = wb.add("d_qe_h", (long)d.Q * C);
   W.d_posemb = wb.add("d_posemb", (long)d.Q * C * 3 / 2);
@@ -568,6 +580,44 @@ static int mha_b_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, l
   a.dkv_overwrite = 1;       // dK_l / dV_l are stored, not accumulated: the executor does not zero them in this mode
   a.dkv_bf16 = dkv16;        // ... and as bf16: the K/V-projection backward rounds them to bf16 anyway (PETR_GEMM_A_BF16)
   return petr_mha_bwd_bf16(&a, s);
+}
+
+// ---- transposed decoder weights for the backward ----
+// dx = dy W reads the nn.Linear weight W[N_out][K_in] along its rows: as the B operand of the contraction (k = n_out) it is
+// "K-major", which the 900-row kernels can only read with 4-byte loads (gemm.hip: the float4 fragment path needs
+// K-contiguous operands) - measured 19-22 us per 900 x 256 x 256 input gradient against 12 us for the same-sized forward.
+// One batched transposition per backward (36 matrices, ~35 MB read + written, on a side stream beside the branch
+// backward) turns every decoder-layer input gradient into a forward-shaped contraction.
+struct TrEntry { const float* src; float* dst; long ld; int rows, cols, tile0; };     // dst[c][r] = src[r * ld + c]
+struct TrBatch { int n; TrEntry e[48]; };
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const TrBatch b) {
+  __shared__ float tile[32][33];
+  int ei = 0;
+  while (ei + 1 < b.n && (int)blockIdx.x >= b.e[ei + 1].tile0) ++ei;
+  const TrEntry& e = b.e[ei];
+  const int t = blockIdx.x - e.tile0, tiles_c = (e.cols + 31) >> 5;
+  const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + ty + 8 * j, c = c0 + tx;
+    tile[ty + 8 * j][tx] = (r < e.rows && c < e.cols) ? e.src[(long)r * e.ld + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + 8 * j, r = r0 + tx;
+    if (r < e.rows && c < e.cols) e.dst[(long)c * e.rows + r] = tile[tx][ty + 8 * j];
+  }
+}
+// dx[M,K] = dy[M,N] @ w[N,K] through wT[K][N]: both operands K-contiguous, like a forward
+static petr_gemm_args lin_dgrad_t(const float* dy, const float* wT, float* dx, long M, int N, int K) {
+  petr_gemm_args g = gemm0();
+  g.a = dy; g.lda = N; g.a_kcontig = 1;
+  g.b = wT; g.ldb = N; g.b_kcontig = 1;
+  g.c = dx; g.ldc = K;
+  g.M = (int)M; g.N = K; g.K = N;
+  return g;
 }
 
 // bf16 mode stores the two 4C-wide position-embedding hiddens (relu outputs, the largest activations of the step) and their
@@ -1011,11 +1061,26 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   void* s = ln.m();
   // Weight-gradient contractions only feed d_params: they leave the critical path (the chain of input-gradient
   // kernels) and alternate over the side streams.  Every dy they read lives in private scratch (WOff::lg / s0_*).
-  int wg_rr = 0;
+  // Inside the box / decoder-layer stages they are only QUEUED and issued together at the end of the stage, behind one
+  // fork: an event record is a barrier packet in the main queue (~7 us of bubble each, measured in the kernel trace), and
+  // there would be one per contraction - seven per decoder layer.  (PETR_WGRAD_DEFER=0: fork per contraction.)
+  static const bool defer_env = env_on("PETR_WGRAD_DEFER");
+  static const bool dgrad_t = env_on("PETR_DGRAD_T");        // PETR_DGRAD_T=0: input gradients read W itself (K-major operand)
+  hipEvent_t ev_tr = nullptr;
+  int wg_rr = 0, n_pend = 0;
+  bool defer = false;
+  petr_gemm_args pend[24];
+  auto flush_wgrads = [&]() -> int {
+    if (!n_pend) return PETR_OK;
+    ln.fork_first(2);
+    for (int i = 0; i < n_pend; ++i) RUN(petr_gemm(&pend[i], ln.side(wg_rr++ & 1)));
+    n_pend = 0;
+    return PETR_OK;
+  };
   auto wgrad = [&](petr_gemm_args g) -> int {
-    const int lane = wg_rr++ & 1;
-    ln.fork(lane);
-    return petr_gemm(&g, ln.side(lane));
+    if (n_pend == 24) RUN(flush_wgrads());
+    pend[n_pend++] = g;
+    return defer ? PETR_OK : flush_wgrads();
   };
   // io->attn_bf16: the token-sized gradient contractions (K/V projections, position-embedding MLPs, input_proj,
   // PETRv2's feature-guided PE) and the cross-attention backward run on the bf16 matrix cores, like their forwards
@@ -1041,6 +1106,8 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   const int dkv_flag = dkv16 ? PETR_GEMM_A_BF16 : 0;
 
   for (int stage = stage_begin; stage < stage_end; ++stage) {
+    // (stage 0 always defers: its cls-branch gradients are produced on a side stream and only joined at the end)
+    defer = stage == 0 || (defer_env && stage <= d.NL);      // the final stage's token-sized weight gradients start as soon as they can
     if (stage == 0) {
       // clear every += / atomic target of this backward pass; in bf16 mode dK / dV of all layers (the bulk of the range:
       // 2 x 6 x L x 256 floats) are stored by petr_mha_bwd_bf16 and need no zero-fill
@@ -1053,6 +1120,34 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         e = hipMemsetAsync(Wm + W.zero_begin, 0, (size_t)(W.zero_end - W.zero_begin) * sizeof(float), ln.main);
       }
       PETR_CHECK(e == hipSuccess, PETR_ERR_LAUNCH, "head_bwd: memset failed: %s", hipGetErrorString(e));
+      // transposed decoder weights for the layer stages' input gradients: side stream 1, beside the branch backward
+      if (dgrad_t) {
+        TrBatch tb;
+        tb.n = 0;
+        int tiles = 0;
+        auto add = [&](const float* src, long dst_off, int rows, int cols) {
+          TrEntry& en = tb.e[tb.n++];
+          en.src = src; en.dst = Wm + dst_off; en.ld = cols; en.rows = rows; en.cols = cols; en.tile0 = tiles;
+          tiles += (int)(cdiv(rows, 32) * cdiv(cols, 32));
+        };
+        for (int l = 0; l < d.NL; ++l) {
+          const LayerP& lp = P.lay[l];
+          const WOff::LayerT& t = W.wt[l];
+          add(Pm + lp.f2_w, t.f2, C, d.F);
+          add(Pm + lp.f1_w, t.f1, d.F, C);
+          add(Pm + lp.ca_out_w, t.ca_out, C, C);
+          add(Pm + lp.ca_in_w, t.ca_q, C, C);            // q rows of the cross-attention in_proj
+          add(Pm + lp.sa_out_w, t.sa_out, C, C);
+          add(Pm + lp.sa_in_w, t.sa_in, 3 * C, C);
+        }
+        ln.fork(1);
+        hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)ln.side(1), tb);
+        PETR_LAUNCH_CHECK("transpose_batch");
+        if (ln.ctx) {
+          ev_tr = ln.next();
+          (void)hipEventRecord(ev_tr, (hipStream_t)ln.side(1));
+        }
+      }
       // ---- box epilogue + reg branch ----
       const int G = cfg->shared_branches ? 1 : d.NL;
       const long RG = d.R / G;
@@ -1121,32 +1216,36 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       RUN(wgrad(gw(lin_wgrad(d_r1, C, Wm + W.outs, C, Gp + P.reg_w[0], Gp + P.reg_b[0], RG, C, C), C, C)));
       g = gd(lin_dgrad(d_r1, Pm + P.reg_w[0], Wm + W.d_outs, RG, C, C), C, C, C);
       RUN(petr_gemm(&g, s));
-      // ---- cls branch ----
+      // ---- cls branch: independent of the reg branch until the post-norm, so it runs beside it on side stream 0 and
+      // leaves its input gradient in a buffer of its own (summed by the post-norm backward's prologue) ----
+      void* sc = ln.side(0);
+      ln.fork(0);
       RUN(wgrad(gw(lin_wgrad(gr->d_cls, d.ncls, Wm + W.c2n, C, Gp + P.cls_w[2], Gp + P.cls_b[2], RG, d.ncls, C), d.ncls, C)));
       float* d_c2n = Wm + W.s0_c2n;
       g = gd(lin_dgrad(gr->d_cls, Pm + P.cls_w[2], d_c2n, RG, d.ncls, C), d.ncls, C, C);
-      RUN(petr_gemm(&g, s));
+      RUN(petr_gemm(&g, sc));
       float* d_c2 = Wm + W.s0_c2;
       for (int gi = 0; gi < G; ++gi)
         RUN(ln_bwd(Wm + W.c2 + gi * RG * C, Wm + W.c2_mean + gi * RG, Wm + W.c2_rstd + gi * RG, Pm + P.cls_g[1] + gi * P.br_stride,
                    d_c2n + gi * RG * C, Wm + W.c2n + gi * RG * C, d_c2 + gi * RG * C, Gp + P.cls_g[1] + gi * P.br_stride,
-                   Gp + P.cls_be[1] + gi * P.br_stride, RG, C, PETR_LN_RELU, 0, s));
+                   Gp + P.cls_be[1] + gi * P.br_stride, RG, C, PETR_LN_RELU, 0, sc));
       RUN(wgrad(gw(lin_wgrad(d_c2, C, Wm + W.c1n, C, Gp + P.cls_w[1], Gp + P.cls_b[1], RG, C, C), C, C)));
       float* d_c1n = Wm + W.s0_c1n;
       g = gd(lin_dgrad(d_c2, Pm + P.cls_w[1], d_c1n, RG, C, C), C, C, C);
-      RUN(petr_gemm(&g, s));
+      RUN(petr_gemm(&g, sc));
       float* d_c1 = Wm + W.s0_c1;
       for (int gi = 0; gi < G; ++gi)
         RUN(ln_bwd(Wm + W.c1 + gi * RG * C, Wm + W.c1_mean + gi * RG, Wm + W.c1_rstd + gi * RG, Pm + P.cls_g[0] + gi * P.br_stride,
                    d_c1n + gi * RG * C, Wm + W.c1n + gi * RG * C, d_c1 + gi * RG * C, Gp + P.cls_g[0] + gi * P.br_stride,
-                   Gp + P.cls_be[0] + gi * P.br_stride, RG, C, PETR_LN_RELU, 0, s));
+                   Gp + P.cls_be[0] + gi * P.br_stride, RG, C, PETR_LN_RELU, 0, sc));
       RUN(wgrad(gw(lin_wgrad(d_c1, C, Wm + W.outs, C, Gp + P.cls_w[0], Gp + P.cls_b[0], RG, C, C), C, C)));
-      g = gd(lin_dgrad(d_c1, Pm + P.cls_w[0], Wm + W.d_outs, RG, C, C), C, C, C);
-      g.flags = PETR_GEMM_ACCUMULATE;
-      RUN(petr_gemm(&g, s));
+      g = gd(lin_dgrad(d_c1, Pm + P.cls_w[0], Wm + W.s0_outs_c, RG, C, C), C, C, C);
+      RUN(petr_gemm(&g, sc));
+      ln.join(0);
       // ---- post_norm over all levels -> d_xs[l] ----
       RUN(ln_bwd(Wm + W.xs, Wm + W.mean_p, Wm + W.rstd_p, Pm + P.post_g, Wm + W.d_outs, nullptr, Wm + W.d_xs, Gp + P.post_g,
-                 Gp + P.post_b, d.R, C, 0, 0, s));
+                 Gp + P.post_b, d.R, C, 0, 0, s, 1, 0, Wm + W.s0_outs_c));
+      if (ev_tr) (void)hipStreamWaitEvent(ln.main, ev_tr, 0);      // the layer stages read the transposed weights
     } else if (stage <= d.NL) {
       const int l = d.NL - stage;
       const LayerP& lp = P.lay[l];
@@ -1166,7 +1265,8 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
                  d.BQ, C, 0, 0, s, 1, 0, nullptr, training ? d_f2 : nullptr, &dr[5]));
       RUN(wgrad(lin_wgrad(d_f2, C, Wm + lw.hff, d.F, Gp + lp.f2_w, Gp + lp.f2_b, d.BQ, C, d.F)));
       float* d_h = Wm + lg.d_h;                                 // [BQ, F]
-      petr_gemm_args g = lin_dgrad(d_f2, Pm + lp.f2_w, d_h, d.BQ, C, d.F);
+      const WOff::LayerT& wt = W.wt[l];
+      petr_gemm_args g = dgrad_t ? lin_dgrad_t(d_f2, Wm + wt.f2, d_h, d.BQ, C, d.F) : lin_dgrad(d_f2, Pm + lp.f2_w, d_h, d.BQ, C, d.F);
       // stored hidden = relu(.) * keep/(1-p): (hidden > 0) is relu-mask AND keep; the 1/(1-p) rides on alpha
       g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + lw.hff; g.ldr = d.F;
       if (training) g.alpha = hidden_drop_scale(dr[4]);
@@ -1176,7 +1276,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // contraction is split over K into slabs that the LayerNorm backward sums in its prologue
       float* d_x2 = Wm + lg.d_x2;
       const int sk = W.ffn_split;
-      g = lin_dgrad(d_h, Pm + lp.f1_w, d_x2, d.BQ, d.F, C);
+      g = dgrad_t ? lin_dgrad_t(d_h, Wm + wt.f1, d_x2, d.BQ, d.F, C) : lin_dgrad(d_h, Pm + lp.f1_w, d_x2, d.BQ, d.F, C);
       if (sk > 1) { g.split_k = sk; g.c_split_stride = d.BQ * C; }
       else { g.r = d_z2; g.ldr = C; }
       RUN(petr_gemm(&g, s));
@@ -1187,7 +1287,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
                  Gp + lp.n_b[1], d.BQ, C, 0, 0, s, sk, d.BQ * C, sk > 1 ? d_z2 : nullptr, training ? d_f1 : nullptr, &dr[3]));
       RUN(wgrad(lin_wgrad(d_f1, C, Wm + lw.ao_c, C, Gp + lp.ca_out_w, Gp + lp.ca_out_b, d.BQ, C, C)));
       float* d_ao = Wm + lg.d_ao;
-      g = lin_dgrad(d_f1, Pm + lp.ca_out_w, d_ao, d.BQ, C, C);
+      g = dgrad_t ? lin_dgrad_t(d_f1, Wm + wt.ca_out, d_ao, d.BQ, C, C) : lin_dgrad(d_f1, Pm + lp.ca_out_w, d_ao, d.BQ, C, C);
       RUN(petr_gemm(&g, s));
       float* d_qc = Wm + W.d_qc + (long)l * d.BQ * C;
       if (bf16)
@@ -1232,8 +1332,13 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       }
       // q projection of the cross-attention (rows 0..C of in_proj): weight grads live in the final block
       RUN(wgrad(lin_wgrad(d_qc, C, Wm + lw.xe1, C, Gp + lp.ca_in_w, Gp + lp.ca_in_b, d.BQ, C, C)));
+      // query_pos gradient, this layer's share: d(q-proj input) of the cross-attention into slab [0][l].  It only feeds the
+      // query-embedding MLP in the final stage, so it rides with the weight gradients on the side streams instead of
+      // standing (NL + 1 launches, ~180 us at 900 queries) at the end of the critical chain.
+      RUN(wgrad(dgrad_t ? lin_dgrad_t(d_qc, Wm + wt.ca_q, Wm + W.d_e_slab + (long)l * d.BQ * C, d.BQ, C, C)
+                        : lin_dgrad(d_qc, Pm + lp.ca_in_w, Wm + W.d_e_slab + (long)l * d.BQ * C, d.BQ, C, C)));
       float* d_x1 = Wm + lg.d_x1;
-      g = lin_dgrad(d_qc, Pm + lp.ca_in_w, d_x1, d.BQ, C, C);
+      g = dgrad_t ? lin_dgrad_t(d_qc, Wm + wt.ca_q, d_x1, d.BQ, C, C) : lin_dgrad(d_qc, Pm + lp.ca_in_w, d_x1, d.BQ, C, C);
       g.r = d_z1; g.ldr = C;
       RUN(petr_gemm(&g, s));
       // LN0 / self-attention
@@ -1243,7 +1348,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
                  Gp + lp.n_b[0], d.BQ, C, 0, 0, s, 1, 0, nullptr, training ? d_f0 : nullptr, &dr[1]));
       RUN(wgrad(lin_wgrad(d_f0, C, Wm + lw.ao_s, C, Gp + lp.sa_out_w, Gp + lp.sa_out_b, d.BQ, C, C)));
       float* d_ao_s = Wm + lg.d_ao_s;
-      g = lin_dgrad(d_f0, Pm + lp.sa_out_w, d_ao_s, d.BQ, C, C);
+      g = dgrad_t ? lin_dgrad_t(d_f0, Wm + wt.sa_out, d_ao_s, d.BQ, C, C) : lin_dgrad(d_f0, Pm + lp.sa_out_w, d_ao_s, d.BQ, C, C);
       RUN(petr_gemm(&g, s));
       float* d_qkv = Wm + W.d_qkv + (long)l * d.BQ * 3 * C;
       RUN(mha_b(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
@@ -1251,12 +1356,19 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
                 training ? &dr[0] : nullptr));
       // in_proj: q,k rows see x + query_pos, v rows see x
       RUN(wgrad(lin_wgrad(d_qkv, 3 * C, Wm + lw.xe_in, C, Gp + lp.sa_in_w, Gp + lp.sa_in_b, d.BQ, 2 * C, C)));
+      {   // query_pos gradient through the self-attention q / k rows: slab [1][l]
+        float* slab = Wm + W.d_e_slab + (long)(d.NL + l) * d.BQ * C;
+        petr_gemm_args ge = dgrad_t ? lin_dgrad_t(d_qkv, Wm + wt.sa_in, slab, d.BQ, 2 * C, C) : lin_dgrad(d_qkv, Pm + lp.sa_in_w, slab, d.BQ, 2 * C, C);
+        ge.lda = 3 * C;
+        if (dgrad_t) ge.ldb = 3 * C;          // rows of the transposed [C][3C] in_proj; K = the first 2C columns
+        RUN(wgrad(ge));
+      }
       RUN(wgrad(lin_wgrad(d_qkv + 2 * C, 3 * C, x_in, C, Gp + lp.sa_in_w + (long)2 * C * C, Gp + lp.sa_in_b + 2 * C, d.BQ, C,
                           C)));
       if (l > 0) {
         // d(x_in) = d_z0 (identity) + d_qkv @ W_in, added to the post-norm gradient of level l-1
         float* dst = Wm + W.d_xs + (long)(l - 1) * d.BQ * C;
-        g = lin_dgrad(d_qkv, Pm + lp.sa_in_w, dst, d.BQ, 3 * C, C);
+        g = dgrad_t ? lin_dgrad_t(d_qkv, Wm + wt.sa_in, dst, d.BQ, 3 * C, C) : lin_dgrad(d_qkv, Pm + lp.sa_in_w, dst, d.BQ, 3 * C, C);
         g.flags = PETR_GEMM_ACCUMULATE;
         g.r = d_z0; g.ldr = C;                                   // identity path folded into the same epilogue
         RUN(petr_gemm(&g, s));
@@ -1264,9 +1376,11 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
     } else {
       // ================= final stage =================
       const int V = d.B * d.N;
-      // the K/V projection backward of every layer ran on the side streams behind its layer (see there): wait for it
-      ln.join(0);
-      ln.join(1);
+      // (opt-in schedule) the K/V projection backward of every layer ran on the side streams behind its layer: wait for it
+      if (kv_overlap) {
+        ln.join(0);
+        ln.join(1);
+      }
       for (int kv = 0; kv < 2 && !kv_overlap; ++kv) {     // single-stream / opt-out schedule: all layers in one contraction each
         const float* dkv = dkv_ptr(kv, 0);
         const float* src = kv == 0 ? Wm + W.mempos : Wm + W.mem;
@@ -1355,22 +1469,13 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
           RUN(petr_gemm(&g, s));
         }
       }
-      // query_pos gradient: sum over layers and batch of d(q-proj inputs) (deferred from the layers)
+      // query_pos gradient: sum over layers and batch of the d(q-proj inputs) slabs the layer stages produced on the
+      // side streams
       {
-        petr_gemm_args g = gemm0();
-        g.a = Wm + W.d_qc; g.lda = C; g.a_kcontig = 1; g.a_bs0 = d.BQ * C;
-        g.b = Pm + P.lay[0].ca_in_w; g.ldb = C; g.b_kcontig = 0; g.b_bs0 = P.ca_in_stride;
-        g.c = Wm + W.d_e_slab; g.ldc = C; g.c_bs0 = d.BQ * C;
-        g.M = (int)d.BQ; g.N = C; g.K = C; g.nb0 = d.NL;
-        RUN(petr_gemm(&g, s));
-        for (int l = 0; l < d.NL; ++l) {   // self-attention q,k rows (layer blocks are not uniformly strided by design)
-          g = lin_dgrad(Wm + W.d_qkv + (long)l * d.BQ * 3 * C, Pm + P.lay[l].sa_in_w, Wm + W.d_e_slab + (long)l * d.BQ * C,
-                        d.BQ, 2 * C, C);
-          g.lda = 3 * C;
-          g.flags = PETR_GEMM_ACCUMULATE;
-          RUN(petr_gemm(&g, s));
-        }
-        RUN(petr_reduce_batch(Wm + W.d_e_slab, d.NL * d.B, d.Q, C, Wm + W.d_e, 0, s));
+        petr_gemm_args g;
+        ln.join(0);
+        ln.join(1);
+        RUN(petr_reduce_batch(Wm + W.d_e_slab, 2 * d.NL * d.B, d.Q, C, Wm + W.d_e, 0, s));
         // query_embedding MLP + pos2posemb3d (petr_head.py:422-423)
         RUN(wgrad(lin_wgrad(Wm + W.d_e, C, Wm + W.qe_h, C, Gp + P.qe_w2, Gp + P.qe_b2, d.Q, C, C)));
         g = lin_dgrad(Wm + W.d_e, Pm + P.qe_w2, Wm + W.d_qe_h, d.Q, C, C);
@@ -1383,6 +1488,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         RUN(petr_axpy(Gp + P.ref, Wm + W.d_ref_tmp, 1.f, (long)d.Q * 3, s));
       }
     }
+    RUN(flush_wgrads());     // the stage's queued weight gradients: one fork, alternating side streams
   }
   // The caller's stream is made to wait for the side streams only when the LAST stage has been enqueued.  After an
   // earlier stage range the weight gradients of those stages may still be running on the side streams: whoever

@@ -112,6 +112,32 @@ class _HeadFn(torch.autograd.Function):
         return None, d_feats, None, None
 
 
+class _PinnedRing:
+    """Asynchronous host -> device upload of a small per-call array (img2lidar, the padding mask).
+
+    A copy from pageable memory blocks the host until everything queued on the stream before it has run - the whole
+    previous training step - so the device idles at every step boundary while the host catches up (~130 us per step on
+    MI355X, measured in the kernel trace).  The array goes through a ring of page-locked buffers instead; a slot is reused
+    only after the copy that read it has completed (its event), which with four slots never waits in practice."""
+
+    def __init__(self, shape, dtype, device, slots=4):
+        self.device = device
+        self.bufs = [torch.empty(shape, dtype=dtype).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.i = 0
+
+    def upload(self, arr):
+        i, self.i = self.i, (self.i + 1) % len(self.bufs)
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        self.bufs[i].numpy()[...] = arr
+        out = self.bufs[i].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.events[i] = ev
+        return out
+
+
 class _Run:
     """Everything one forward needs to keep alive until its backward: workspace, outputs, host inputs."""
     __slots__ = ('cfg', 'io', 'ws', 'feats', 'img2lidar', 'mask', 'cls', 'bbox', 'key', 'time_div', 'consumed')
@@ -186,6 +212,7 @@ class PETRHead(nn.Module):
         self._layout = None
         self._runs = {}
         self._free_ws = {}
+        self._rings = {}
         self._anchor = None
         self._ctx = None
 
@@ -377,9 +404,18 @@ class PETRHead(nn.Module):
         # img2lidar: float64 inverse per view on the host, as the reference (petr_head.py:308-315)
         l2i = np.asarray([[np.asarray(m) for m in meta['lidar2img']] for meta in img_metas], dtype=np.float64)
         i2l = np.linalg.inv(l2i).astype(np.float32).reshape(B * N, 16)
-        run.img2lidar = torch.from_numpy(i2l).to(feats.device, non_blocking=True)
-        run.mask = torch.from_numpy(mask_np).to(feats.device, non_blocking=True) if has_mask else None
+        run.img2lidar = self._upload('img2lidar', i2l, feats.device)
+        run.mask = self._upload('mask', mask_np, feats.device) if has_mask else None
         return run
+
+    def _upload(self, name, arr, device):
+        arr = np.ascontiguousarray(arr)
+        key = (name, arr.shape, arr.dtype.str, device)
+        ring = self._rings.get(key)
+        if ring is None:
+            ring = self._rings[key] = _PinnedRing(arr.shape, torch.from_numpy(arr).dtype, device)
+        with torch.cuda.device(device):
+            return ring.upload(arr)
 
     def _context(self):
         """side streams for the work off the critical path (petr_ctx); PETR_AMD_SIDE_STREAMS=0 serialises."""
@@ -400,7 +436,7 @@ class PETRHead(nn.Module):
         for k in ('_ctx', '_last_run', '_stage_hook', '_stage_hook_stages'):
             st.pop(k, None)
         st['_ctx'] = None
-        st['_runs'], st['_free_ws'] = {}, {}
+        st['_runs'], st['_free_ws'], st['_rings'] = {}, {}, {}
         st['_flat'] = st['_flat_grad'] = st['_layout'] = st['_anchor'] = None      # re-flattened lazily on first use
         st.pop('_grad_views', None)
         return st

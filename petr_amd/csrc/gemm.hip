@@ -906,7 +906,9 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
                         !(g.flags & (PETR_GEMM_ACCUMULATE | PETR_GEMM_ATOMIC | PETR_GEMM_RELU_MASK | PETR_GEMM_SIGMOID_MUL |
                                      PETR_GEMM_A_BF16 | PETR_GEMM_B_BF16 | PETR_GEMM_R_BF16)) && vec &&
                         (!g.a_kcontig || !(g.lda & 3)) && !(g.ldb & 3) && (g.a_kcontig || staged);
-    if (simple) return launch_bf16(g, s);
+    // PETR_GEMM16_SIMPLE=0: everything through gemm_bf16.hip (same-box A/B of the two families)
+    static const bool simple_on = !(getenv("PETR_GEMM16_SIMPLE") && atoi(getenv("PETR_GEMM16_SIMPLE")) == 0);
+    if (simple && (simple_on || g.a2)) return launch_bf16(g, s);
     return petr_gemm_bf16_general(g, s);
   }
   PETR_CHECK(!((g.flags & PETR_GEMM_BIAS_M) && (g.flags & PETR_GEMM_BF16)), PETR_ERR_UNSUPPORTED,

@@ -82,6 +82,7 @@ struct Stage16 {
     }
   }
   // round to bf16 and write the [row][k] image; `ragged`: the tile crosses the operand's row or K bound (uniform)
+  template <int PITCH = GB_PITCH>
   __device__ __forceinline__ void store(uint16_t* img, bool ragged, int k0, int kend) {
     const int t = threadIdx.x & 255;
     if (KC) {
@@ -96,7 +97,7 @@ struct Stage16 {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<uint2*>(img + ((t >> 3) + 32 * i) * GB_PITCH + 4 * (t & 7)) =
+        *reinterpret_cast<uint2*>(img + ((t >> 3) + 32 * i) * PITCH + 4 * (t & 7)) =
             pack4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
     } else {
       if (ragged) {
@@ -104,7 +105,7 @@ struct Stage16 {
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = (rowok && kb + e < kend) ? v[e] : 0.f;
       }
-      uint4* d = reinterpret_cast<uint4*>(img + (t & 127) * GB_PITCH + 16 * (t >> 7));
+      uint4* d = reinterpret_cast<uint4*>(img + (t & 127) * PITCH + 16 * (t >> 7));
       const uint2 p0 = pack4(v[0], v[1], v[2], v[3]), p1 = pack4(v[4], v[5], v[6], v[7]);
       const uint2 p2 = pack4(v[8], v[9], v[10], v[11]), p3 = pack4(v[12], v[13], v[14], v[15]);
       d[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
@@ -158,6 +159,7 @@ struct Stage16B {
       x[1] = make_uint4(e16[8] | (e16[9] << 16), e16[10] | (e16[11] << 16), e16[12] | (e16[13] << 16), e16[14] | (e16[15] << 16));
     }
   }
+  template <int PITCH = GB_PITCH>
   __device__ __forceinline__ void store(uint16_t* img, bool ragged, int k0, int kend) {
     const int t = threadIdx.x & 255;
     if (KC) {
@@ -166,7 +168,7 @@ struct Stage16B {
         const int pc = t + 256 * i;
         uint4 v = x[i];
         if (ragged && !(((rowok >> i) & 1u) && k0 + 8 * (pc & 3) < kend)) v = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(img + (pc >> 2) * GB_PITCH + 8 * (pc & 3)) = v;
+        *reinterpret_cast<uint4*>(img + (pc >> 2) * PITCH + 8 * (pc & 3)) = v;
       }
     } else {
       uint4 a = x[0], b = x[1];
@@ -182,7 +184,7 @@ struct Stage16B {
         a = make_uint4(w[0], w[1], w[2], w[3]);
         b = make_uint4(w[4], w[5], w[6], w[7]);
       }
-      uint4* d = reinterpret_cast<uint4*>(img + (t & 127) * GB_PITCH + 16 * (t >> 7));
+      uint4* d = reinterpret_cast<uint4*>(img + (t & 127) * PITCH + 16 * (t >> 7));
       d[0] = a;
       d[1] = b;
     }
@@ -209,11 +211,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_gen_kernel(const petr_gemm_a
   __shared__ __attribute__((aligned(16))) uint16_t lds[2][(GB_BM + GB_BN) * GB_PITCH];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int h = lane >> 5, c = lane & 31;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  // 1-D grid, (batch, K slice) index fastest: the workgroups that share an operand panel (the same activation rows for
+  // every layer's weights, the same K slice of the input for every layer's weight gradient) run side by side on one XCD
+  // and find it in that XCD's L2
+  const int zn = g.nb0 * g.nb1 * g.split_k;
+  const int lin = xcd_remap(blockIdx.x, tiles_m * tiles_n * zn);
+  const int tile = lin / zn;
   const int tm_i = tile / tiles_n, tn_i = tile - tm_i * tiles_n;
   const int m0 = tm_i * GB_BM, n0 = tn_i * GB_BN;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  int z = blockIdx.z;
+  int z = lin - tile * zn;
   const int ks = z % g.split_k;
   z /= g.split_k;
   const int z1 = z % g.nb1, z0 = z / g.nb1;
@@ -352,107 +359,63 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_gen_kernel(const petr_gemm_a
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Producer / consumer version of the kernel above (same tiles, same LDS images, same epilogue): 8 waves per workgroup,
-// waves 0..3 multiply (64 x 64 outputs each), waves 4..7 only move operands: global memory -> registers -> bf16 LDS image,
-// with THREE tiles in flight in their registers.  Why: the one-tile register prefetch above leaves every K step waiting
-// for one exposed memory latency (~2.4 us per step per workgroup measured on the K/V projections, 0.21 us of MFMA work),
-// and a deeper ring in the multiplying waves does not fit beside 64 accumulator registers; loader waves hold no
-// accumulators, so three stages (96 registers) fit, and the multiplying waves never wait for global memory at all.
-// The ring is unrolled by hand (three named stages) and its loads are unconditional from clamped tile indices so that
-// hipcc keeps counted vmcnt waits.
+// Deep-step version of the kernel above: K step 128 instead of 32, the whole step of both operands in flight at once.
+//
+// Why: the token-sized contractions of the bf16 step have SHORT contractions (K = 192 .. 384 for the 1x1 convolutions and
+// the K/V projections, 1024 / 1536 for two of them) over 12 000 .. 24 000 rows.  With K steps of 32 a workgroup spent
+// ~2.4 us per step waiting for one memory round trip and 0.2 us multiplying (measured on the K/V projections): eight
+// exposed latencies per 128 x 128 tile, 270 TFLOP/s and 1.4 TB/s on a kernel whose HBM floor is 5x lower.  Here one step
+// carries 4x the bytes (the same per-thread staging pattern, four 32-k groups issued back to back before anything waits),
+// so a K = 256 tile pays two round trips; the LDS image [256 rows][128 k] bf16 (pitch 136: conflict-free 16-byte fragment
+// reads) is single-buffered - 68 KB, two workgroups per CU - and the next step's loads are issued before the products of
+// the current one.
+// Epilogue through LDS: the accumulators go to a [128][132] fp32 image (the operand image is free by then), each wave reads
+// its own 64 x 64 block back row-wise and applies bias / residual / mask / activation on float4s: 16-byte loads of the
+// residual or mask operand and 16-byte (fp32) or 8-byte (bf16) stores instead of 64 two- or four-byte ones per lane.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(512) void gemm_bf16_pc_kernel(const petr_gemm_args g, const int tiles_m, const int tiles_n) {
-  __shared__ __attribute__((aligned(16))) uint16_t lds[2][(GB_BM + GB_BN) * GB_PITCH];
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+constexpr int GD_BK = 128, GD_PITCH = 136, GD_CP = 132;
+constexpr size_t GD_LDS_BYTES = (size_t)(GB_BM + GB_BN) * GD_PITCH * 2;      // 69 632 >= 128 * 132 * 4 = 67 584
+
+template <bool AKC, bool BKC, bool A16, bool B16>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_deep_kernel(const petr_gemm_args g, const int tiles_m, const int tiles_n,
+                                                                const int vec_epi) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t dlds[];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int h = lane >> 5, c = lane & 31;
+  // 1-D grid, (batch, K slice) index fastest: the workgroups that share an operand panel (the same activation rows for
+  // every layer's weights, the same K slice of the input for every layer's weight gradient) run side by side on one XCD
+  // and find it in that XCD's L2
+  const int zn = g.nb0 * g.nb1 * g.split_k;
+  const int lin = xcd_remap(blockIdx.x, tiles_m * tiles_n * zn);
+  const int tile = lin / zn;
   const int tm_i = tile / tiles_n, tn_i = tile - tm_i * tiles_n;
   const int m0 = tm_i * GB_BM, n0 = tn_i * GB_BN;
-  int z = blockIdx.z;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  int z = lin - tile * zn;
   const int ks = z % g.split_k;
   z /= g.split_k;
   const int z1 = z % g.nb1, z0 = z / g.nb1;
+  constexpr int AE = A16 ? 2 : 4, BE = B16 ? 2 : 4;
+  const char* Ab = reinterpret_cast<const char*>(g.a) + (z0 * g.a_bs0 + z1 * g.a_bs1) * AE;
+  const char* Bb = reinterpret_cast<const char*>(g.b) + (z0 * g.b_bs0 + z1 * g.b_bs1) * BE;
+
   const int kseg = g.k_seg > 0 ? g.k_seg : g.K;
   const int nseg = g.k_seg > 0 ? g.K / g.k_seg : 1;
-  const int tps = (kseg + GB_BK - 1) / GB_BK;
+  const int tps = (kseg + GD_BK - 1) / GD_BK;
   const int ktiles = nseg * tps;
   const int kt_per = (ktiles + g.split_k - 1) / g.split_k;
   const int kt_begin = ks * kt_per;
   const int kt_end = min(ktiles, kt_begin + kt_per);
-  const int nk = kt_end - kt_begin;
-  const bool loader = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4;      // wave-uniform, provably
 
-  if (loader) {
-    // ---------------- operand movers: thread u = threadIdx.x - 256 plays the staging role of the kernel above ----------------
-    const float* Ab = g.a + z0 * g.a_bs0 + z1 * g.a_bs1;
-    const float* Bb = g.b + z0 * g.b_bs0 + z1 * g.b_bs1;
-    Stage16<AKC> sa[3];
-    Stage16<BKC> sb[3];
+  typename StageSel<AKC, A16>::type sa[4];
+  typename StageSel<BKC, B16>::type sb[4];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      sa[i].init(g.lda, m0, g.M);
-      sb[i].init(g.ldb, n0, g.N);
-    }
-    const bool rows_ragged_a = m0 + GB_BM > g.M, rows_ragged_b = n0 + GB_BN > g.N;
-    const bool do_colsum = g.a_colsum != nullptr && tn_i == 0;
-    float colacc = 0.f;
-    const int u = threadIdx.x - 256;
-    auto gload = [&](int i_tile, Stage16<AKC>& ra, Stage16<BKC>& rb) {       // i_tile: index inside this K slice, clamped
-      const int kt = kt_begin + min(i_tile, max(nk - 1, 0));
-      const int seg = kt / tps;
-      const int k0 = (kt - seg * tps) * GB_BK;
-      ra.load(Ab + (long)seg * g.a_seg_stride, g.lda, k0, kseg);
-      rb.load(Bb + (long)seg * g.b_seg_stride, g.ldb, k0, kseg);
-    };
-    auto lstore = [&](int i_tile, Stage16<AKC>& ra, Stage16<BKC>& rb) {
-      const int kt = kt_begin + i_tile;
-      const int seg = kt / tps;
-      const int k0 = (kt - seg * tps) * GB_BK;
-      const bool kr = k0 + GB_BK > kseg;
-      if (!AKC && do_colsum) {
-        const int kb = k0 + 16 * (u >> 7);
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s += (kb + e < kseg) ? ra.v[e] : 0.f;
-        colacc += s;
-      }
-      uint16_t* img = lds[i_tile & 1];
-      ra.store(img, rows_ragged_a || kr, k0, kseg);
-      rb.store(img + GB_BM * GB_PITCH, rows_ragged_b || kr, k0, kseg);
-    };
-    if (nk > 0) {
-      gload(0, sa[0], sb[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      gload(1, sa[1], sb[1]);
-      __builtin_amdgcn_sched_barrier(0);
-      gload(2, sa[2], sb[2]);
-      __builtin_amdgcn_sched_barrier(0);
-      lstore(0, sa[0], sb[0]);
-      gload(3, sa[0], sb[0]);
-    }
-    // iteration `it`: the multiplying waves read image it & 1; tile it+1 goes from its stage into the other image and the
-    // stage is re-issued for tile it+4.  Stage of tile j = j % 3.
-    auto step = [&](int it, Stage16<AKC>& ra, Stage16<BKC>& rb) -> bool {
-      __syncthreads();
-      if (it + 1 < nk) lstore(it + 1, ra, rb);
-      gload(it + 4, ra, rb);
-      return it + 1 >= nk;
-    };
-    if (nk > 0) {
-      for (int it = 0;; it += 3) {
-        if (step(it, sa[1], sb[1])) break;
-        if (step(it + 1, sa[2], sb[2])) break;
-        if (step(it + 2, sa[0], sb[0])) break;
-      }
-    }
-    if (!AKC && do_colsum && m0 + (u & 127) < g.M)
-      atomicAdd(g.a_colsum + z0 * g.cs_bs0 + z1 * g.cs_bs1 + m0 + (u & 127), colacc);
-    return;
+  for (int q = 0; q < 4; ++q) {         // identical loop-invariant addressing: one copy survives
+    sa[q].init(g.lda, m0, g.M);
+    sb[q].init(g.ldb, n0, g.N);
   }
+  const bool rows_ragged_a = m0 + GB_BM > g.M, rows_ragged_b = n0 + GB_BN > g.N;
 
-  // ---------------- multiplying waves ----------------
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int h = lane >> 5, c = lane & 31;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -460,32 +423,150 @@ __global__ __launch_bounds__(512) void gemm_bf16_pc_kernel(const petr_gemm_args 
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  for (int it = 0; it < nk; ++it) {
-    __syncthreads();                       // image it & 1 complete (written one iteration ago by the movers)
-    const uint16_t* As = lds[it & 1];
-    const uint16_t* Bs = As + GB_BM * GB_PITCH;
+
+  const bool do_colsum = g.a_colsum != nullptr && tn_i == 0;    // host guarantees a K-major A with a_colsum
+  float colacc = 0.f;
+
+  uint16_t* As = dlds;
+  uint16_t* Bs = dlds + GB_BM * GD_PITCH;
+  int k0_cur = 0, k0_nxt = 0;
+  auto gload = [&](int kt, int& k0_out) {
+    const int seg = kt / tps;
+    const int k0 = (kt - seg * tps) * GD_BK;
+    k0_out = k0;
+    const float* ab = reinterpret_cast<const float*>(Ab + (long)seg * g.a_seg_stride * AE);
+    const float* bb = reinterpret_cast<const float*>(Bb + (long)seg * g.b_seg_stride * BE);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      uint4 fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = *reinterpret_cast<const uint4*>(As + (wm + 32 * i + c) * GB_PITCH + 16 * j + 8 * h);
-        fb[i] = *reinterpret_cast<const uint4*>(Bs + (wn + 32 * i + c) * GB_PITCH + 16 * j + 8 * h);
+    for (int q = 0; q < 4; ++q)
+      if (k0 + 32 * q < kseg) {           // uniform: 32-k groups beyond the segment are neither loaded nor multiplied
+        sa[q].load(ab, g.lda, k0 + 32 * q, kseg);
+        sb[q].load(bb, g.ldb, k0 + 32 * q, kseg);
       }
+  };
+  auto lstore = [&](int k0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int q = 0; q < 4; ++q) {
+      const int kq = k0 + 32 * q;
+      if (kq < kseg) {
+        const bool kr = kq + 32 > kseg;
+        if (!AKC && do_colsum) {
+          if constexpr (A16) {
+            colacc += sa[q].ksum(kq, kseg);
+          } else {
+            const int kb = kq + 16 * (t >> 7);
+            float sum = 0.f;
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, fa[i]),
-                                                               __builtin_bit_cast(hbf16x8, fb[jn]), acc[i][jn], 0, 0, 0);
+            for (int e = 0; e < 16; ++e) sum += (kb + e < kseg) ? sa[q].v[e] : 0.f;
+            colacc += sum;
+          }
+        }
+        sa[q].template store<GD_PITCH>(As + 32 * q, rows_ragged_a || kr, kq, kseg);
+        sb[q].template store<GD_PITCH>(Bs + 32 * q, rows_ragged_b || kr, kq, kseg);
+      }
+    }
+  };
+
+  const int nk = kt_end - kt_begin;
+  if (nk > 0) {
+    gload(kt_begin, k0_cur);
+    for (int it = 0; it < nk; ++it) {
+      if (it > 0) __syncthreads();           // every wave is done with the previous step's image
+      lstore(k0_cur);
+      __syncthreads();
+      const int chunks = min(GD_BK / 16, (kseg - k0_cur + 15) >> 4);
+      if (it + 1 < nk) {
+        gload(kt_begin + it + 1, k0_nxt);
+        k0_cur = k0_nxt;
+      }
+      for (int j = 0; j < chunks; ++j) {     // 16-deep chunks of the K step
+        uint4 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[i] = *reinterpret_cast<const uint4*>(As + (wm + 32 * i + c) * GD_PITCH + 16 * j + 8 * h);
+          fb[i] = *reinterpret_cast<const uint4*>(Bs + (wn + 32 * i + c) * GD_PITCH + 16 * j + 8 * h);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jn = 0; jn < 2; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, fa[i]),
+                                                                 __builtin_bit_cast(hbf16x8, fb[jn]), acc[i][jn], 0, 0, 0);
+      }
     }
   }
+
+  if (!AKC && do_colsum && m0 + (t & 127) < g.M)
+    atomicAdd(g.a_colsum + z0 * g.cs_bs0 + z1 * g.cs_bs1 + m0 + (t & 127), colacc);
+
+  // ---- epilogue ----
   const bool atomic = (g.flags & PETR_GEMM_ATOMIC) != 0;
-  const bool plain = g.split_k > 1 && !atomic;
-  float* C = g.c + z0 * g.c_bs0 + z1 * g.c_bs1 + (atomic ? 0 : (long)ks * g.c_split_stride);
+  const bool plain = g.split_k > 1 && !atomic;       // K slices store raw partial sums
+  const long cz = z0 * g.c_bs0 + z1 * g.c_bs1 + (atomic ? 0 : (long)ks * g.c_split_stride);
+  float* C = g.c + cz;
   const float* bias = (!plain && g.bias) ? g.bias + z0 * g.bias_bs0 + z1 * g.bias_bs1 : nullptr;
   const float* R = (!plain && g.r) ? g.r + z0 * g.r_bs0 + z1 * g.r_bs1 : nullptr;
   const int flags = plain ? 0 : g.flags;
+  if (vec_epi) {
+    float* Cs = reinterpret_cast<float*>(dlds);
+    __syncthreads();                         // the operand image is dead
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Cs[(wm + 32 * i + mfma32_row(r, h)) * GD_CP + wn + 32 * jn + c] = acc[i][jn][r];
+    // each wave reads back only what it wrote (its 64 x 64 block): LDS operations of one wave complete in order
+    const int col = wn + 4 * (lane & 15);
+    const int n = n0 + col;
+    if (n < g.N) {                           // N % 4 == 0: a float4 is entirely inside or outside
+      const long ccol = g.c_nblk > 0 ? (long)(n / g.c_nblk) * g.c_nblk_stride + (n % g.c_nblk) : (long)n;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+      const uint16_t* R16 = reinterpret_cast<const uint16_t*>(g.r) + z0 * g.r_bs0 + z1 * g.r_bs1;
+      uint16_t* C16 = reinterpret_cast<uint16_t*>(g.c) + cz;
+#pragma unroll 4
+      for (int rr = 0; rr < 16; ++rr) {
+        const int row = wm + 4 * rr + (lane >> 4);
+        const int m = m0 + row;
+        if (m >= g.M) continue;
+        const float4 a4 = *reinterpret_cast<const float4*>(Cs + row * GD_CP + col);
+        float v[4] = {a4.x * g.alpha + bv.x, a4.y * g.alpha + bv.y, a4.z * g.alpha + bv.z, a4.w * g.alpha + bv.w};
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (R) {
+          if (flags & PETR_GEMM_R_BF16) {
+            const uint2 u = *reinterpret_cast<const uint2*>(R16 + (long)m * g.ldr + n);
+            rv[0] = __uint_as_float(u.x << 16); rv[1] = __uint_as_float(u.x & 0xFFFF0000u);
+            rv[2] = __uint_as_float(u.y << 16); rv[3] = __uint_as_float(u.y & 0xFFFF0000u);
+          } else {
+            const float4 u = *reinterpret_cast<const float4*>(R + (long)m * g.ldr + n);
+            rv[0] = u.x; rv[1] = u.y; rv[2] = u.z; rv[3] = u.w;
+          }
+        }
+        float* dst = C + (long)m * g.ldc + ccol;
+        float old[4] = {0.f, 0.f, 0.f, 0.f};
+        if (flags & PETR_GEMM_ACCUMULATE) {
+          const float4 u = *reinterpret_cast<const float4*>(dst);
+          old[0] = u.x; old[1] = u.y; old[2] = u.z; old[3] = u.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (flags & PETR_GEMM_RELU_MASK) v[e] = rv[e] > 0.f ? v[e] : 0.f;
+          else v[e] += rv[e];
+          if (flags & PETR_GEMM_RELU) v[e] = fmaxf(v[e], 0.f);
+          v[e] += old[e];
+        }
+        if (flags & PETR_GEMM_STORE_BF16) {
+          *reinterpret_cast<uint2*>(C16 + (long)m * g.ldc + ccol) = pack4(v[0], v[1], v[2], v[3]);
+        } else if (atomic) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(dst + e, v[e]);
+        } else {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int jn = 0; jn < 2; ++jn) {
     const int n = n0 + wn + 32 * jn + c;
@@ -501,7 +582,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pc_kernel(const petr_gemm_args 
         const bool ok = m < g.M && n < g.N;
         float v = acc[i][jn][r] * g.alpha + bv;
         float* dst = C + (long)mc * g.ldc + ccol;
-        const float rv = R ? R[(long)mc * g.ldr + nc] : 0.f;
+        float rv = 0.f;
+        if (R) {
+          if (flags & PETR_GEMM_R_BF16)
+            rv = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(g.r)[z0 * g.r_bs0 + z1 * g.r_bs1 + (long)mc * g.ldr + nc] << 16);
+          else rv = R[(long)mc * g.ldr + nc];
+        }
         const float old = (flags & PETR_GEMM_ACCUMULATE) ? *dst : 0.f;
         if (flags & PETR_GEMM_RELU_MASK) v = rv > 0.f ? v : 0.f;
         else v += rv;
@@ -509,8 +595,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pc_kernel(const petr_gemm_args 
         v += old;
         if (ok) {
           if (flags & PETR_GEMM_STORE_BF16)
-            reinterpret_cast<uint16_t*>(g.c)[z0 * g.c_bs0 + z1 * g.c_bs1 + (long)mc * g.ldc + ccol] =
-                __builtin_bit_cast(uint16_t, (__bf16)v);
+            reinterpret_cast<uint16_t*>(g.c)[cz + (long)mc * g.ldc + ccol] = __builtin_bit_cast(uint16_t, (__bf16)v);
           else if (atomic) atomicAdd(dst, v);
           else *dst = v;
         }
@@ -536,29 +621,52 @@ int petr_gemm_bf16_general(const petr_gemm_args& g, hipStream_t s) {
                PETR_ERR_UNSUPPORTED,
                "gemm: PETR_GEMM_BF16 needs 16-byte aligned K-contiguous operands (K %% 4 == 0 for fp32, K %% 8 == 0 for bf16 sources)");
   }
-  PETR_CHECK(!((g.flags & (PETR_GEMM_A_BF16 | PETR_GEMM_B_BF16 | PETR_GEMM_R_BF16)) && (getenv("PETR_GEMM16_PC") && atoi(getenv("PETR_GEMM16_PC")))),
-             PETR_ERR_UNSUPPORTED, "gemm: the producer/consumer variant takes fp32 sources only");
   // 32-bit element offsets inside one batch / segment
   PETR_CHECK((long)(g.a_kcontig ? g.M : kseg) * g.lda + (g.a_kcontig ? kseg : g.M) < (1L << 31) &&
                  (long)(g.b_kcontig ? g.N : kseg) * g.ldb + (g.b_kcontig ? kseg : g.N) < (1L << 31),
              PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_BF16 operand batch/segment must span < 2^31 elements");
   const int tm = (int)cdiv(g.M, GB_BM), tn = (int)cdiv(g.N, GB_BN);
-  // opt-in (PETR_GEMM16_PC=1).  Measured and rejected as the default (scripts/gemm16_time.py, same box, L = 24 000):
-  // d_src dgrad 70 us (general) vs 93 us (producer/consumer), dW_kv 89 vs 130, pe2 dgrad 141 vs 243, pe2 wgrad 72 vs 101.
-  // These contractions move fp32 operands and already run at 4.5-6.5 TB/s of HBM traffic with two 4-wave workgroups per
-  // CU; one 8-wave workgroup per CU with four multiplying waves loses more than the deeper ring gains.
-  static const bool use_pc = getenv("PETR_GEMM16_PC") && atoi(getenv("PETR_GEMM16_PC")) != 0;
-  if (use_pc) {
-    dim3 grid2(tm * tn, 1, g.nb0 * g.nb1 * g.split_k), block2(512);
-    if (g.a_kcontig && g.b_kcontig) hipLaunchKernelGGL((gemm_bf16_pc_kernel<true, true>), grid2, block2, 0, s, g, tm, tn);
-    else if (g.a_kcontig) hipLaunchKernelGGL((gemm_bf16_pc_kernel<true, false>), grid2, block2, 0, s, g, tm, tn);
-    else if (g.b_kcontig) hipLaunchKernelGGL((gemm_bf16_pc_kernel<false, true>), grid2, block2, 0, s, g, tm, tn);
-    else hipLaunchKernelGGL((gemm_bf16_pc_kernel<false, false>), grid2, block2, 0, s, g, tm, tn);
-    PETR_LAUNCH_CHECK("gemm_bf16_pc");
+  const bool a16 = (g.flags & PETR_GEMM_A_BF16) != 0, b16 = (g.flags & PETR_GEMM_B_BF16) != 0;
+  // the deep-step kernel (K step 128, LDS epilogue) is the default; PETR_GEMM16_DEEP=0 selects the K-step-32 kernel
+  static const bool deep_on = !(getenv("PETR_GEMM16_DEEP") && atoi(getenv("PETR_GEMM16_DEEP")) == 0);
+  if (deep_on && g.split_k == 1) {      // K slices (weight gradients, long contractions): the double-buffered K-step-32 kernel
+    // vector epilogue: 4 consecutive columns per lane must be contiguous, 16-byte (fp32) / 8-byte (bf16) aligned
+    const bool st16 = (g.flags & PETR_GEMM_STORE_BF16) != 0, r16 = (g.flags & PETR_GEMM_R_BF16) != 0;
+    const uintptr_t cmask = st16 ? 7 : 15, rmask = r16 ? 7 : 15;
+    const bool slabs = g.split_k > 1 && !(g.flags & PETR_GEMM_ATOMIC);
+    const int vec_epi =
+        !(g.N & 3) && !(g.ldc & 3) && !(g.c_bs0 & 3) && !(g.c_bs1 & 3) && !((uintptr_t)g.c & cmask) &&
+        (!slabs || !(g.c_split_stride & 3)) && (g.c_nblk <= 0 || (!(g.c_nblk & 3) && !(g.c_nblk_stride & 3))) &&
+        (!g.bias || (aligned16(g.bias) && !(g.bias_bs0 & 3) && !(g.bias_bs1 & 3))) &&
+        (!g.r || (!(g.ldr & 3) && !(g.r_bs0 & 3) && !(g.r_bs1 & 3) && !((uintptr_t)g.r & rmask)));
+    dim3 grid(tm * tn * g.nb0 * g.nb1 * g.split_k), block(256);
+#define PETR_GD(AKC, BKC, A16, B16)                                                                                      \
+  do {                                                                                                                   \
+    auto kern = gemm_bf16_deep_kernel<AKC, BKC, A16, B16>;                                                               \
+    static bool attr_set = false;                                                                                        \
+    if (!attr_set) {                                                                                                     \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GD_LDS_BYTES);       \
+      attr_set = true;                                                                                                   \
+    }                                                                                                                    \
+    hipLaunchKernelGGL(kern, grid, block, GD_LDS_BYTES, s, g, tm, tn, vec_epi);                                          \
+  } while (0)
+#define PETR_GD2(AKC, BKC)                                  \
+  do {                                                      \
+    if (a16 && b16) PETR_GD(AKC, BKC, true, true);          \
+    else if (a16) PETR_GD(AKC, BKC, true, false);           \
+    else if (b16) PETR_GD(AKC, BKC, false, true);           \
+    else PETR_GD(AKC, BKC, false, false);                   \
+  } while (0)
+    if (g.a_kcontig && g.b_kcontig) PETR_GD2(true, true);
+    else if (g.a_kcontig) PETR_GD2(true, false);
+    else if (g.b_kcontig) PETR_GD2(false, true);
+    else PETR_GD2(false, false);
+#undef PETR_GD2
+#undef PETR_GD
+    PETR_LAUNCH_CHECK("gemm_bf16_deep");
     return PETR_OK;
   }
-  dim3 grid(tm * tn, 1, g.nb0 * g.nb1 * g.split_k), block(256);
-  const bool a16 = (g.flags & PETR_GEMM_A_BF16) != 0, b16 = (g.flags & PETR_GEMM_B_BF16) != 0;
+  dim3 grid(tm * tn * g.nb0 * g.nb1 * g.split_k), block(256);
 #define PETR_G16(AKC, BKC)                                                                                              \
   do {                                                                                                                  \
     if (a16 && b16) hipLaunchKernelGGL((gemm_bf16_gen_kernel<AKC, BKC, true, true>), grid, block, 0, s, g, tm, tn);     \

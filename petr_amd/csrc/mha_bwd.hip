@@ -34,6 +34,7 @@ struct MhaBwdParams {
   int nkb, q_splits, qtiles_per_split;
   int vec;             // q/do/k/v 16-byte loads legal
   DropDev drop;        // the forward's probability dropout (thr == 0: off)
+  int diag;            // TIMING-ONLY ablations (PETR_BWD32_DIAG; results are wrong when non-zero)
 };
 
 // DROP: the forward multiplied the probabilities by keep/(1-p) after the softmax, so with m = keep/(1-p)
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
       if (qt + 2 < qt_end) gload(qt + 2);
     }
 
+    if (p.diag & 4) continue;
     f32x16 dQp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dQp[r] = 0.f;
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
       for (int j = 0; j < 4; ++j) {
         const int idx = t + 256 * j;
         const float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
-        if (qt * 32 + (idx >> 5) < a.Q) atomicAdd(dq + dq_off[j], v * a.scale);
+        if (qt * 32 + (idx >> 5) < a.Q && !(p.diag & 1)) atomicAdd(dq + dq_off[j], v * a.scale);
       }
     }
   }
@@ -264,7 +266,9 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
         const float gk = red[wave][kr * P33 + d], gv = dSs[wave][kr * P33 + d];
         float* pk = dk + (long)kg * a.dk_rs + d;
         float* pv = dv + (long)kg * a.dv_rs + d;
-        if (use_atomic) {
+        if (p.diag & 2) {
+          if (gk == 123.456f) *pk = gv;
+        } else if (use_atomic) {
           atomicAdd(pk, gk);
           atomicAdd(pv, gv);
         } else {
@@ -324,6 +328,7 @@ extern "C" int petr_mha_bwd(const petr_mha_bwd_args* ap, void* stream) {
   PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "mha_bwd: dropout p=%g outside [0,1)", (double)a.drop.p);
   PETR_CHECK((long)a.B * a.H * a.Q < (1L << 32), PETR_ERR_UNSUPPORTED, "mha_bwd: dropout row index needs B*H*Q < 2^32");
   p.drop = make_drop(a.drop);
+  p.diag = getenv("PETR_BWD32_DIAG") ? atoi(getenv("PETR_BWD32_DIAG")) : 0;
   auto launch = [&](auto kern) { hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), 0, s, ev0, ev1, 0, p); };
   switch ((p.drop.thr ? 4 : 0) | (a.kpm ? 2 : 0) | (p.vec ? 1 : 0)) {
     case 0: launch(mha_bwd_kernel<false, false, false>); break;

@@ -357,6 +357,8 @@ int petr_gate_fwd(const float* x, const float* u, float* out, long n, void* stre
 int petr_gate_bwd(const float* dout, const float* x, const float* u, float* dx, float* du, long n, void* stream);
 /* out[m,:] = x[m,:] + e[m % e_rows,:]   (key + key_pos, petr_transformer.py:343-344) */
 int petr_add_rows(const float* x, const float* e, float* out, long M, int e_rows, int C, void* stream);
+/* the same sum with bf16 x and bf16 out (bf16 mode of the head: memory and key = memory + key_pos live as bf16) */
+int petr_add_rows_bf16(const uint16_t* x, const float* e, uint16_t* out, long M, int e_rows, int C, void* stream);
 int petr_fill(float* p, float v, long n, void* stream);
 int petr_axpy(float* y, const float* x, float alpha, long n, void* stream); /* y += alpha*x */
 /* out[m,:] = sum_p x[p*stride + m*C..] (+ bias) (+ residual); generic partial reducer */

@@ -221,6 +221,7 @@ def lib():
     L.petr_prof_begin.argtypes = [C.c_int]
     L.petr_prof_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
     L.petr_add_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]
+    L.petr_add_rows_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]
     L.petr_gate_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.petr_gate_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.petr_fill.argtypes = [C.c_void_p, C.c_float, C.c_long, C.c_void_p]
@@ -255,7 +256,7 @@ EXPORTS = [
     'petr_posemb3d_fwd', 'petr_posemb3d_bwd', 'petr_gemm', 'petr_colsum_workspace_bytes', 'petr_colsum',
     'petr_layernorm_fwd', 'petr_layernorm_bwd_workspace_bytes', 'petr_layernorm_bwd',
     'petr_mha_fwd_workspace_bytes', 'petr_mha_choose_split', 'petr_mha_fwd', 'petr_mha_fwd_bf16_workspace_bytes',
-    'petr_mha_fwd_bf16', 'petr_cast_bf16', 'petr_mha_bwd_workspace_bytes',
+    'petr_mha_fwd_bf16', 'petr_cast_bf16', 'petr_add_rows_bf16', 'petr_mha_bwd_workspace_bytes',
     'petr_mha_bwd', 'petr_mha_bwd_bf16_workspace_bytes', 'petr_mha_bwd_bf16', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows', 'petr_gate_fwd', 'petr_gate_bwd', 'petr_prof_begin', 'petr_prof_end',
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',

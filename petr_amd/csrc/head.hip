@@ -54,6 +54,8 @@ static int check_config(const petr_head_config* c) {
 }
 
 static long align4(long v) { return (v + 3) & ~3L; }
+// parameter slots start on multiples of 8 elements: 16-byte aligned in the fp32 buffer AND in its bf16 copy
+static long align8(long v) { return (v + 7) & ~7L; }
 
 // ---------------------------------------------------------------------------------------------
 // parameter layout
@@ -92,7 +94,7 @@ struct LayoutBuilder {
       out->alias_of[count] = alias_of;
     }
     ++count;
-    if (alias_of < 0) cur = align4(cur + n);
+    if (alias_of < 0) cur = align8(cur + n);
     return off;
   }
 };
@@ -171,7 +173,7 @@ static void build_layout(const petr_head_config* c, POff* P, petr_head_layout_t*
         snprintf(nm, sizeof nm, "reg_branches.%d.task_heads.%d.2.weight", lvl, t);
         o = lb.add(nm, 2, TH_DIMS[t], d.C);
         if (first && t == 0) P->th_w2 = o;
-        lb.cur = slot + align4((long)d.C * d.C) + align4(d.C) + align4(3L * d.C);   // pad to the widest head (3 rows)
+        lb.cur = slot + align8((long)d.C * d.C) + align8(d.C) + align8(3L * d.C);   // pad to the widest head (3 rows)
         snprintf(nm, sizeof nm, "reg_branches.%d.task_heads.%d.2.bias", lvl, t);
         o = lb.add(nm, 1, TH_DIMS[t]);
         if (first && t == 0) P->th_b2 = o;
@@ -251,7 +253,7 @@ struct LayerW {
   long qkv, ao_s, lse_s, z0, mean0, rstd0, x1, xe1, qc, ao_c, lse_c, z1, mean1, rstd1, x2, hff, z2, mean2, rstd2, xe_in;
 };
 struct WOff {
-  long posemb, qe_h, qe, vol, sine, mem, h1, h2, pos, mempos, k_all, v_all, x0;
+  long posemb, qe_h, qe, vol, sine, mem, h1, h2, pos, mempos, p16, k_all, v_all, x0;
   LayerW lay[8];
   long xs, mean_p, rstd_p, outs;
   long c1, c1_mean, c1_rstd, c1n, c2, c2_mean, c2_rstd, c2n, r1, r2, reg_raw;
@@ -300,6 +302,11 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
   W.h2 = wb.add("sine_hidden", d.BL * 4 * C);
   W.pos = wb.add("pos_embed", d.BL * C);
   W.mempos = wb.add("mempos", d.BL * C);
+  {   // bf16 copy of the flat parameter buffer (bf16 mode: the token-sized contractions read their weights from it)
+    POff Pl;
+    build_layout(c, &Pl, nullptr);
+    W.p16 = wb.add("params_bf16", (Pl.total + 1) / 2);
+  }
   W.k_all = wb.add("k_all", (long)d.B * d.NL * d.L * C);
   W.v_all = wb.add("v_all", (long)d.B * d.NL * d.L * C);
   // the attention tile-ticket counters (petr_mha_fwd_args.sched) sit right behind x0 so that the one fill that
@@ -628,6 +635,16 @@ static bool hidden_bf16(const petr_head_io* io) {
   static const bool on = env_on("PETR_HID16");       // PETR_HID16=0: fp32 storage (the same-box A/B switch)
   return io->attn_bf16 != 0 && on;
 }
+// bf16 mode keeps memory (input_proj's output) and key = memory + key_pos as bf16 and reads every token-sized
+// contraction's weights from a bf16 copy of the parameter buffer made once per forward: with 128-row tiles a
+// contraction re-reads its whole weight panel per tile, so at 24 000 tokens the K/V projections moved as many bytes of
+// (L2-resident) weights as of activations - halving both is what the deep-step kernel is bound by (PETR_TOK16=0: fp32)
+static bool token_bf16(const petr_head_config* c, const petr_head_io* io) {
+  static const bool on = env_on("PETR_TOK16");
+  // bf16-source K-contiguous operands are read in 16-byte pieces: every contraction length on the token side must be a
+  // multiple of 8 (3 D of the coordinate volume and the input channels can be anything in a toy configuration)
+  return io->attn_bf16 != 0 && on && (3 * c->depth_num) % 8 == 0 && c->C_in % 8 == 0 && c->embed_dims % 16 == 0;
+}
 static bool dkv_bf16(const petr_head_io* io) {       // dK / dV of the cross-attention stored as bf16 (PETR_DKV16=0: fp32)
   static const bool on = env_on("PETR_DKV16");
   return io->attn_bf16 != 0 && on;
@@ -751,6 +768,14 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   // backward: petr_mha_fwd_bf16 / petr_mha_bwd_bf16) reads them; query-sized work (900 rows) stays fp32
   const bool attn_bf16 = io->attn_bf16 != 0;
   const bool hid16 = hidden_bf16(io);
+  const bool tok16 = token_bf16(cfg, io);
+  uint16_t* p16 = reinterpret_cast<uint16_t*>(Wm + W.p16);
+  // weight at parameter offset `off`: the bf16 copy (element-indexed like the fp32 buffer) or the parameter itself
+  auto Wp = [&](long off) -> const float* { return tok16 ? reinterpret_cast<const float*>(p16 + off) : Pm + off; };
+  const int wflag = tok16 ? (PETR_GEMM_BF16 | PETR_GEMM_B_BF16) : 0;
+  uint16_t* mem16 = reinterpret_cast<uint16_t*>(Wm + W.mem);          // tok16: bf16 images in the front half of the
+  uint16_t* mempos16 = reinterpret_cast<uint16_t*>(Wm + W.mempos);    // fp32 buffers, same element indexing
+  if (tok16) RUN(petr_cast_bf16(Pm, p16, P.total, s));
   // bf16 mode: the 1x1 convolutions over NCHW maps take the K-major variant of the bf16 contraction where it applies
   auto bf16_km = [&](const petr_gemm_args& q) {
     return attn_bf16 && q.K % 32 == 0 && (long)q.M * q.N * (q.nb0 > 0 ? q.nb0 : 1) >= 128L * 128 * 64 && !(q.lda & 3) && !(q.ldb & 3);
@@ -775,7 +800,8 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     (void)hipEventRecord(*ev0, (hipStream_t)side);
     petr_gemm_args g1 = g;
     g1.nb1 = d.NL - 1;
-    g1.b = g.b + g.b_bs1;
+    g1.b = (g.flags & PETR_GEMM_B_BF16) ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(g.b) + g.b_bs1)
+                                        : g.b + g.b_bs1;
     g1.bias = g.bias + g.bias_bs1;
     g1.c = st16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(g.c) + g.c_bs1) : g.c + g.c_bs1;
     return petr_gemm(&g1, side);
@@ -786,10 +812,11 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   {
     petr_gemm_args g = gemm0();   // NCHW view [C_in][HW] read as an M-contiguous operand -> token-major memory
     g.a = io->feats; g.lda = d.HW; g.a_kcontig = 0; g.a_bs0 = (long)d.Cin * d.HW;
-    g.b = Pm + P.in_w; g.ldb = d.Cin; g.b_kcontig = 1;
+    g.b = Wp(P.in_w); g.ldb = d.Cin; g.b_kcontig = 1;
     g.c = Wm + W.mem; g.ldc = C; g.c_bs0 = (long)d.HW * C; g.bias = Pm + P.in_b;
     g.M = d.HW; g.N = C; g.K = d.Cin; g.nb0 = V;
     if (bf16_km(g)) g.flags |= PETR_GEMM_BF16;
+    if (tok16) g.flags |= wflag | PETR_GEMM_STORE_BF16;         // memory as bf16
     RUN(petr_gemm(&g, s2));
     petr_sine3d_args b;
     memset(&b, 0, sizeof b);
@@ -798,11 +825,12 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     RUN(petr_sine3d_fwd(&b, s2));
     g = gemm0();
     g.a = Wm + W.sine; g.lda = d.HW; g.a_kcontig = 0; g.a_bs0 = (long)(C * 3 / 2) * d.HW;
-    g.b = Pm + P.ad_w1; g.ldb = C * 3 / 2; g.b_kcontig = 1;
+    g.b = Wp(P.ad_w1); g.ldb = C * 3 / 2; g.b_kcontig = 1;
     g.c = Wm + W.h2; g.ldc = 4 * C; g.c_bs0 = (long)d.HW * 4 * C; g.bias = Pm + P.ad_b1;
     g.M = d.HW; g.N = 4 * C; g.K = C * 3 / 2; g.nb0 = V; g.flags = PETR_GEMM_RELU;
     if (bf16_km(g)) g.flags |= PETR_GEMM_BF16;
     if (hid16) g.flags |= PETR_GEMM_BF16 | PETR_GEMM_STORE_BF16;      // bf16 hidden (same element indexing, 2-byte elements)
+    g.flags |= wflag;
     RUN(petr_gemm(&g, s2));
   }
   // ---- side 1: 3D position embedding (petr_head.py:286-334): coords3d, conv 3D->4C, ReLU, conv 4C->C ----
@@ -816,15 +844,17 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     RUN(petr_coords3d_fwd(&a, s1));
     petr_gemm_args g = gemm0();
     g.a = Wm + W.vol; g.lda = d.HW; g.a_kcontig = 0; g.a_bs0 = (long)3 * d.D * d.HW;
-    g.b = Pm + P.pe_w1; g.ldb = 3 * d.D; g.b_kcontig = 1;
+    g.b = Wp(P.pe_w1); g.ldb = 3 * d.D; g.b_kcontig = 1;
     g.c = Wm + W.h1; g.ldc = 4 * C; g.c_bs0 = (long)d.HW * 4 * C; g.bias = Pm + P.pe_b1;
     g.M = d.HW; g.N = 4 * C; g.K = 3 * d.D; g.nb0 = V; g.flags = PETR_GEMM_RELU;
     if (bf16_km(g)) g.flags |= PETR_GEMM_BF16;
     if (hid16) g.flags |= PETR_GEMM_BF16 | PETR_GEMM_STORE_BF16;
+    g.flags |= wflag;
     RUN(petr_gemm(&g, s1));
-    g = lin_fwd(Wm + W.h1, Pm + P.pe_w2, Pm + P.pe_b2, Wm + (cfg->with_fpe ? W.pe1 : W.pos), d.BL, C, 4 * C);
+    g = lin_fwd(Wm + W.h1, Wp(P.pe_w2), Pm + P.pe_b2, Wm + (cfg->with_fpe ? W.pe1 : W.pos), d.BL, C, 4 * C);
     if (attn_bf16) g.flags |= PETR_GEMM_BF16;      // bf16 mode: the K-contiguous L-sized contractions run on bf16 MFMA
     if (hid16) g.flags |= PETR_GEMM_A_BF16;
+    g.flags |= wflag;
     RUN(petr_gemm(&g, s1));
     // wait for side 2 (memory, sine hidden)
     if (ln.ctx) {
@@ -834,41 +864,46 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     }
     if (cfg->with_fpe) {
       // feature-guided PE (petrv2_head.py:464-466, SELayer :48-60): pos3d * sigmoid(expand(relu(reduce(x))))
-      g = lin_fwd(Wm + W.mem, Pm + P.fpe_rw, Pm + P.fpe_rb, Wm + W.fpe_h, d.BL, C, C);
-      g.flags = PETR_GEMM_RELU | (attn_bf16 ? PETR_GEMM_BF16 : 0);
+      g = lin_fwd(Wm + W.mem, Wp(P.fpe_rw), Pm + P.fpe_rb, Wm + W.fpe_h, d.BL, C, C);
+      g.flags = PETR_GEMM_RELU | (attn_bf16 ? PETR_GEMM_BF16 : 0) | wflag | (tok16 ? PETR_GEMM_A_BF16 : 0);
       RUN(petr_gemm(&g, s1));
-      g = lin_fwd(Wm + W.fpe_h, Pm + P.fpe_ew, Pm + P.fpe_eb, Wm + W.fpe_u, d.BL, C, C);
+      g = lin_fwd(Wm + W.fpe_h, Wp(P.fpe_ew), Pm + P.fpe_eb, Wm + W.fpe_u, d.BL, C, C);
       if (attn_bf16) g.flags |= PETR_GEMM_BF16;
+      g.flags |= wflag;
       RUN(petr_gemm(&g, s1));
       RUN(petr_gate_fwd(Wm + W.pe1, Wm + W.fpe_u, Wm + W.pos, d.BL * C, s1));
     }
     // pos += adapt_pos3d(sine) (petr_head.py:400-402)
-    g = lin_fwd(Wm + W.h2, Pm + P.ad_w2, Pm + P.ad_b2, Wm + W.pos, d.BL, C, 4 * C);
+    g = lin_fwd(Wm + W.h2, Wp(P.ad_w2), Pm + P.ad_b2, Wm + W.pos, d.BL, C, 4 * C);
     if (attn_bf16) { g.flags = PETR_GEMM_BF16; g.r = Wm + W.pos; g.ldr = C; }   // same sum with pos as the residual operand
     else g.flags = PETR_GEMM_ACCUMULATE;
     if (hid16) g.flags |= PETR_GEMM_A_BF16;
+    g.flags |= wflag;
     RUN(petr_gemm(&g, s1));
     // key = memory + key_pos (petr_transformer.py:343-344), once for all layers
-    RUN(petr_add_rows(Wm + W.mem, Wm + W.pos, Wm + W.mempos, d.BL, 0, C, s1));
+    if (tok16) RUN(petr_add_rows_bf16(mem16, Wm + W.pos, mempos16, d.BL, 0, C, s1));
+    else RUN(petr_add_rows(Wm + W.mem, Wm + W.pos, Wm + W.mempos, d.BL, 0, C, s1));
     // K_l = (mem+pos) Wk_l^T + bk_l for ALL layers: [B][NL][L][C]
     g = gemm0();
     g.a = Wm + W.mempos; g.lda = C; g.a_kcontig = 1; g.a_bs0 = d.L * C;
-    g.b = Pm + P.lay[0].ca_in_w + (long)C * C; g.ldb = C; g.b_kcontig = 1; g.b_bs1 = P.ca_in_stride;
+    g.b = Wp(P.lay[0].ca_in_w + (long)C * C); g.ldb = C; g.b_kcontig = 1; g.b_bs1 = P.ca_in_stride;
     g.bias = Pm + P.lay[0].ca_in_b + C; g.bias_bs1 = P.ca_in_stride;
     g.c = Wm + W.k_all; g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
     g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
     if (attn_bf16) { g.c = reinterpret_cast<float*>(k16); g.flags |= PETR_GEMM_STORE_BF16 | PETR_GEMM_BF16; }   // bf16 MFMA, bf16 store
+    if (tok16) g.flags |= wflag | PETR_GEMM_A_BF16;
     RUN(kv_project(g, s1, &ev_k0));
   }
   {
     // V_l = mem Wv_l^T + bv_l on side 2 (memory was produced there)
     petr_gemm_args g = gemm0();
     g.a = Wm + W.mem; g.lda = C; g.a_kcontig = 1; g.a_bs0 = d.L * C;
-    g.b = Pm + P.lay[0].ca_in_w + (long)2 * C * C; g.ldb = C; g.b_kcontig = 1; g.b_bs1 = P.ca_in_stride;
+    g.b = Wp(P.lay[0].ca_in_w + (long)2 * C * C); g.ldb = C; g.b_kcontig = 1; g.b_bs1 = P.ca_in_stride;
     g.bias = Pm + P.lay[0].ca_in_b + 2 * C; g.bias_bs1 = P.ca_in_stride;
     g.c = Wm + W.v_all; g.ldc = C; g.c_bs0 = (long)d.NL * d.L * C; g.c_bs1 = d.L * C;
     g.M = (int)d.L; g.N = C; g.K = C; g.nb0 = d.B; g.nb1 = d.NL;
     if (attn_bf16) { g.c = reinterpret_cast<float*>(v16); g.flags |= PETR_GEMM_STORE_BF16 | PETR_GEMM_BF16; }
+    if (tok16) g.flags |= wflag | PETR_GEMM_A_BF16;
     RUN(kv_project(g, s2, &ev_v0));
   }
 
@@ -1086,6 +1121,10 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   // PETRv2's feature-guided PE) and the cross-attention backward run on the bf16 matrix cores, like their forwards
   const bool bf16 = io->attn_bf16 != 0;
   const bool hid16 = hidden_bf16(io);
+  const bool tok16 = token_bf16(cfg, io);
+  const uint16_t* p16 = reinterpret_cast<const uint16_t*>(Wm + W.p16);        // made by the forward (same parameters)
+  auto Wp = [&](long off) -> const float* { return tok16 ? reinterpret_cast<const float*>(p16 + off) : Pm + off; };
+  const int wflag = tok16 ? PETR_GEMM_B_BF16 : 0;
   auto L16 = [&](const petr_gemm_args& g) { return bf16 ? to_bf16(g) : g; };
   // PETR_KV_BWD_OVERLAP=1 (opt-in): the K/V projection backward per layer on the side streams beside the decoder chain
   // instead of two batched contractions in the final stage.  Measured and rejected as a default (same-box A/B,
@@ -1301,6 +1340,13 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
                 Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, d_ao, Wm + lw.lse_c, kpm, d_qc,
                 Wm + W.dk_all + (long)l * d.L * C, Wm + W.dv_all + (long)l * d.L * C, d, (int)d.L, mws, W.mha_ws_bytes, s,
                 training ? &dr[2] : nullptr));
+      // the weight gradients queued so far (FFN, cross-attention out-projection) start BEHIND the cross-attention backward
+      // (the fork is recorded after it): that kernel fills the machine, everything issued beside it only slowed it down
+      // (211 -> 240-270 us at 24 000 tokens in the kernel trace); the 900-row kernels that follow leave most CUs idle
+      // (bf16 mode only: its cross-attention backward is a 512-thread-per-workgroup kernel that occupies every CU; same-box
+      // A/B p4-1600 bf16 6.07 -> 6.00 ms, while the fp32 step at c5 lost 1.5 % to the extra fork, so fp32 keeps one flush)
+      static const bool midflush = env_on("PETR_WGRAD_MIDFLUSH");       // =0: only at the end of the stage
+      if (defer && midflush && bf16) RUN(flush_wgrads());
       // K / V projection backward of THIS layer (token-sized: the largest contractions of the backward) leaves the
       // critical path: dW_l and d_src (+)= dKV_l W_l go to the side streams right behind the attention backward that
       // produced dK_l / dV_l and run beside the 900-row chain of the remaining layers; the final stage only joins.
@@ -1317,16 +1363,16 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g2.a_colsum = Gp + lp.ca_in_b + (kv + 1) * C;
         g2.M = C; g2.N = C; g2.K = (int)d.BL;
         g2.k_seg = (int)d.L; g2.a_seg_stride = (long)d.NL * d.L * C; g2.b_seg_stride = d.L * C;
-        g2.flags = PETR_GEMM_ATOMIC | dkv_flag;
+        g2.flags = PETR_GEMM_ATOMIC | dkv_flag | wflag;
         g2.split_k = 32;
         g2 = L16(g2);
         RUN(petr_gemm(&g2, sd));
         g2 = gemm0();      // d_src[b][t][c] (+)= sum_o dKV[b][l][t][o] * W_l[o][c]   (first layer processed overwrites)
         g2.a = dkv; g2.lda = C; g2.a_kcontig = 1; g2.a_bs0 = (long)d.NL * d.L * C;
-        g2.b = Pm + lp.ca_in_w + (long)(kv + 1) * C * C; g2.ldb = C; g2.b_kcontig = 0;
+        g2.b = Wp(lp.ca_in_w + (long)(kv + 1) * C * C); g2.ldb = C; g2.b_kcontig = 0;
         g2.c = Wm + (kv == 0 ? W.d_mempos : W.d_mem); g2.ldc = C; g2.c_bs0 = d.L * C;
         g2.M = (int)d.L; g2.N = C; g2.K = C; g2.nb0 = d.B;
-        g2.flags = (l != d.NL - 1 ? PETR_GEMM_ACCUMULATE : 0) | dkv_flag;
+        g2.flags = (l != d.NL - 1 ? PETR_GEMM_ACCUMULATE : 0) | dkv_flag | wflag;
         g2 = L16(g2);
         RUN(petr_gemm(&g2, sd));
       }
@@ -1383,7 +1429,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       }
       for (int kv = 0; kv < 2 && !kv_overlap; ++kv) {     // single-stream / opt-out schedule: all layers in one contraction each
         const float* dkv = dkv_ptr(kv, 0);
-        const float* src = kv == 0 ? Wm + W.mempos : Wm + W.mem;
+        const float* src = kv == 0 ? Wm + W.mempos : Wm + W.mem;          // tok16: bf16 images, same element indexing
         petr_gemm_args g = gemm0();      // dW_l[C,C] += sum_{b,t} dKV[b][l][t][o] * src[b][t][c]
         g.a = dkv; g.lda = C; g.a_kcontig = 0; g.a_bs0 = d.L * C;
         g.b = src; g.ldb = C; g.b_kcontig = 0;
@@ -1391,16 +1437,16 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g.a_colsum = Gp + P.lay[0].ca_in_b + (kv + 1) * C; g.cs_bs0 = P.ca_in_stride;
         g.M = C; g.N = C; g.K = (int)d.BL; g.nb0 = d.NL;
         g.k_seg = (int)d.L; g.a_seg_stride = (long)d.NL * d.L * C; g.b_seg_stride = d.L * C;
-        g.flags = PETR_GEMM_ATOMIC | dkv_flag;
+        g.flags = PETR_GEMM_ATOMIC | dkv_flag | wflag;          // (wflag: the bf16 B operand here is memory / key)
         g.split_k = 8;
         RUN(wgrad(L16(g)));
         g = gemm0();      // d_src[b][t][c] = sum_{l,o} dKV[b][l][t][o] * W_l[o][c]
         g.a = dkv; g.lda = C; g.a_kcontig = 1; g.a_bs0 = (long)d.NL * d.L * C;
-        g.b = Pm + P.lay[0].ca_in_w + (long)(kv + 1) * C * C; g.ldb = C; g.b_kcontig = 0;
+        g.b = Wp(P.lay[0].ca_in_w + (long)(kv + 1) * C * C); g.ldb = C; g.b_kcontig = 0;
         g.c = Wm + (kv == 0 ? W.d_mempos : W.d_mem); g.ldc = C; g.c_bs0 = d.L * C;
         g.M = (int)d.L; g.N = C; g.K = d.NL * C; g.nb0 = d.B;
         g.k_seg = C; g.a_seg_stride = d.L * C; g.b_seg_stride = P.ca_in_stride;
-        g.flags = dkv_flag;
+        g.flags = dkv_flag | wflag;
         g = L16(g);
         RUN(petr_gemm(&g, s));
       }
@@ -1413,13 +1459,15 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         RUN(petr_gate_bwd(d_pos, Wm + W.pe1, Wm + W.fpe_u, Wm + W.d_pe1, Wm + W.d_fpe_u, d.BL * C, s));
         d_pe = Wm + W.d_pe1;
         RUN(wgrad(L16(lin_wgrad(Wm + W.d_fpe_u, C, Wm + W.fpe_h, C, Gp + P.fpe_ew, Gp + P.fpe_eb, d.BL, C, C))));
-        petr_gemm_args g = lin_dgrad(Wm + W.d_fpe_u, Pm + P.fpe_ew, Wm + W.d_fpe_h, d.BL, C, C);
-        g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.fpe_h; g.ldr = C;
+        petr_gemm_args g = lin_dgrad(Wm + W.d_fpe_u, Wp(P.fpe_ew), Wm + W.d_fpe_h, d.BL, C, C);
+        g.flags = PETR_GEMM_RELU_MASK | wflag; g.r = Wm + W.fpe_h; g.ldr = C;
         g = L16(g);
         RUN(petr_gemm(&g, s));
-        RUN(wgrad(L16(lin_wgrad(Wm + W.d_fpe_h, C, Wm + W.mem, C, Gp + P.fpe_rw, Gp + P.fpe_rb, d.BL, C, C))));
-        g = lin_dgrad(Wm + W.d_fpe_h, Pm + P.fpe_rw, Wm + W.d_mem, d.BL, C, C);
-        g.flags = PETR_GEMM_ACCUMULATE;
+        g = lin_wgrad(Wm + W.d_fpe_h, C, Wm + W.mem, C, Gp + P.fpe_rw, Gp + P.fpe_rb, d.BL, C, C);
+        g.flags |= wflag;                                              // B = memory (bf16 image when tok16)
+        RUN(wgrad(L16(g)));
+        g = lin_dgrad(Wm + W.d_fpe_h, Wp(P.fpe_rw), Wm + W.d_mem, d.BL, C, C);
+        g.flags = PETR_GEMM_ACCUMULATE | wflag;
         g = L16(g);
         RUN(petr_gemm(&g, s));
       }
@@ -1435,8 +1483,8 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         petr_gemm_args g = lin_wgrad(dy, C, hid, 4 * C, Gp + w2, Gp + b2, d.BL, C, 4 * C);
         if (hid16) g.flags |= PETR_GEMM_B_BF16;
         RUN(wgrad(L16(g)));
-        g = lin_dgrad(dy, Pm + w2, d_hpe, d.BL, C, 4 * C);
-        g.flags = PETR_GEMM_RELU_MASK; g.r = hid; g.ldr = 4 * C;
+        g = lin_dgrad(dy, Wp(w2), d_hpe, d.BL, C, 4 * C);
+        g.flags = PETR_GEMM_RELU_MASK | wflag; g.r = hid; g.ldr = 4 * C;
         if (hid16) g.flags |= PETR_GEMM_R_BF16 | PETR_GEMM_STORE_BF16;       // bf16 mask operand, bf16 hidden gradient
         g = L16(g);
         RUN(petr_gemm(&g, s));
@@ -1461,10 +1509,11 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         RUN(wgrad(L16(g)));
         if (gr->d_feats) {
           g = gemm0();      // d_x[view][ci][hw] = sum_o W[o][ci] * d_mem[view*HW+hw][o]
-          g.a = Pm + P.in_w; g.lda = d.Cin; g.a_kcontig = 0;
+          g.a = Wp(P.in_w); g.lda = d.Cin; g.a_kcontig = 0;
           g.b = Wm + W.d_mem; g.ldb = C; g.b_kcontig = 1; g.b_bs0 = (long)d.HW * C;
           g.c = gr->d_feats; g.ldc = d.HW; g.c_bs0 = (long)d.Cin * d.HW;
           g.M = d.Cin; g.N = d.HW; g.K = C; g.nb0 = V;
+          if (tok16) g.flags |= PETR_GEMM_A_BF16;
           g = L16(g);
           RUN(petr_gemm(&g, s));
         }

@@ -310,6 +310,24 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const float4* x, const fl
   const float4 a = x[i], b = e[i % e_n4];
   out[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
+// the same sum with a bf16 x and a bf16 result (bf16 mode: memory is stored as bf16 by input_proj, key = memory + pos
+// is only ever read by bf16 contractions); 8 elements per thread
+__global__ __launch_bounds__(256) void add_rows_bf16_kernel(const uint4* x, const float4* e, uint4* out, long n8, long e_n8) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 a = x[i];
+  const long j = i % e_n8;
+  const float4 b0 = e[2 * j], b1 = e[2 * j + 1];
+  auto lo = [](uint32_t w) { return __uint_as_float(w << 16); };
+  auto hi = [](uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); };
+  auto pk = [](float u, float v) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 o = {(__bf16)u, (__bf16)v};
+    return __builtin_bit_cast(uint32_t, o);
+  };
+  out[i] = make_uint4(pk(lo(a.x) + b0.x, hi(a.x) + b0.y), pk(lo(a.y) + b0.z, hi(a.y) + b0.w),
+                      pk(lo(a.z) + b1.x, hi(a.z) + b1.y), pk(lo(a.w) + b1.z, hi(a.w) + b1.w));
+}
 // SELayer gate of PETRv2 (petrv2_head.py:55-60): out = x * sigmoid(u)
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* x, const float* u, float* out, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -485,6 +503,16 @@ extern "C" int petr_add_rows(const float* x, const float* e, float* out, long M,
   hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
                      (const float4*)e, (float4*)out, n4, e_n4);
   PETR_LAUNCH_CHECK("add_rows");
+  return PETR_OK;
+}
+
+extern "C" int petr_add_rows_bf16(const uint16_t* x, const float* e, uint16_t* out, long M, int e_rows, int C, void* stream) {
+  PETR_CHECK(x && e && out && M > 0 && C > 0 && (C & 7) == 0 && aligned16(x) && aligned16(e) && aligned16(out),
+             PETR_ERR_INVALID, "add_rows_bf16: bad argument");
+  const long n8 = M * C / 8, e_n8 = (long)(e_rows > 0 ? e_rows : M) * C / 8;
+  hipLaunchKernelGGL(add_rows_bf16_kernel, dim3((unsigned)cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x,
+                     (const float4*)e, (uint4*)out, n8, e_n8);
+  PETR_LAUNCH_CHECK("add_rows_bf16");
   return PETR_OK;
 }
 

@@ -897,12 +897,12 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
   PETR_CHECK(!(g.flags & PETR_GEMM_STORE_BF16) || (g.split_k == 1 && !(g.flags & (PETR_GEMM_ACCUMULATE | PETR_GEMM_ATOMIC))),
              PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_STORE_BF16 needs a plain store (no accumulate / atomic / split_k)");
   if (g.flags & PETR_GEMM_BF16) {
-    PETR_CHECK(!gp->drop.p, PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_BF16 has no dropout epilogue");
+    const bool has_drop = gp->drop.p > 0.f;      // only the deep-step kernel of gemm_bf16.hip has the dropout epilogue
     // forward-shaped requests (K-contiguous B, plain epilogue) keep gemm.hip's two kernels; everything else - K-major B,
     // K segments, K slices, accumulate / atomic / ReLU-mask epilogues, bias-gradient column sums: the gradient
     // contractions of the bf16 training step - goes to the general kernel of gemm_bf16.hip
     const bool staged = g.K % 32 == 0 && (long)g.M * g.N * g.nb0 * g.nb1 >= 128L * 128 * 64;
-    const bool simple = g.b_kcontig && g.K % 16 == 0 && g.split_k == 1 && g.k_seg <= 0 && !g.a_colsum &&
+    const bool simple = !has_drop && g.b_kcontig && g.K % 16 == 0 && g.split_k == 1 && g.k_seg <= 0 && !g.a_colsum &&
                         !(g.flags & (PETR_GEMM_ACCUMULATE | PETR_GEMM_ATOMIC | PETR_GEMM_RELU_MASK | PETR_GEMM_SIGMOID_MUL |
                                      PETR_GEMM_A_BF16 | PETR_GEMM_B_BF16 | PETR_GEMM_R_BF16)) && vec &&
                         (!g.a_kcontig || !(g.lda & 3)) && !(g.ldb & 3) && (g.a_kcontig || staged);

@@ -506,6 +506,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_deep_kernel(const petr_gemm_
   const float* bias = (!plain && g.bias) ? g.bias + z0 * g.bias_bs0 + z1 * g.bias_bs1 : nullptr;
   const float* R = (!plain && g.r) ? g.r + z0 * g.r_bs0 + z1 * g.r_bs1 : nullptr;
   const int flags = plain ? 0 : g.flags;
+  DropDev dd;                      // dropout of the result (the FFN hidden of the bf16 step); thr == 0: off
+  __builtin_memcpy(&dd, &g.drop, sizeof dd);
+  if (plain) dd.thr = 0;
   if (vec_epi) {
     float* Cs = reinterpret_cast<float*>(dlds);
     __syncthreads();                         // the operand image is dead
@@ -548,11 +551,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_deep_kernel(const petr_gemm_
           const float4 u = *reinterpret_cast<const float4*>(dst);
           old[0] = u.x; old[1] = u.y; old[2] = u.z; old[3] = u.w;
         }
+        const uint32_t rk = dd.thr ? drop_row_key(dd, (uint32_t)m) : 0u;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (flags & PETR_GEMM_RELU_MASK) v[e] = rv[e] > 0.f ? v[e] : 0.f;
           else v[e] += rv[e];
           if (flags & PETR_GEMM_RELU) v[e] = fmaxf(v[e], 0.f);
+          if (dd.thr) v[e] = drop_keep(rk, (uint32_t)(n + e), dd.thr) ? v[e] * dd.scale : 0.f;
           v[e] += old[e];
         }
         if (flags & PETR_GEMM_STORE_BF16) {
@@ -592,6 +597,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_deep_kernel(const petr_gemm_
         if (flags & PETR_GEMM_RELU_MASK) v = rv > 0.f ? v : 0.f;
         else v += rv;
         if (flags & PETR_GEMM_RELU) v = fmaxf(v, 0.f);
+        if (dd.thr) v = drop_keep(drop_row_key(dd, (uint32_t)mc), (uint32_t)nc, dd.thr) ? v * dd.scale : 0.f;
         v += old;
         if (ok) {
           if (flags & PETR_GEMM_STORE_BF16)
@@ -629,7 +635,10 @@ int petr_gemm_bf16_general(const petr_gemm_args& g, hipStream_t s) {
   const bool a16 = (g.flags & PETR_GEMM_A_BF16) != 0, b16 = (g.flags & PETR_GEMM_B_BF16) != 0;
   // the deep-step kernel (K step 128, LDS epilogue) is the default; PETR_GEMM16_DEEP=0 selects the K-step-32 kernel
   static const bool deep_on = !(getenv("PETR_GEMM16_DEEP") && atoi(getenv("PETR_GEMM16_DEEP")) == 0);
-  if (deep_on && g.split_k == 1) {      // K slices (weight gradients, long contractions): the double-buffered K-step-32 kernel
+  // K slices: only short ones (<= 4 deep steps per slice: the split FFN contractions of the 900-row chain); long slices
+  // (weight gradients over all tokens) stay with the double-buffered K-step-32 kernel, which measured 2x faster there
+  const long deep_steps = (long)(g.k_seg > 0 ? g.K / g.k_seg : 1) * cdiv(kseg, GD_BK);
+  if (deep_on && (g.split_k == 1 || cdiv(deep_steps, g.split_k) <= 4)) {
     // vector epilogue: 4 consecutive columns per lane must be contiguous, 16-byte (fp32) / 8-byte (bf16) aligned
     const bool st16 = (g.flags & PETR_GEMM_STORE_BF16) != 0, r16 = (g.flags & PETR_GEMM_R_BF16) != 0;
     const uintptr_t cmask = st16 ? 7 : 15, rmask = r16 ? 7 : 15;
@@ -665,6 +674,11 @@ int petr_gemm_bf16_general(const petr_gemm_args& g, hipStream_t s) {
 #undef PETR_GD
     PETR_LAUNCH_CHECK("gemm_bf16_deep");
     return PETR_OK;
+  }
+  {
+    DropDev dd;
+    memcpy(&dd, &g.drop, sizeof dd);      // petr_gemm() has already derived the device keys
+    PETR_CHECK(!dd.thr, PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_BF16 dropout epilogue needs the deep-step kernel (short K slices)");
   }
   dim3 grid(tm * tn * g.nb0 * g.nb1 * g.split_k), block(256);
 #define PETR_G16(AKC, BKC)                                                                                              \

@@ -776,6 +776,8 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   uint16_t* mem16 = reinterpret_cast<uint16_t*>(Wm + W.mem);          // tok16: bf16 images in the front half of the
   uint16_t* mempos16 = reinterpret_cast<uint16_t*>(Wm + W.mempos);    // fp32 buffers, same element indexing
   if (tok16) RUN(petr_cast_bf16(Pm, p16, P.total, s));
+  static const bool ffn16_env = env_on("PETR_FFN16");
+  const bool ffn16 = tok16 && ffn16_env;
   // bf16 mode: the 1x1 convolutions over NCHW maps take the K-major variant of the bf16 contraction where it applies
   auto bf16_km = [&](const petr_gemm_args& q) {
     return attn_bf16 && q.K % 32 == 0 && (long)q.M * q.N * (q.nb0 > 0 ? q.nb0 : 1) >= 128L * 128 * 64 && !(q.lda & 3) && !(q.ldb & 3);
@@ -986,11 +988,14 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
                training ? Wm + lw.z1 : nullptr, Wm + lw.mean1, Wm + lw.rstd1, d.BQ, C, 0, nullptr, nullptr, 0, s,
                training ? &dr_co : nullptr));
     // FFN (mmcv FFN): x + W2 relu(W1 x + b1) + b2 ; second contraction split over K
-    g = lin_fwd(Wm + lw.x2, Pm + lp.f1_w, Pm + lp.f1_b, Wm + lw.hff, d.BQ, d.F, C);
-    g.flags = PETR_GEMM_RELU;
+    // bf16 mode: both FFN contractions on the bf16 matrix cores with the bf16 weight copy, as autocast runs them
+    // (900 x 2048 x 256 alone: 21.8 -> 11.8 us; PETR_FFN16=0: fp32)
+    g = lin_fwd(Wm + lw.x2, ffn16 ? Wp(lp.f1_w) : Pm + lp.f1_w, Pm + lp.f1_b, Wm + lw.hff, d.BQ, d.F, C);
+    g.flags = PETR_GEMM_RELU | (ffn16 ? wflag : 0);
     if (training) g.drop = dr_fh;                                       // Linear, ReLU, Dropout (mmcv FFN)
     RUN(petr_gemm(&g, s));
-    g = lin_fwd(Wm + lw.hff, Pm + lp.f2_w, nullptr, Wm + W.ffn_part, d.BQ, C, d.F);
+    g = lin_fwd(Wm + lw.hff, ffn16 ? Wp(lp.f2_w) : Pm + lp.f2_w, nullptr, Wm + W.ffn_part, d.BQ, C, d.F);
+    if (ffn16) g.flags |= wflag;
     g.split_k = W.ffn_split; g.c_split_stride = d.BQ * C;
     float* xs_l = Wm + W.xs + (long)l * d.BQ * C;
     if (W.ffn_split == 1 && !training) { g.bias = Pm + lp.f2_b; g.r = Wm + lw.x2; g.ldr = C; g.c = Wm + lw.z2; }
@@ -1125,6 +1130,8 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   const uint16_t* p16 = reinterpret_cast<const uint16_t*>(Wm + W.p16);        // made by the forward (same parameters)
   auto Wp = [&](long off) -> const float* { return tok16 ? reinterpret_cast<const float*>(p16 + off) : Pm + off; };
   const int wflag = tok16 ? PETR_GEMM_B_BF16 : 0;
+  static const bool ffn16_env = env_on("PETR_FFN16");
+  const bool ffn16 = tok16 && ffn16_env;
   auto L16 = [&](const petr_gemm_args& g) { return bf16 ? to_bf16(g) : g; };
   // PETR_KV_BWD_OVERLAP=1 (opt-in): the K/V projection backward per layer on the side streams beside the decoder chain
   // instead of two batched contractions in the final stage.  Measured and rejected as a default (same-box A/B,
@@ -1306,8 +1313,9 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       float* d_h = Wm + lg.d_h;                                 // [BQ, F]
       const WOff::LayerT& wt = W.wt[l];
       petr_gemm_args g = dgrad_t ? lin_dgrad_t(d_f2, Wm + wt.f2, d_h, d.BQ, C, d.F) : lin_dgrad(d_f2, Pm + lp.f2_w, d_h, d.BQ, C, d.F);
+      if (ffn16) g = lin_dgrad(d_f2, Wp(lp.f2_w), d_h, d.BQ, C, d.F);     // bf16 route: the bf16 weight, read K-major
       // stored hidden = relu(.) * keep/(1-p): (hidden > 0) is relu-mask AND keep; the 1/(1-p) rides on alpha
-      g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + lw.hff; g.ldr = d.F;
+      g.flags = PETR_GEMM_RELU_MASK | (ffn16 ? PETR_GEMM_BF16 | wflag : 0); g.r = Wm + lw.hff; g.ldr = d.F;
       if (training) g.alpha = hidden_drop_scale(dr[4]);
       RUN(petr_gemm(&g, s));
       RUN(wgrad(lin_wgrad(d_h, d.F, Wm + lw.x2, C, Gp + lp.f1_w, Gp + lp.f1_b, d.BQ, d.F, C)));
@@ -1316,6 +1324,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       float* d_x2 = Wm + lg.d_x2;
       const int sk = W.ffn_split;
       g = dgrad_t ? lin_dgrad_t(d_h, Wm + wt.f1, d_x2, d.BQ, d.F, C) : lin_dgrad(d_h, Pm + lp.f1_w, d_x2, d.BQ, d.F, C);
+      if (ffn16) { g = lin_dgrad(d_h, Wp(lp.f1_w), d_x2, d.BQ, d.F, C); g.flags = PETR_GEMM_BF16 | wflag; }
       if (sk > 1) { g.split_k = sk; g.c_split_stride = d.BQ * C; }
       else { g.r = d_z2; g.ldr = C; }
       RUN(petr_gemm(&g, s));
@@ -1340,13 +1349,13 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
                 Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, d_ao, Wm + lw.lse_c, kpm, d_qc,
                 Wm + W.dk_all + (long)l * d.L * C, Wm + W.dv_all + (long)l * d.L * C, d, (int)d.L, mws, W.mha_ws_bytes, s,
                 training ? &dr[2] : nullptr));
-      // the weight gradients queued so far (FFN, cross-attention out-projection) start BEHIND the cross-attention backward
-      // (the fork is recorded after it): that kernel fills the machine, everything issued beside it only slowed it down
-      // (211 -> 240-270 us at 24 000 tokens in the kernel trace); the 900-row kernels that follow leave most CUs idle
-      // (bf16 mode only: its cross-attention backward is a 512-thread-per-workgroup kernel that occupies every CU; same-box
-      // A/B p4-1600 bf16 6.07 -> 6.00 ms, while the fp32 step at c5 lost 1.5 % to the extra fork, so fp32 keeps one flush)
-      static const bool midflush = env_on("PETR_WGRAD_MIDFLUSH");       // =0: only at the end of the stage
-      if (defer && midflush && bf16) RUN(flush_wgrads());
+      // (tried: start the weight gradients queued so far BEHIND the cross-attention backward - that kernel fills the machine and
+      // runs 211 -> 240-270 us at 24 000 tokens when they execute beside it)
+      // Opt-in (PETR_WGRAD_MIDFLUSH=1): interleaved three-round A/B on one box (scripts/ab_multi.sh) - c5 bf16 4.47 -> 4.54 ms,
+      // v2-800 bf16 5.78 -> 5.86, p4-1600 bf16 6.04 -> 6.06, c5 fp32 4.94 -> 5.01: the second fork per layer costs more than
+      // the overlap it removes, so the stage keeps its single flush at the end.
+      static const bool midflush = getenv("PETR_WGRAD_MIDFLUSH") && atoi(getenv("PETR_WGRAD_MIDFLUSH")) != 0;
+      if (defer && midflush) RUN(flush_wgrads());
       // K / V projection backward of THIS layer (token-sized: the largest contractions of the backward) leaves the
       // critical path: dW_l and d_src (+)= dKV_l W_l go to the side streams right behind the attention backward that
       // produced dK_l / dV_l and run beside the 900-row chain of the remaining layers; the final stage only joins.

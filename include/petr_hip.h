@@ -99,6 +99,16 @@ typedef struct { uint64_t seed; uint32_t site; float p; } petr_dropout;
 /* keep[row*cols + col] = 1 / 0 for the element a kernel addresses as (row, col): attention P uses
  * row = (b*H + h)*Q + q, col = key; row-major activations use row = m, col = n.               */
 int petr_dropout_mask(const petr_dropout* d, long rows, long cols, uint8_t* keep, void* stream);
+/* The same mask packed for ONE attention call (row = bh*Q + q, col = key; BH = B*H):
+ *   bits_q[(bh * nkb + kb) * 32 nqt + q]   bit j = keep(q, 32 kb + j)   query-major
+ *   bits_k[(bh * nqt + qt) * 32 nkb + k]   bit i = keep(32 qt + i, k)   key-major: the layout petr_mha_fwd* leaves in its
+ *                                          drop_bits and petr_mha_bwd* reads (the key sits on the lane there), so that the
+ *                                          backward tests a bit instead of re-hashing (~20 % of its time at 24 000 keys)
+ * nqt = ceil(Q/32), nkb = ceil(L/32); each layout holds petr_dropout_bits_words(BH, Q, L) uint32_t; either may be NULL.
+ * (Generating the masks with this kernel ahead of the attention calls, so that the forward tests bits too, was measured:
+ * it costs what it saves - the generator is as much VALU work as the hashing it replaces.) */
+size_t petr_dropout_bits_words(int BH, int Q, int L);
+int petr_dropout_bits(const petr_dropout* d, int BH, int Q, int L, uint32_t* bits_q, uint32_t* bits_k, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense contraction  C[z][m, n] (+)= act( alpha * sum_k A(m,k) * B(n,k) + bias[n] + R[m,n] )
@@ -237,6 +247,9 @@ typedef struct {
   petr_dropout drop;   /* dropout of the attention probabilities (row = (b*H+h)*Q+q, col = key) */
   int* sched;   /* optional: B*H*ceil(Q/128) ints, ZERO on entry and left zero on exit; enables dynamic K/V-tile
                  * scheduling between the n_split workers of a query block (NULL: equal static ranges) */
+  uint32_t* drop_bits;   /* out, optional with drop.p > 0: petr_dropout_bits_words(B*H, Q, L) words; the kernel leaves the
+                          * dropout mask it applied there, packed key-major (the bits_k layout of petr_dropout_bits), for
+                          * petr_mha_bwd's drop_bits: the backward then tests one bit per probability instead of hashing it */
 } petr_mha_fwd_args;
 size_t petr_mha_fwd_workspace_bytes(int B, int H, int Q, int L, int n_split);
 int petr_mha_choose_split(int B, int H, int Q, int L);
@@ -260,6 +273,7 @@ typedef struct {
   void* ws; size_t ws_bytes;
   petr_dropout drop;
   int* sched;
+  uint32_t* drop_bits;   /* as petr_mha_fwd_args.drop_bits */
 } petr_mha_fwd_bf16_args;
 size_t petr_mha_fwd_bf16_workspace_bytes(int B, int H, int Q, int L, int n_split);
 int petr_mha_fwd_bf16(const petr_mha_fwd_bf16_args* a, void* stream);
@@ -285,6 +299,8 @@ typedef struct {
   float scale;
   void* ws; size_t ws_bytes;
   petr_dropout drop;   /* must equal the forward's */
+  const uint32_t* drop_bits;   /* optional with drop.p > 0: the KEY-major packed mask - what the forward left in its
+                                * drop_bits, or bits_k of petr_dropout_bits() for the same (drop, B*H, Q, L); NULL: re-hash */
 } petr_mha_bwd_args;
 size_t petr_mha_bwd_workspace_bytes(int B, int H, int Q, int L);
 int petr_mha_bwd(const petr_mha_bwd_args* a, void* stream);
@@ -310,6 +326,7 @@ typedef struct {
   float scale;
   void* ws; size_t ws_bytes;   /* unused (0 bytes needed); kept so that the block mirrors petr_mha_bwd_args */
   petr_dropout drop;           /* must equal the forward's */
+  const uint32_t* drop_bits;   /* as petr_mha_bwd_args.drop_bits */
   int dkv_overwrite;           /* 1: dk and dv are STORED (no zero-fill by the caller, no read-modify-write; the query range is
                                 * then never split over workgroups); 0: accumulated like petr_mha_bwd.  dq is always += */
   int dkv_bf16;                /* 1 (needs dkv_overwrite): dk / dv point to bf16 storage (uint16_t bits, round to nearest even),

@@ -89,7 +89,8 @@ class MhaFwdArgs(C.Structure):
         ('o', C.c_void_p), ('o_bs', C.c_long), ('o_hs', C.c_long), ('o_rs', C.c_long),
         ('lse', C.c_void_p), ('kpm', C.c_void_p),
         ('B', C.c_int), ('H', C.c_int), ('Q', C.c_int), ('L', C.c_int), ('scale', C.c_float),
-        ('n_split', C.c_int), ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('drop', Dropout), ('sched', C.c_void_p))
+        ('n_split', C.c_int), ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('drop', Dropout), ('sched', C.c_void_p),
+        ('drop_bits', C.c_void_p))
 
 
 class MhaBwdArgs(C.Structure):
@@ -104,7 +105,7 @@ class MhaBwdArgs(C.Structure):
         ('dk', C.c_void_p), ('dk_bs', C.c_long), ('dk_hs', C.c_long), ('dk_rs', C.c_long),
         ('dv', C.c_void_p), ('dv_bs', C.c_long), ('dv_hs', C.c_long), ('dv_rs', C.c_long),
         ('B', C.c_int), ('H', C.c_int), ('Q', C.c_int), ('L', C.c_int), ('scale', C.c_float),
-        ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('drop', Dropout))
+        ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('drop', Dropout), ('drop_bits', C.c_void_p))
 
 
 class MhaBwdBf16Args(C.Structure):    # petr_mha_bwd_bf16_args = petr_mha_bwd_args (k / v bf16) + dkv_overwrite, dkv_bf16
@@ -210,6 +211,9 @@ def lib():
     L.petr_mha_fwd_bf16_workspace_bytes.restype = C.c_size_t
     L.petr_mha_fwd_bf16.argtypes = [C.POINTER(MhaFwdArgs), C.c_void_p]   # same block, k / v are bf16
     L.petr_cast_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+    L.petr_dropout_bits_words.argtypes = [C.c_int] * 3
+    L.petr_dropout_bits_words.restype = C.c_size_t
+    L.petr_dropout_bits.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.petr_mha_bwd_workspace_bytes.argtypes = [C.c_int] * 4
     L.petr_mha_bwd_workspace_bytes.restype = C.c_size_t
     L.petr_mha_bwd.argtypes = [C.POINTER(MhaBwdArgs), C.c_void_p]
@@ -260,7 +264,7 @@ EXPORTS = [
     'petr_mha_bwd', 'petr_mha_bwd_bf16_workspace_bytes', 'petr_mha_bwd_bf16', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows', 'petr_gate_fwd', 'petr_gate_bwd', 'petr_prof_begin', 'petr_prof_end',
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
-    'petr_ctx_create', 'petr_ctx_destroy', 'petr_ctx_join_into', 'petr_dropout_mask', 'petr_loss_workspace_bytes', 'petr_loss_fwd_bwd',
+    'petr_ctx_create', 'petr_ctx_destroy', 'petr_ctx_join_into', 'petr_dropout_mask', 'petr_dropout_bits_words', 'petr_dropout_bits', 'petr_loss_workspace_bytes', 'petr_loss_fwd_bwd',
     'petr_decode_boxes', 'petr_decode_topk', 'petr_fpn_upsample_add',
 ]
 

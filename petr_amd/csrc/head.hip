@@ -254,6 +254,7 @@ struct LayerW {
 };
 struct WOff {
   long posemb, qe_h, qe, vol, sine, mem, h1, h2, pos, mempos, p16, k_all, v_all, x0;
+  long bits, bits_cross_n, bits_self_n;      // [NL][cross | self] key-major words
   LayerW lay[8];
   long xs, mean_p, rstd_p, outs;
   long c1, c1_mean, c1_rstd, c1n, c2, c2_mean, c2_rstd, c2n, r1, r2, reg_raw;
@@ -302,6 +303,11 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
   W.h2 = wb.add("sine_hidden", d.BL * 4 * C);
   W.pos = wb.add("pos_embed", d.BL * C);
   W.mempos = wb.add("mempos", d.BL * C);
+  {   // packed attention-dropout masks (training mode), key-major, per layer: the forward kernels leave them, the backward reads
+    W.bits_cross_n = (long)d.B * d.NH * cdiv(d.L, 32) * 32 * cdiv(d.Q, 32);
+    W.bits_self_n = (long)d.B * d.NH * cdiv(d.Q, 32) * 32 * cdiv(d.Q, 32);
+    W.bits = wb.add("dropout_bits", (long)d.NL * (W.bits_cross_n + W.bits_self_n));
+  }
   {   // bf16 copy of the flat parameter buffer (bf16 mode: the token-sized contractions read their weights from it)
     POff Pl;
     build_layout(c, &Pl, nullptr);
@@ -514,7 +520,7 @@ static int ln_bwd(const float* z, const float* mean, const float* rstd, const fl
 
 static int mha_f(const float* q, long q_bs, long q_rs, const float* k, long k_bs, long k_rs, const float* v, float* o,
                  float* lse, const uint8_t* kpm, const Dims& d, int L, float* ws, size_t ws_bytes, int* sched, void* s,
-                 const petr_dropout* drop = nullptr) {
+                 const petr_dropout* drop = nullptr, uint32_t* bits = nullptr) {
   petr_mha_fwd_args a;
   memset(&a, 0, sizeof a);
   if (drop) a.drop = *drop;
@@ -524,14 +530,14 @@ static int mha_f(const float* q, long q_bs, long q_rs, const float* k, long k_bs
   a.o = o; a.o_bs = (long)d.Q * d.C; a.o_hs = 32; a.o_rs = d.C;
   a.lse = lse; a.kpm = kpm; a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
   a.scale = 1.0f / sqrtf(32.f);
-  a.n_split = 0; a.ws = ws; a.ws_bytes = ws_bytes; a.sched = sched;
+  a.n_split = 0; a.ws = ws; a.ws_bytes = ws_bytes; a.sched = sched; a.drop_bits = bits;
   return petr_mha_fwd(&a, s);
 }
 
 // cross-attention with bf16 K/V (io->attn_bf16)
 static int mha_f_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, long k_bs, long k_rs, const uint16_t* v,
                       float* o, float* lse, const uint8_t* kpm, const Dims& d, int L, float* ws, size_t ws_bytes, void* s,
-                      const petr_dropout* drop = nullptr) {
+                      const petr_dropout* drop = nullptr, uint32_t* bits = nullptr) {
   petr_mha_fwd_bf16_args a;
   memset(&a, 0, sizeof a);
   if (drop) a.drop = *drop;
@@ -541,13 +547,14 @@ static int mha_f_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, l
   a.o = o; a.o_bs = (long)d.Q * d.C; a.o_hs = 32; a.o_rs = d.C;
   a.lse = lse; a.kpm = kpm; a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
   a.scale = 1.0f / sqrtf(32.f);
-  a.n_split = 0; a.ws = ws; a.ws_bytes = ws_bytes;
+  a.n_split = 0; a.ws = ws; a.ws_bytes = ws_bytes; a.drop_bits = bits;
   return petr_mha_fwd_bf16(&a, s);
 }
 
 static int mha_b(const float* q, long q_bs, long q_rs, const float* k, long k_bs, long k_rs, const float* v,
                  const float* o, const float* d_o, const float* lse, const uint8_t* kpm, float* dq, float* dk, float* dv,
-                 const Dims& d, int L, float* ws, size_t ws_bytes, void* s, const petr_dropout* drop = nullptr) {
+                 const Dims& d, int L, float* ws, size_t ws_bytes, void* s, const petr_dropout* drop = nullptr,
+                 const uint32_t* bits = nullptr) {
   petr_mha_bwd_args a;
   memset(&a, 0, sizeof a);
   if (drop) a.drop = *drop;
@@ -562,14 +569,15 @@ static int mha_b(const float* q, long q_bs, long q_rs, const float* k, long k_bs
   a.dv = dv; a.dv_bs = k_bs; a.dv_hs = 32; a.dv_rs = k_rs;
   a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
   a.scale = 1.0f / sqrtf(32.f);
-  a.ws = ws; a.ws_bytes = ws_bytes;
+  a.ws = ws; a.ws_bytes = ws_bytes; a.drop_bits = bits;
   return petr_mha_bwd(&a, s);
 }
 
 // gradient of mha_f_bf16 (io->attn_bf16 training step)
 static int mha_b_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, long k_bs, long k_rs, const uint16_t* v,
                       const float* o, const float* d_o, const float* lse, const uint8_t* kpm, float* dq, uint16_t* dk,
-                      uint16_t* dv, bool dkv16, const Dims& d, int L, void* s, const petr_dropout* drop = nullptr) {
+                      uint16_t* dv, bool dkv16, const Dims& d, int L, void* s, const petr_dropout* drop = nullptr,
+                      const uint32_t* bits = nullptr) {
   petr_mha_bwd_bf16_args a;
   memset(&a, 0, sizeof a);
   if (drop) a.drop = *drop;
@@ -585,6 +593,7 @@ static int mha_b_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, l
   a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
   a.scale = 1.0f / sqrtf(32.f);
   a.dkv_overwrite = 1;       // dK_l / dV_l are stored, not accumulated: the executor does not zero them in this mode
+  a.drop_bits = bits;
   a.dkv_bf16 = dkv16;        // ... and as bf16: the K/V-projection backward rounds them to bf16 anyway (PETR_GEMM_A_BF16)
   return petr_mha_bwd_bf16(&a, s);
 }
@@ -941,6 +950,14 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     dr.seed = io->dropout_seed; dr.site = (uint32_t)(8 * l + k); dr.p = io->dropout_p;
     return dr;
   };
+  // Training mode: the attention kernels leave the dropout mask they applied as packed key-major bits; the backward tests
+  // one bit per probability instead of hashing it again (PETR_DROP_BITS=0: re-hash).
+  static const bool drop_bits_env = env_on("PETR_DROP_BITS");
+  const bool use_bits = training && drop_bits_env;
+  uint32_t* bits0 = reinterpret_cast<uint32_t*>(Wm + W.bits);
+  auto bits_ptr = [&](int l, int self) -> uint32_t* {
+    return bits0 + (long)l * (W.bits_cross_n + W.bits_self_n) + (self ? W.bits_cross_n : 0);
+  };
   for (int l = 0; l < d.NL; ++l) {
     const LayerP& lp = P.lay[l];
     const LayerW& lw = W.lay[l];
@@ -951,7 +968,8 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g.a2 = E; g.a2_rows = d.Q; g.a2_ncols = 2 * C;
     RUN(petr_gemm(&g, s));
     RUN(mha_f(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
-              Wm + lw.ao_s, Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, sched, s, training ? &dr_sp : nullptr));
+              Wm + lw.ao_s, Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, sched, s, training ? &dr_sp : nullptr,
+              use_bits ? bits_ptr(l, 1) : nullptr));
     g = lin_fwd(Wm + lw.ao_s, Pm + lp.sa_out_w, Pm + lp.sa_out_b, Wm + lw.z0, d.BQ, C, C);
     if (!training) { g.r = x_in; g.ldr = C; }                          // identity + out (petr_transformer.py:367)
     RUN(petr_gemm(&g, s));
@@ -976,11 +994,11 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     if (attn_bf16)
       RUN(mha_f_bf16(Wm + lw.qc, (long)d.Q * C, C, k16 + (long)l * d.L * C, (long)d.NL * d.L * C, C,
                      v16 + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, s,
-                     training ? &dr_cp : nullptr));
+                     training ? &dr_cp : nullptr, use_bits ? bits_ptr(l, 0) : nullptr));
     else
     RUN(mha_f(Wm + lw.qc, (long)d.Q * C, C, Wm + W.k_all + (long)l * d.L * C, (long)d.NL * d.L * C, C,
               Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, sched, s,
-              training ? &dr_cp : nullptr));
+              training ? &dr_cp : nullptr, use_bits ? bits_ptr(l, 0) : nullptr));
     g = lin_fwd(Wm + lw.ao_c, Pm + lp.ca_out_w, Pm + lp.ca_out_b, Wm + lw.z1, d.BQ, C, C);
     if (!training) { g.r = Wm + lw.x1; g.ldr = C; }
     RUN(petr_gemm(&g, s));
@@ -1132,6 +1150,12 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   const int wflag = tok16 ? PETR_GEMM_B_BF16 : 0;
   static const bool ffn16_env = env_on("PETR_FFN16");
   const bool ffn16 = tok16 && ffn16_env;
+  static const bool drop_bits_env = env_on("PETR_DROP_BITS");          // the forward generated them (same workspace)
+  const bool use_bits = io->dropout_p > 0.f && drop_bits_env;
+  const uint32_t* bits0 = reinterpret_cast<const uint32_t*>(Wm + W.bits);
+  auto bits_ptr = [&](int l, int self) -> const uint32_t* {
+    return bits0 + (long)l * (W.bits_cross_n + W.bits_self_n) + (self ? W.bits_cross_n : 0);
+  };
   auto L16 = [&](const petr_gemm_args& g) { return bf16 ? to_bf16(g) : g; };
   // PETR_KV_BWD_OVERLAP=1 (opt-in): the K/V projection backward per layer on the side streams beside the decoder chain
   // instead of two batched contractions in the final stage.  Measured and rejected as a default (same-box A/B,
@@ -1343,12 +1367,12 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
                        v16 + (long)l * d.L * C, Wm + lw.ao_c, d_ao, Wm + lw.lse_c, kpm, d_qc,
                        dkv16 ? dk16 + (long)l * d.L * C : reinterpret_cast<uint16_t*>(Wm + W.dk_all + (long)l * d.L * C),
                        dkv16 ? dv16 + (long)l * d.L * C : reinterpret_cast<uint16_t*>(Wm + W.dv_all + (long)l * d.L * C), dkv16, d,
-                       (int)d.L, s, training ? &dr[2] : nullptr));
+                       (int)d.L, s, training ? &dr[2] : nullptr, use_bits ? bits_ptr(l, 0) : nullptr));
       else
       RUN(mha_b(Wm + lw.qc, (long)d.Q * C, C, Wm + W.k_all + (long)l * d.L * C, (long)d.NL * d.L * C, C,
                 Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, d_ao, Wm + lw.lse_c, kpm, d_qc,
                 Wm + W.dk_all + (long)l * d.L * C, Wm + W.dv_all + (long)l * d.L * C, d, (int)d.L, mws, W.mha_ws_bytes, s,
-                training ? &dr[2] : nullptr));
+                training ? &dr[2] : nullptr, use_bits ? bits_ptr(l, 0) : nullptr));
       // (tried: start the weight gradients queued so far BEHIND the cross-attention backward - that kernel fills the machine and
       // runs 211 -> 240-270 us at 24 000 tokens when they execute beside it)
       // Opt-in (PETR_WGRAD_MIDFLUSH=1): interleaved three-round A/B on one box (scripts/ab_multi.sh) - c5 bf16 4.47 -> 4.54 ms,
@@ -1408,7 +1432,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       float* d_qkv = Wm + W.d_qkv + (long)l * d.BQ * 3 * C;
       RUN(mha_b(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
                 Wm + lw.ao_s, d_ao_s, Wm + lw.lse_s, nullptr, d_qkv, d_qkv + C, d_qkv + 2 * C, d, d.Q, mws, W.mha_ws_bytes, s,
-                training ? &dr[0] : nullptr));
+                training ? &dr[0] : nullptr, use_bits ? bits_ptr(l, 1) : nullptr));
       // in_proj: q,k rows see x + query_pos, v rows see x
       RUN(wgrad(lin_wgrad(d_qkv, 3 * C, Wm + lw.xe_in, C, Gp + lp.sa_in_w, Gp + lp.sa_in_b, d.BQ, 2 * C, C)));
       {   // query_pos gradient through the self-attention q / k rows: slab [1][l]

@@ -34,7 +34,8 @@ struct MhaBwdParams {
   int nkb, q_splits, qtiles_per_split;
   int vec;             // q/do/k/v 16-byte loads legal
   DropDev drop;        // the forward's probability dropout (thr == 0: off)
-  int diag;            // TIMING-ONLY ablations (PETR_BWD32_DIAG; results are wrong when non-zero)
+  const uint32_t* drop_bits;   // key-major packed mask (petr_dropout_bits) or null: re-hash
+  int nqt32, lpad;             // its dimensions: ceil(Q/32) query tiles, 32 * ceil(L/32) keys per tile
 };
 
 // DROP: the forward multiplied the probabilities by keep/(1-p) after the softmax, so with m = keep/(1-p)
@@ -112,6 +113,10 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
   const float* op = a.o + (long)b * a.o_bs + (long)hd * a.o_hs;
   float4 qreg, greg, oreg;
   float lreg = 0.f;
+  // packed dropout mask: the word of this lane's key for the query tile travels with the tile's prefetch (dnext) and
+  // becomes current (dbits) when the tile is staged
+  const bool use_bits = DROP && p.drop_bits != nullptr;
+  uint32_t dnext = 0u, dbits = 0u;
   // raw loads only (clamped rows): selects/negations happen at the LDS store so that nothing waits at the load
   // Tile addresses are a wave-uniform base (scalar arithmetic) + a per-lane 32-bit offset computed once: the f32
   // MFMA shares the vector issue port, and 32/64-bit integer multiplies are quarter rate.
@@ -138,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
       oreg = make_float4(o[0], o[1], o[2], o[3]);
     }
     lreg = a.lse[(long)bh * a.Q + qt * 32 + lo];
+    if (use_bits) dnext = p.drop_bits[((long)bh * p.nqt32 + qt) * p.lpad + key_ld];
   };
 
   int dq_off[4];   // element (row, d) = (idx >> 5, idx & 31) of the 32 x 32 dQ tile, idx = t + 256 j
@@ -146,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
 
   // registers -> LDS for query tile qt (raw loads were issued one tile earlier)
   auto stage = [&](int qt) {
+    dbits = dnext;
     const int row = t >> 3, c4 = t & 7;
     const bool ok = qt * 32 + row < a.Q;
     float* d = Qs + row * P33 + 4 * c4;
@@ -192,7 +199,11 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
       S[r] = __builtin_amdgcn_exp2f(S[r] * sc2);   // p
       if (DROP) {
         const int qr = mfma32_row(r, h);
-        const float m = drop_keep(rk_s[qr], (uint32_t)key, p.drop.thr) ? p.drop.scale : 0.f;
+        float m;
+        if (use_bits)      // wave-uniform: bit qr of the key's mask word instead of a hash
+          m = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe(dbits >> (4 * h), (r & 3) + 8 * (r >> 2), 1) & __float_as_uint(p.drop.scale));
+        else
+          m = drop_keep(rk_s[qr], (uint32_t)key, p.drop.thr) ? p.drop.scale : 0.f;
         dP[r] = S[r] * (dP[r] * m + dl_s[qr]);     // ds = p * (m * dO.V - delta)
         S[r] *= m;                                 // dropped probability: B operand of dV
       } else {
@@ -213,7 +224,6 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
       if (qt + 2 < qt_end) gload(qt + 2);
     }
 
-    if (p.diag & 4) continue;
     f32x16 dQp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dQp[r] = 0.f;
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
       for (int j = 0; j < 4; ++j) {
         const int idx = t + 256 * j;
         const float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
-        if (qt * 32 + (idx >> 5) < a.Q && !(p.diag & 1)) atomicAdd(dq + dq_off[j], v * a.scale);
+        if (qt * 32 + (idx >> 5) < a.Q) atomicAdd(dq + dq_off[j], v * a.scale);
       }
     }
   }
@@ -266,9 +276,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
         const float gk = red[wave][kr * P33 + d], gv = dSs[wave][kr * P33 + d];
         float* pk = dk + (long)kg * a.dk_rs + d;
         float* pv = dv + (long)kg * a.dv_rs + d;
-        if (p.diag & 2) {
-          if (gk == 123.456f) *pk = gv;
-        } else if (use_atomic) {
+        if (use_atomic) {
           atomicAdd(pk, gk);
           atomicAdd(pv, gv);
         } else {
@@ -328,7 +336,9 @@ extern "C" int petr_mha_bwd(const petr_mha_bwd_args* ap, void* stream) {
   PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "mha_bwd: dropout p=%g outside [0,1)", (double)a.drop.p);
   PETR_CHECK((long)a.B * a.H * a.Q < (1L << 32), PETR_ERR_UNSUPPORTED, "mha_bwd: dropout row index needs B*H*Q < 2^32");
   p.drop = make_drop(a.drop);
-  p.diag = getenv("PETR_BWD32_DIAG") ? atoi(getenv("PETR_BWD32_DIAG")) : 0;
+  p.drop_bits = a.drop.p > 0.f ? a.drop_bits : nullptr;
+  p.nqt32 = (int)cdiv(a.Q, 32);
+  p.lpad = 32 * (int)cdiv(a.L, 32);
   auto launch = [&](auto kern) { hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), 0, s, ev0, ev1, 0, p); };
   switch ((p.drop.thr ? 4 : 0) | (a.kpm ? 2 : 0) | (p.vec ? 1 : 0)) {
     case 0: launch(mha_bwd_kernel<false, false, false>); break;

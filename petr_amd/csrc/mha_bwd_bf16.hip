@@ -62,6 +62,8 @@ struct MhaBwd16Params {
   petr_mha_bwd_bf16_args a;
   int nkb, q_splits, qtiles_per_split;
   DropDev drop;        // the forward's probability dropout (thr == 0: off)
+  const uint32_t* drop_bits;   // key-major packed mask (petr_dropout_bits) or null: re-hash
+  int nqt32, lpad;             // its dimensions: ceil(Q/32) query tiles, 32 * ceil(L/32) keys per tile
 };
 
 __device__ __forceinline__ s16x4 tr16(const uint16_t* p) {
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mha_bwd_bf16_kernel(
   float* rows_s = reinterpret_cast<float*>(smem + OFF_ROWS);
   uint16_t* ds_all = reinterpret_cast<uint16_t*>(smem + OFF_DS);
   float* red = reinterpret_cast<float*>(smem + off_red(NW));
+  __shared__ uint32_t bits_s[2][NW * 32 * KT];       // packed dropout mask words of the workgroup's keys, per query-tile buffer
 
   const petr_mha_bwd_bf16_args& a = p.a;
   const int total = p.nkb * a.B * a.H * p.q_splits;
@@ -188,9 +191,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mha_bwd_bf16_kernel(
   const bool stager = __builtin_amdgcn_readfirstlane(t >> 6) < NW / 2;     // wave-uniform, provably
   float4 rq[NP], rg[NP], ro[NP];
   float lreg = 0.f;
+  uint32_t breg[KT];
+#pragma unroll
+  for (int i = 0; i < KT; ++i) breg[i] = 0u;
+  const bool use_bits = DROP && p.drop_bits != nullptr;
 #pragma unroll
   for (int j = 0; j < NP; ++j) rq[j] = rg[j] = ro[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto gload = [&](int qt) {
+    if (use_bits) {       // the mask words of the workgroup's keys for this query tile travel with the tile (stager waves:
+#pragma unroll            // the flusher waves' vector-memory queue holds atomics only)
+      for (int i = 0; i < KT; ++i)
+        breg[i] = p.drop_bits[((long)bh * p.nqt32 + qt) * p.lpad + min(kb * (NW * 32 * KT) + (t & (NS - 1)) + NS * i, a.L - 1)];
+    }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int pc = (t & (NS - 1)) + NS * j;              // piece: row pc >> 3, columns 4 (pc & 7) ..
@@ -204,6 +216,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mha_bwd_bf16_kernel(
   };
   auto stage = [&](int qt, int buf) {
     float* rw = rows_s + buf * 96;
+    if (use_bits) {
+#pragma unroll
+      for (int i = 0; i < KT; ++i) bits_s[buf][(t & (NS - 1)) + NS * i] = breg[i];
+    }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int pc = (t & (NS - 1)) + NS * j;
@@ -321,7 +337,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mha_bwd_bf16_kernel(
       dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], vB[i][0], dP, 0, 0, 0);
       dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], vB[i][1], dP, 0, 0, 0);
       } else { dP[0] += (float)ga[0][0] + (float)vB[i][0][0] + (float)ga[1][1] + (float)vB[i][1][1]; }
-      if (DROP) {
+      if (DROP && use_bits) {
+        // one bit test per probability: row mfma32_row(r, h) of this key's word (shifted by 4 h once)
+        const uint32_t w = bits_s[buf][wave * 32 * KT + 32 * i + c] >> (4 * h);
+        const uint32_t sbits = __float_as_uint(p.drop.scale);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 y = *reinterpret_cast<const float4*>(rw + 32 + 8 * g + 4 * h);   // -delta, read where it is used
+          const float nd4[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const float pr = __builtin_amdgcn_exp2f(S[r]);
+            const float m = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe(w, e + 8 * g, 1) & sbits);     // scale or 0
+            dP[r] = pr * (dP[r] * m + nd4[e]);     // ds = p * (m * dO.V - delta)
+            S[r] = pr * m;                         // dropped probability: B operand of dV
+          }
+        }
+      } else if (DROP) {
         const uint32_t key = (uint32_t)(key_base + 32 * i + c);
         const uint32_t* rk = reinterpret_cast<const uint32_t*>(rw) + 64;
 #pragma unroll
@@ -484,6 +517,9 @@ extern "C" int petr_mha_bwd_bf16(const petr_mha_bwd_bf16_args* ap, void* stream)
   PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "mha_bwd_bf16: dropout p=%g outside [0,1)", (double)a.drop.p);
   PETR_CHECK((long)a.B * a.H * a.Q < (1L << 32), PETR_ERR_UNSUPPORTED, "mha_bwd_bf16: dropout row index needs B*H*Q < 2^32");
   p.drop = make_drop(a.drop);
+  p.drop_bits = a.drop.p > 0.f ? a.drop_bits : nullptr;
+  p.nqt32 = (int)cdiv(a.Q, 32);
+  p.lpad = 32 * (int)cdiv(a.L, 32);
   // two shapes of the same kernel, 256 keys per workgroup either way: (NW, KT) = (8, 1) - eight waves with one key tile
   // each, one workgroup per CU - is the default; (4, 2) - four waves with two key tiles each, two workgroups per CU,
   // PETR_MHA_BWD16_SHAPE=42 - was built to cut the LDS traffic per product by a third, but hipcc spills 27-40 registers of

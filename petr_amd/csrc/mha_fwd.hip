@@ -39,6 +39,33 @@ struct MhaFwdParams {
   int n_tiles, n_tickets;
   DropDev drop;    // dropout of the probabilities (thr == 0: off)
   int* sched;      // [B*H*nqb] tile tickets (dynamic mode), zero on entry, zero again on exit
+  uint32_t* drop_bits;   // out (optional): the key-major packed dropout mask (petr_dropout_bits layout) for the backward
+  int nqt32, lpad;       // its dimensions: ceil(Q/32) query tiles, 32 * ceil(L/32) keys per tile
+};
+
+// The keep decisions of one 32 query x 32 key block, as the backward wants them (key on the lane): the ballot of
+// accumulator register r holds, in its low / high word, the 32 queries' bits for key mfma32_row(r, 0) / (r, 1); collected
+// into lane `key` of one register (v_writelane), the block is one 128-byte store.
+template <int LANE>
+__device__ __forceinline__ uint32_t write_lane(uint32_t wv, uint32_t uniform) {
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(wv) : "s"(uniform), "n"(LANE));
+  return wv;
+}
+template <int R>
+__device__ __forceinline__ uint32_t bits_put(uint32_t wv, unsigned long long ballot) {
+  wv = write_lane<(R & 3) + 8 * (R >> 2)>(wv, (uint32_t)ballot);
+  return write_lane<(R & 3) + 8 * (R >> 2) + 4>(wv, (uint32_t)(ballot >> 32));
+}
+// the 16 ballots of one block -> lane `key` of wv (compile-time register indices need an unrolled chain)
+template <int I>
+struct BitsPut {
+  static __device__ __forceinline__ uint32_t run(uint32_t wv, const unsigned long long (&bal)[16]) {
+    return bits_put<I>(BitsPut<I - 1>::run(wv, bal), bal[I]);
+  }
+};
+template <>
+struct BitsPut<-1> {
+  static __device__ __forceinline__ uint32_t run(uint32_t wv, const unsigned long long (&)[16]) { return wv; }
 };
 
 #ifdef PETR_DIAG_CLOCK   // diagnostic build only (scripts/diag_clock.cpp): in-kernel clock of the main loop
@@ -307,11 +334,19 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
     }
     if (DROP) {
       // accumulator registers (2i, 2i+1) hold the keys (2j, 2j+1) of one column pair: one hash per two probabilities
+      unsigned long long bal[16];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const uint32_t hsh = drop_pair_hash(drop_rk, (uint32_t)(k0 + kh * 32 + mfma32_row(2 * i, h)) >> 1);
-        S[2 * i] = (hsh & 0xFFFFu) >= p.drop.thr ? S[2 * i] : 0.f;
-        S[2 * i + 1] = (hsh >> 16) >= p.drop.thr ? S[2 * i + 1] : 0.f;
+        const bool k0b = (hsh & 0xFFFFu) >= p.drop.thr, k1b = (hsh >> 16) >= p.drop.thr;
+        S[2 * i] = k0b ? S[2 * i] : 0.f;
+        S[2 * i + 1] = k1b ? S[2 * i + 1] : 0.f;
+        bal[2 * i] = __builtin_amdgcn_ballot_w64(k0b);
+        bal[2 * i + 1] = __builtin_amdgcn_ballot_w64(k1b);
+      }
+      if (p.drop_bits) {             // wave-uniform: leave the mask for the backward (it then tests bits instead of hashing)
+        const uint32_t wv = BitsPut<15>::run(0u, bal);
+        if (lane < 32) p.drop_bits[((long)bh * p.nqt32 + (qb * 4 + qg)) * p.lpad + (k0 + kh * 32) + lane] = wv;
       }
     }
 #endif
@@ -523,6 +558,7 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_bf16_kernel(const MhaFwdParams
 #ifndef PETR_DIAG_BF16_NO_BARRIER
     __syncthreads();   // image `buf` is complete; every wave is done reading the other one
 #endif
+    const int kw = kh * 64;     // this wave's keys inside the tile
 #ifndef PETR_DIAG_BF16_NO_STAGE
     lstore(k0 + BT, buf ^ 1, g);     // unconditional as well (after the last tile: into the image nobody reads any more)
     gload(k_base + min(it + 1 + PF, n_tiles - 1) * BT, g);
@@ -530,7 +566,6 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_bf16_kernel(const MhaFwdParams
     const uint16_t* Ks = smem16 + buf * BIMG;
     const uint16_t* Vt = Ks + BT * BK_PITCH;
     const bool use_bias = HAS_MASK || (k0 + BT > k_end);
-    const int kw = kh * 64;     // this wave's keys inside the tile
     if (wave_active && k0 + kw < k_end) {
       uint4 kfr[2][2];
 #pragma unroll
@@ -618,13 +653,22 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_bf16_kernel(const MhaFwdParams
 #endif
       if (DROP) {
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
+        for (int sb = 0; sb < 2; ++sb) {
+          unsigned long long bal[16];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const uint32_t hsh = drop_pair_hash(drop_rk, (uint32_t)(k0 + kw + 32 * sb + mfma32_row(2 * i, h)) >> 1);
-            S[sb][2 * i] = (hsh & 0xFFFFu) >= p.drop.thr ? S[sb][2 * i] : 0.f;
-            S[sb][2 * i + 1] = (hsh >> 16) >= p.drop.thr ? S[sb][2 * i + 1] : 0.f;
+            const bool k0b = (hsh & 0xFFFFu) >= p.drop.thr, k1b = (hsh >> 16) >= p.drop.thr;
+            S[sb][2 * i] = k0b ? S[sb][2 * i] : 0.f;
+            S[sb][2 * i + 1] = k1b ? S[sb][2 * i + 1] : 0.f;
+            bal[2 * i] = __builtin_amdgcn_ballot_w64(k0b);
+            bal[2 * i + 1] = __builtin_amdgcn_ballot_w64(k1b);
           }
+          if (p.drop_bits && k0 + kw + 32 * sb < p.lpad) {      // wave-uniform: the mask for the backward, key-major
+            const uint32_t wv = BitsPut<15>::run(0u, bal);
+            if (lane < 32) p.drop_bits[((long)bh * p.nqt32 + (qb * 4 + qg)) * p.lpad + (k0 + kw + 32 * sb) + lane] = wv;
+          }
+        }
       }
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb)
@@ -787,6 +831,9 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
   p.n_tiles = tiles;
   p.n_sub = (int)cdiv(a.L, 32);   // ns <= tiles <= n_sub: every static range owns at least one 32-key half tile
   p.sched = ns > 1 ? a.sched : nullptr;
+  p.drop_bits = a.drop.p > 0.f ? a.drop_bits : nullptr;
+  p.nqt32 = (int)cdiv(a.Q, 32);
+  p.lpad = 32 * (int)cdiv(a.L, 32);
   PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "mha_fwd: dropout p=%g outside [0,1)", (double)a.drop.p);
   PETR_CHECK((long)a.B * a.H * a.Q < (1L << 32), PETR_ERR_UNSUPPORTED, "mha_fwd: dropout row index needs B*H*Q < 2^32");
   p.drop = make_drop(a.drop);
@@ -876,6 +923,9 @@ extern "C" int petr_mha_fwd_bf16(const petr_mha_fwd_bf16_args* ap, void* stream)
   p.n_tiles = (int)cdiv(a.L, BT);
   p.n_tickets = 0;
   p.sched = nullptr;
+  p.drop_bits = a.drop.p > 0.f ? a.drop_bits : nullptr;
+  p.nqt32 = (int)cdiv(a.Q, 32);
+  p.lpad = 32 * (int)cdiv(a.L, 32);
   PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "mha_fwd_bf16: dropout p=%g outside [0,1)", (double)a.drop.p);
   PETR_CHECK((long)a.B * a.H * a.Q < (1L << 32), PETR_ERR_UNSUPPORTED, "mha_fwd_bf16: dropout row index needs B*H*Q < 2^32");
   p.drop = make_drop(a.drop);

@@ -371,6 +371,62 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(DropDev d, long rows,
 }
 }  // namespace
 
+namespace {
+// Packed attention-dropout masks (see petr_dropout_bits in petr_hip.h).  One wave = one 32 query x 32 key tile: lane
+// (q = lane & 31, half = lane >> 5) evaluates the 16 keys 16 half .. + 15 of its row with eight pair hashes (the same
+// function, hence the same mask, as drop_keep); the per-key ballots are the key-major words, the per-lane bit strings
+// the query-major ones.
+__global__ __launch_bounds__(256) void dropout_bits_kernel(DropDev d, int BH, int Q, int L, int nqt, int nkb, uint32_t* bits_q,
+                                                           uint32_t* bits_k) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int kb_groups = (nkb + 3) >> 2;
+  int w = blockIdx.x;
+  const int kbg = w % kb_groups;
+  w /= kb_groups;
+  const int qt = w % nqt, bh = w / nqt;
+  const int kb = 4 * kbg + wave;
+  if (kb >= nkb) return;                                  // wave-uniform
+  const int q = 32 * qt + (lane & 31), half = lane >> 5;
+  const uint32_t rk = drop_row_key(d, (uint32_t)(bh * Q + min(q, Q - 1)));
+  uint32_t mine = 0u, colw = 0u;                            // this lane's 16 key bits; (lanes 0..31) the word of key `lane`
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t col = (uint32_t)(32 * kb + 16 * half + 2 * j);
+    const uint32_t hsh = drop_pair_hash(rk, col >> 1);
+    const bool k0 = (hsh & 0xFFFFu) >= d.thr, k1 = (hsh >> 16) >= d.thr;
+    mine |= (k0 ? 1u : 0u) << (2 * j) | (k1 ? 1u : 0u) << (2 * j + 1);
+    const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);       // low word: half 0 (key 2j), high word: half 1 (16 + 2j)
+    colw = (lane == 2 * j) ? (uint32_t)b0 : colw;
+    colw = (lane == 16 + 2 * j) ? (uint32_t)(b0 >> 32) : colw;
+    colw = (lane == 2 * j + 1) ? (uint32_t)b1 : colw;
+    colw = (lane == 16 + 2 * j + 1) ? (uint32_t)(b1 >> 32) : colw;
+  }
+  const uint32_t other = __shfl_xor(mine, 32, 64);
+  if (lane < 32) {
+    const long tile = ((long)bh * nkb + kb) * (32L * nqt) + q;                 // query-major: [bh][kb][q]
+    if (bits_q) bits_q[tile] = mine | (other << 16);
+    if (bits_k) bits_k[((long)bh * nqt + qt) * (32L * nkb) + 32 * kb + lane] = colw;   // key-major: [bh][qt][key]
+  }
+}
+}  // namespace
+
+extern "C" size_t petr_dropout_bits_words(int BH, int Q, int L) {
+  return (size_t)BH * (size_t)cdiv(L, 32) * 32 * (size_t)cdiv(Q, 32);
+}
+
+extern "C" int petr_dropout_bits(const petr_dropout* d, int BH, int Q, int L, uint32_t* bits_q, uint32_t* bits_k, void* stream) {
+  PETR_CHECK(d && (bits_q || bits_k) && BH > 0 && Q > 0 && L > 0, PETR_ERR_INVALID, "dropout_bits: bad arguments");
+  PETR_CHECK(d->p > 0.f && d->p < 1.f, PETR_ERR_INVALID, "dropout_bits: p=%g outside (0,1)", (double)d->p);
+  PETR_CHECK((long)BH * Q < (1L << 32), PETR_ERR_UNSUPPORTED, "dropout_bits: row index needs B*H*Q < 2^32");
+  const int nqt = (int)cdiv(Q, 32), nkb = (int)cdiv(L, 32);
+  const long blocks = (long)BH * nqt * cdiv(nkb, 4);
+  PETR_CHECK(blocks < (1L << 31), PETR_ERR_UNSUPPORTED, "dropout_bits: grid too large");
+  hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, make_drop(*d), BH, Q, L, nqt,
+                     nkb, bits_q, bits_k);
+  PETR_LAUNCH_CHECK("dropout_bits");
+  return PETR_OK;
+}
+
 extern "C" int petr_dropout_mask(const petr_dropout* d, long rows, long cols, uint8_t* keep, void* stream) {
   PETR_CHECK(d && keep && rows > 0 && cols > 0 && rows < (1L << 32) && cols < (1L << 32), PETR_ERR_INVALID,
              "dropout_mask: bad arguments");

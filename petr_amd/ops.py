@@ -117,6 +117,18 @@ def dropout_mask(drop, rows, cols, device='cuda'):
     return keep.bool()
 
 
+def dropout_bits(drop, BH, Q, L, device='cuda'):
+    """The attention-dropout mask of ``dropout_mask(drop, BH * Q, L)`` packed for the attention kernels:
+    (query-major words for ``mha_fwd*``, key-major words for ``mha_bwd*``), both int32 [petr_dropout_bits_words]."""
+    Lb = _C.lib()
+    n = Lb.petr_dropout_bits_words(BH, Q, L)
+    bq = torch.empty(n, dtype=torch.int32, device=device)
+    bk = torch.empty(n, dtype=torch.int32, device=device)
+    d = _C.dropout(drop)
+    _C.check(Lb.petr_dropout_bits(C.byref(d), BH, Q, L, _ptr(bq), _ptr(bk), _stream()), 'petr_dropout_bits')
+    return bq, bk
+
+
 def conv1x1(x, w, bias=None, relu=False, out=None, accumulate=False):
     """x [V, C_in, HW] (NCHW views) -> token-major [V*HW, C_out]; w [C_out, C_in]."""
     V, Cin, HW = x.shape
@@ -184,7 +196,7 @@ def _bhsd(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
-def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True, dynamic=False, drop=None):
+def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True, dynamic=False, drop=None, drop_bits=None):
     """softmax(scale q k^T + mask) v for [B,H,S,32] (strided) views.  Returns (o [B,H,Q,32], lse [B,H,Q]).
     ``dynamic``: the L-split workers draw K/V tiles from per-query-block ticket counters (zeroed here)."""
     L = _C.lib()
@@ -199,7 +211,7 @@ def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True
     kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
     sched = torch.zeros(B * H * ((Q + 127) // 128), dtype=torch.int32, device=q.device) if dynamic else None
     a = _C.MhaFwdArgs(_ptr(_f32(q)), *_bhsd(q), _ptr(_f32(k)), *_bhsd(k), _ptr(_f32(v)), *_bhsd(v), _ptr(o), *_bhsd(o),
-                      _ptr(lse), _ptr(kpm), B, H, Q, Lk, scale, ns, _ptr(ws), nbytes, _C.dropout(drop), _ptr(sched))
+                      _ptr(lse), _ptr(kpm), B, H, Q, Lk, scale, ns, _ptr(ws), nbytes, _C.dropout(drop), _ptr(sched), _ptr(drop_bits))
     _C.check(L.petr_mha_fwd(C.byref(a), _stream()), 'petr_mha_fwd')
     return o, lse
 
@@ -213,7 +225,7 @@ def cast_bf16(x):
     return y
 
 
-def mha_fwd_bf16(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True, drop=None):
+def mha_fwd_bf16(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True, drop=None, drop_bits=None):
     """``mha_fwd`` with bfloat16 K/V ([B,H,L,32] strided views), fp32 Q / output / softmax (BASELINE configs 3-5)."""
     L = _C.lib()
     assert k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16, 'mha_fwd_bf16: K and V must be bfloat16'
@@ -226,12 +238,12 @@ def mha_fwd_bf16(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse
     ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=q.device)
     kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
     a = _C.MhaFwdArgs(_ptr(_f32(q)), *_bhsd(q), _ptr(k), *_bhsd(k), _ptr(v), *_bhsd(v), _ptr(o), *_bhsd(o),
-                      _ptr(lse), _ptr(kpm), B, H, Q, Lk, scale, n_split, _ptr(ws), nbytes, _C.dropout(drop), None)
+                      _ptr(lse), _ptr(kpm), B, H, Q, Lk, scale, n_split, _ptr(ws), nbytes, _C.dropout(drop), None, _ptr(drop_bits))
     _C.check(L.petr_mha_fwd_bf16(C.byref(a), _stream()), 'petr_mha_fwd_bf16')
     return o, lse
 
 
-def mha_bwd(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=None):
+def mha_bwd(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=None, drop_bits=None):
     L = _C.lib()
     B, H, Q, _ = q.shape
     Lk = k.shape[2]
@@ -244,12 +256,13 @@ def mha_bwd(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=None):
     kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
     a = _C.MhaBwdArgs(_ptr(_f32(q)), *_bhsd(q), _ptr(_f32(k)), *_bhsd(k), _ptr(_f32(v)), *_bhsd(v), _ptr(_f32(o)), *_bhsd(o),
                       _ptr(_f32(do)), *_bhsd(do), _ptr(lse), _ptr(kpm), _ptr(dq), *_bhsd(dq), _ptr(dk), *_bhsd(dk),
-                      _ptr(dv), *_bhsd(dv), B, H, Q, Lk, scale, _ptr(ws), nbytes, _C.dropout(drop))
+                      _ptr(dv), *_bhsd(dv), B, H, Q, Lk, scale, _ptr(ws), nbytes, _C.dropout(drop), _ptr(drop_bits))
     _C.check(L.petr_mha_bwd(C.byref(a), _stream()), 'petr_mha_bwd')
     return dq, dk, dv
 
 
-def mha_bwd_bf16(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=None, overwrite=False, dkv_bf16=False):
+def mha_bwd_bf16(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=None, overwrite=False, dkv_bf16=False,
+                 drop_bits=None):
     """``mha_bwd`` with bfloat16 K/V ([B,H,L,32] strided views): the gradient of ``mha_fwd_bf16``; fp32 dq, dk, dv.
     ``overwrite``: dk / dv are stored into UNINITIALISED buffers (``dkv_overwrite``) instead of accumulated into zeros."""
     L = _C.lib()
@@ -268,7 +281,7 @@ def mha_bwd_bf16(q, k, v, o, do, lse, key_padding_mask=None, scale=None, drop=No
     kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
     a = _C.MhaBwdBf16Args(_ptr(_f32(q)), *_bhsd(q), _ptr(k), *_bhsd(k), _ptr(v), *_bhsd(v), _ptr(_f32(o)), *_bhsd(o),
                           _ptr(_f32(do)), *_bhsd(do), _ptr(lse), _ptr(kpm), _ptr(dq), *_bhsd(dq), _ptr(dk), *_bhsd(dk),
-                          _ptr(dv), *_bhsd(dv), B, H, Q, Lk, scale, None, 0, _C.dropout(drop), int(overwrite), int(dkv_bf16))
+                          _ptr(dv), *_bhsd(dv), B, H, Q, Lk, scale, None, 0, _C.dropout(drop), _ptr(drop_bits), int(overwrite), int(dkv_bf16))
     _C.check(L.petr_mha_bwd_bf16(C.byref(a), _stream()), 'petr_mha_bwd_bf16')
     return dq, dk, dv
 

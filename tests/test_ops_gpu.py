@@ -699,3 +699,55 @@ def test_gemm_bf16_sources(ops):
                  alpha=1.0, nb0=1, nb1=1)
     assert relerr(dw, _bf(dy).T @ _bf(x)) < 3e-5
     assert relerr(db, _bf(dy).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize('BH,Q,L', [(8, 900, 4224), (3, 70, 333), (2, 31, 65), (1, 1, 1), (4, 129, 513)])
+def test_dropout_bits_are_the_packed_mask(ops, BH, Q, L):
+    """petr_dropout_bits: both packed layouts hold exactly the mask of petr_dropout_mask (row = bh*Q + q, col = key)."""
+    drop = (77, 5, 0.1)
+    keep = ops.dropout_mask(drop, BH * Q, L).view(BH, Q, L).cpu()
+    bq, bk = ops.dropout_bits(drop, BH, Q, L)
+    nqt, nkb = (Q + 31) // 32, (L + 31) // 32
+    sh = torch.arange(32, dtype=torch.int64)
+    wq = bq.cpu().to(torch.int64).bitwise_and(0xFFFFFFFF).view(BH, nkb, 32 * nqt)        # [bh][kb][q]: bit j = key 32 kb + j
+    got_q = ((wq[..., None] >> sh) & 1).permute(0, 2, 1, 3).reshape(BH, 32 * nqt, 32 * nkb)[:, :Q, :L].bool()
+    assert torch.equal(got_q, keep)
+    wk = bk.cpu().to(torch.int64).bitwise_and(0xFFFFFFFF).view(BH, nqt, 32 * nkb)        # [bh][qt][key]: bit i = row 32 qt + i
+    got_k = ((wk[..., None] >> sh) & 1).permute(0, 1, 3, 2).reshape(BH, 32 * nqt, 32 * nkb)[:, :Q, :L].bool()
+    assert torch.equal(got_k, keep)
+
+
+@pytest.mark.parametrize('B,H,Q,L,split,masked', [(1, 8, 900, 4224, 0, False), (2, 3, 70, 333, 3, True), (1, 2, 31, 65, 2, False),
+                                                   (1, 8, 900, 900, 0, False), (1, 4, 129, 513, 8, True)])
+def test_attention_backward_reads_the_mask_the_forward_left(ops, B, H, Q, L, split, masked):
+    """The forward kernels (fp32 and bf16 K/V) leave the dropout mask they applied as packed key-major bits: exactly the
+    words of petr_dropout_bits wherever a (query tile, key) exists; the backward that tests those bits returns what the
+    re-hashing backward returns (same mask, same arithmetic; float atomics reorder the last bit)."""
+    g = torch.Generator().manual_seed(Q * 7 + L)
+    q, k, v, do = (dev(torch.randn(B, H, n, 32, generator=g)) for n in (Q, L, L, Q))
+    kpm = None
+    if masked:
+        kpm = torch.zeros(B, L, dtype=torch.bool)
+        kpm[:, L - L // 4:] = True
+        kpm = dev(kpm)
+    drop = (4321, 9, 0.1)
+    _, want_k = ops.dropout_bits(drop, B * H, Q, L)
+    nqt, nkb = (Q + 31) // 32, (L + 31) // 32
+    valid = torch.zeros(B * H, nqt, 32 * nkb, dtype=torch.bool)
+    valid[:, :, :L] = True                                   # keys beyond L are never produced
+    rowmask = torch.full((nqt,), -1, dtype=torch.int64)      # rows beyond Q: bits undefined
+    if Q % 32:
+        rowmask[-1] = (1 << (Q % 32)) - 1
+    kb, vb = ops.cast_bf16(k), ops.cast_bf16(v)
+    for fwd, bwd, kk, vv in ((ops.mha_fwd, ops.mha_bwd, k, v), (ops.mha_fwd_bf16, ops.mha_bwd_bf16, kb, vb)):
+        bits = torch.zeros_like(want_k)
+        o0, l0 = fwd(q, kk, vv, kpm, n_split=split, drop=drop)
+        o1, l1 = fwd(q, kk, vv, kpm, n_split=split, drop=drop, drop_bits=bits)
+        assert torch.equal(o0, o1) and torch.equal(l0, l1)
+        got = bits.cpu().view(B * H, nqt, 32 * nkb).to(torch.int64) & rowmask[None, :, None]
+        ref = want_k.cpu().view(B * H, nqt, 32 * nkb).to(torch.int64) & rowmask[None, :, None]
+        assert torch.equal(got[valid], ref[valid])
+        g0 = bwd(q, kk, vv, o0, do, l0, kpm, drop=drop)
+        g1 = bwd(q, kk, vv, o0, do, l0, kpm, drop=drop, drop_bits=bits)
+        for a, b in zip(g0, g1):
+            assert (a - b).abs().max().item() <= 1e-5 * (1 + a.abs().max().item())

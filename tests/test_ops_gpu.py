@@ -95,6 +95,10 @@ def test_sine3d(ops, golden_dir):
     got0 = ops.sine3d(None, dev(dim_t), 1, 6, 16, 44)
     want0 = O.sine_positional_encoding_3d(torch.zeros(1, 6, 16, 44, dtype=torch.bool), 128, normalize=True)
     assert (got0.cpu() - want0).abs().max().item() < 2e-6
+    # the per-row kernel of the unmasked case returns the bits of the general (masked) kernel run on an all-zero mask
+    for shape in ((1, 6, 16, 44), (2, 3, 40, 100), (1, 2, 5, 7)):
+        zero = torch.zeros(shape, dtype=torch.bool)
+        assert torch.equal(ops.sine3d(None, dev(dim_t), *shape), ops.sine3d(dev(zero), dev(dim_t), *shape))
 
 
 def test_posemb3d_fwd_bwd(ops, golden_dir):

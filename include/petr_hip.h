@@ -101,9 +101,12 @@ typedef struct { uint64_t seed; uint32_t site; float p; } petr_dropout;
 int petr_dropout_mask(const petr_dropout* d, long rows, long cols, uint8_t* keep, void* stream);
 /* The same mask packed for ONE attention call (row = bh*Q + q, col = key; BH = B*H):
  *   bits_q[(bh * nkb + kb) * 32 nqt + q]   bit j = keep(q, 32 kb + j)   query-major
- *   bits_k[(bh * nqt + qt) * 32 nkb + k]   bit i = keep(32 qt + i, k)   key-major: the layout petr_mha_fwd* leaves in its
- *                                          drop_bits and petr_mha_bwd* reads (the key sits on the lane there), so that the
- *                                          backward tests a bit instead of re-hashing (~20 % of its time at 24 000 keys)
+ *   bits_k[(bh * nqt + qt) * 32 nkb + 32 kb + slot(c)]   bit i = keep(32 qt + i, 32 kb + c)   key-major, the 32 words of a
+ *                                          key block in the order the forward's comparisons produce them:
+ *                                          slot(c) = 2 ((c & 3) + 4 (c >> 3)) + ((c >> 2) & 1).  This is what petr_mha_fwd*
+ *                                          leaves in its drop_bits (scalar stores of the comparison masks, no vector work)
+ *                                          and petr_mha_bwd* reads (the key sits on the lane there), so that the backward
+ *                                          tests a bit instead of re-hashing (~20 % of its time at 24 000 keys)
  * nqt = ceil(Q/32), nkb = ceil(L/32); each layout holds petr_dropout_bits_words(BH, Q, L) uint32_t; either may be NULL.
  * (Generating the masks with this kernel ahead of the attention calls, so that the forward tests bits too, was measured:
  * it costs what it saves - the generator is as much VALU work as the hashing it replaces.) */

@@ -119,6 +119,10 @@ __device__ __forceinline__ bool drop_keep(uint32_t row_key, uint32_t col, uint32
   return ((col & 1u) ? (hsh >> 16) : (hsh & 0xFFFFu)) >= thr;
 }
 
+// position of key c (0..31) inside a 32-word block of the packed key-major dropout mask: the order in which the forward's
+// accumulator ballots fall (register r, lane half) - see petr_dropout_bits in petr_hip.h
+__host__ __device__ __forceinline__ int petr_bits_slot(int c) { return 2 * ((c & 3) + 4 * (c >> 3)) + ((c >> 2) & 1); }
+
 #define PETR_CHECK(cond, code, ...)     \
   do {                                  \
     if (!(cond)) {                      \

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
       oreg = make_float4(o[0], o[1], o[2], o[3]);
     }
     lreg = a.lse[(long)bh * a.Q + qt * 32 + lo];
-    if (use_bits) dnext = p.drop_bits[((long)bh * p.nqt32 + qt) * p.lpad + key_ld];
+    if (use_bits) dnext = p.drop_bits[((long)bh * p.nqt32 + qt) * p.lpad + min(key0, p.lpad - 32) + petr_bits_slot(c)];
   };
 
   int dq_off[4];   // element (row, d) = (idx >> 5, idx & 31) of the 32 x 32 dQ tile, idx = t + 256 j

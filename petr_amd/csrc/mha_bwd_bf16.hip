@@ -200,8 +200,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mha_bwd_bf16_kernel(
   auto gload = [&](int qt) {
     if (use_bits) {       // the mask words of the workgroup's keys for this query tile travel with the tile (stager waves:
 #pragma unroll            // the flusher waves' vector-memory queue holds atomics only)
-      for (int i = 0; i < KT; ++i)
-        breg[i] = p.drop_bits[((long)bh * p.nqt32 + qt) * p.lpad + min(kb * (NW * 32 * KT) + (t & (NS - 1)) + NS * i, a.L - 1)];
+      for (int i = 0; i < KT; ++i) {
+        const int kidx = kb * (NW * 32 * KT) + (t & (NS - 1)) + NS * i;          // this thread's key: block kidx >> 5, slot of kidx & 31
+        breg[i] = p.drop_bits[((long)bh * p.nqt32 + qt) * p.lpad + min(kidx & ~31, p.lpad - 32) + petr_bits_slot(kidx & 31)];
+      }
     }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {

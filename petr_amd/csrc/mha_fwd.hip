@@ -43,30 +43,26 @@ struct MhaFwdParams {
   int nqt32, lpad;       // its dimensions: ceil(Q/32) query tiles, 32 * ceil(L/32) keys per tile
 };
 
-// The keep decisions of one 32 query x 32 key block, as the backward wants them (key on the lane): the ballot of
-// accumulator register r holds, in its low / high word, the 32 queries' bits for key mfma32_row(r, 0) / (r, 1); collected
-// into lane `key` of one register (v_writelane), the block is one 128-byte store.
-template <int LANE>
-__device__ __forceinline__ uint32_t write_lane(uint32_t wv, uint32_t uniform) {
-  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(wv) : "s"(uniform), "n"(LANE));
-  return wv;
-}
+// The keep decisions of one 32 query x 32 key block leave the kernel as they fall out of the comparisons: the ballot of
+// accumulator register r (an SGPR pair) holds, in its low / high word, the 32 queries' bits for key mfma32_row(r, 0) /
+// (r, 1) of the block.  They are written with SCALAR stores - no vector instruction is spent on them (collecting them in
+// a vector register with v_writelane cost the forward 3-5 %) - as 16 x 2 words per block: word 2 r + half of block
+// (query tile, key block) = key (r & 3) + 8 (r >> 2) + 4 half, i.e. key c sits at petr_bits_slot(c) (petr_hip.h).
+// Scalar stores go through the scalar data cache: every wave writes it back (s_dcache_wb) before it ends.
 template <int R>
-__device__ __forceinline__ uint32_t bits_put(uint32_t wv, unsigned long long ballot) {
-  wv = write_lane<(R & 3) + 8 * (R >> 2)>(wv, (uint32_t)ballot);
-  return write_lane<(R & 3) + 8 * (R >> 2) + 4>(wv, (uint32_t)(ballot >> 32));
+__device__ __forceinline__ void bits_sstore(unsigned long long base, unsigned long long bal) {
+  asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(bal), "s"(base), "n"(8 * R) : "memory");
 }
-// the 16 ballots of one block -> lane `key` of wv (compile-time register indices need an unrolled chain)
-template <int I>
-struct BitsPut {
-  static __device__ __forceinline__ uint32_t run(uint32_t wv, const unsigned long long (&bal)[16]) {
-    return bits_put<I>(BitsPut<I - 1>::run(wv, bal), bal[I]);
-  }
-};
-template <>
-struct BitsPut<-1> {
-  static __device__ __forceinline__ uint32_t run(uint32_t wv, const unsigned long long (&)[16]) { return wv; }
-};
+__device__ __forceinline__ void bits_store_block(uint32_t* block, const unsigned long long (&bal)[16]) {
+  const unsigned long long a = (unsigned long long)block;
+  // (readfirstlane returns a signed int: widen through uint32_t, or a low half with bit 31 set smears over the high half)
+  const unsigned long long base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) |
+                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  bits_sstore<0>(base, bal[0]);   bits_sstore<1>(base, bal[1]);   bits_sstore<2>(base, bal[2]);    bits_sstore<3>(base, bal[3]);
+  bits_sstore<4>(base, bal[4]);   bits_sstore<5>(base, bal[5]);   bits_sstore<6>(base, bal[6]);    bits_sstore<7>(base, bal[7]);
+  bits_sstore<8>(base, bal[8]);   bits_sstore<9>(base, bal[9]);   bits_sstore<10>(base, bal[10]);  bits_sstore<11>(base, bal[11]);
+  bits_sstore<12>(base, bal[12]); bits_sstore<13>(base, bal[13]); bits_sstore<14>(base, bal[14]);  bits_sstore<15>(base, bal[15]);
+}
 
 #ifdef PETR_DIAG_CLOCK   // diagnostic build only (scripts/diag_clock.cpp): in-kernel clock of the main loop
 __device__ unsigned long long g_diag[4 * 4 * 4096];   // per wave: cycles, realtime ticks, tiles | active<<32, hw_id | xcc_id<<32
@@ -344,10 +340,8 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
         bal[2 * i] = __builtin_amdgcn_ballot_w64(k0b);
         bal[2 * i + 1] = __builtin_amdgcn_ballot_w64(k1b);
       }
-      if (p.drop_bits) {             // wave-uniform: leave the mask for the backward (it then tests bits instead of hashing)
-        const uint32_t wv = BitsPut<15>::run(0u, bal);
-        if (lane < 32) p.drop_bits[((long)bh * p.nqt32 + (qb * 4 + qg)) * p.lpad + (k0 + kh * 32) + lane] = wv;
-      }
+      if (p.drop_bits)               // wave-uniform: leave the mask for the backward (it then tests bits instead of hashing)
+        bits_store_block(p.drop_bits + ((long)bh * p.nqt32 + (qb * 4 + qg)) * p.lpad + (k0 + kh * 32), bal);
     }
 #endif
 #pragma unroll
@@ -370,6 +364,7 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   }
 #endif
 
+  if (DROP && p.drop_bits) asm volatile("s_dcache_wb" ::: "memory");     // the scalar-stored mask words leave the scalar cache
   // ---- merge the two key halves of each query group (upper wave -> LDS -> lower wave) ----
   __syncthreads();   // every wave is done with the K/V images
   float* mo = smem + (qg * 64 + lane) * MERGE_PITCH;
@@ -664,10 +659,8 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_bf16_kernel(const MhaFwdParams
             bal[2 * i] = __builtin_amdgcn_ballot_w64(k0b);
             bal[2 * i + 1] = __builtin_amdgcn_ballot_w64(k1b);
           }
-          if (p.drop_bits && k0 + kw + 32 * sb < p.lpad) {      // wave-uniform: the mask for the backward, key-major
-            const uint32_t wv = BitsPut<15>::run(0u, bal);
-            if (lane < 32) p.drop_bits[((long)bh * p.nqt32 + (qb * 4 + qg)) * p.lpad + (k0 + kw + 32 * sb) + lane] = wv;
-          }
+          if (p.drop_bits && k0 + kw + 32 * sb < p.lpad)        // wave-uniform: the mask for the backward
+            bits_store_block(p.drop_bits + ((long)bh * p.nqt32 + (qb * 4 + qg)) * p.lpad + (k0 + kw + 32 * sb), bal);
         }
       }
 #pragma unroll
@@ -703,6 +696,7 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_bf16_kernel(const MhaFwdParams
   }
   if (!DROP) l_run = Lacc[0];
 
+  if (DROP && p.drop_bits) asm volatile("s_dcache_wb" ::: "memory");     // the scalar-stored mask words leave the scalar cache
   // ---- merge the two key halves of each query group (upper wave -> LDS -> lower wave) ----
   float* smem = reinterpret_cast<float*>(smem16);
   __syncthreads();

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void dropout_bits_kernel(DropDev d, int BH, in
   if (lane < 32) {
     const long tile = ((long)bh * nkb + kb) * (32L * nqt) + q;                 // query-major: [bh][kb][q]
     if (bits_q) bits_q[tile] = mine | (other << 16);
-    if (bits_k) bits_k[((long)bh * nqt + qt) * (32L * nkb) + 32 * kb + lane] = colw;   // key-major: [bh][qt][key]
+    if (bits_k) bits_k[((long)bh * nqt + qt) * (32L * nkb) + 32 * kb + petr_bits_slot(lane)] = colw;   // key-major: [bh][qt][block][slot]
   }
 }
 }  // namespace

@@ -716,7 +716,9 @@ def test_dropout_bits_are_the_packed_mask(ops, BH, Q, L):
     wq = bq.cpu().to(torch.int64).bitwise_and(0xFFFFFFFF).view(BH, nkb, 32 * nqt)        # [bh][kb][q]: bit j = key 32 kb + j
     got_q = ((wq[..., None] >> sh) & 1).permute(0, 2, 1, 3).reshape(BH, 32 * nqt, 32 * nkb)[:, :Q, :L].bool()
     assert torch.equal(got_q, keep)
-    wk = bk.cpu().to(torch.int64).bitwise_and(0xFFFFFFFF).view(BH, nqt, 32 * nkb)        # [bh][qt][key]: bit i = row 32 qt + i
+    c = torch.arange(32)
+    slot = 2 * ((c & 3) + 4 * (c >> 3)) + ((c >> 2) & 1)        # position of key c inside its 32-word block (petr_hip.h)
+    wk = bk.cpu().to(torch.int64).bitwise_and(0xFFFFFFFF).view(BH, nqt, nkb, 32)[..., slot].reshape(BH, nqt, 32 * nkb)
     got_k = ((wk[..., None] >> sh) & 1).permute(0, 1, 3, 2).reshape(BH, 32 * nqt, 32 * nkb)[:, :Q, :L].bool()
     assert torch.equal(got_k, keep)
 

@@ -116,7 +116,7 @@ __device__ __forceinline__ uint32_t drop_pair_hash(uint32_t row_key, uint32_t pa
 }
 __device__ __forceinline__ bool drop_keep(uint32_t row_key, uint32_t col, uint32_t thr) {
   const uint32_t hsh = drop_pair_hash(row_key, col >> 1);
-  return ((col & 1u) ? (hsh >> 16) : (hsh & 0xFFFFu)) >= thr;
+  return (uint16_t)((col & 1u) ? (hsh >> 16) : hsh) >= (uint16_t)thr;
 }
 
 // position of key c (0..31) inside a 32-word block of the packed key-major dropout mask: the order in which the forward's

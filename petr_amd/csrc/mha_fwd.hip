@@ -113,6 +113,7 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
   // the row sum l keeps the UNdropped probabilities (softmax first, dropout after), the 1/(1-p) is applied once
   // to the finished output
   const uint32_t drop_rk = DROP ? drop_row_key(p.drop, (uint32_t)(bh * a.Q + q_ld)) : 0u;
+  const uint16_t thr16 = (uint16_t)p.drop.thr;        // thr <= 65535 (make_drop)
 
   // Static ranges are cut at 32-key granularity (132 halves over 8 workers = 16/17 each at c5, not 9,9,...,3
   // tiles): the worker's tiles are 64-key steps from ITS first key and its last tile may be half (the half-tile
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_kernel(const MhaFwdParams p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const uint32_t hsh = drop_pair_hash(drop_rk, (uint32_t)(k0 + kh * 32 + mfma32_row(2 * i, h)) >> 1);
-        const bool k0b = (hsh & 0xFFFFu) >= p.drop.thr, k1b = (hsh >> 16) >= p.drop.thr;
+        const bool k0b = (uint16_t)hsh >= thr16, k1b = (uint16_t)(hsh >> 16) >= thr16;     // SDWA half-word compares: no extraction
         S[2 * i] = k0b ? S[2 * i] : 0.f;
         S[2 * i + 1] = k1b ? S[2 * i + 1] : 0.f;
         bal[2 * i] = __builtin_amdgcn_ballot_w64(k0b);
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_bf16_kernel(const MhaFwdParams
   const int q_ld = min(q_row, a.Q - 1);
   const bool wave_active = qb * 128 + qg * 32 < a.Q;
   const uint32_t drop_rk = DROP ? drop_row_key(p.drop, (uint32_t)(bh * a.Q + q_ld)) : 0u;
+  const uint16_t thr16 = (uint16_t)p.drop.thr;        // thr <= 65535 (make_drop)
 
   // static key ranges at 64-key granularity (one wave's share of a tile)
   const int base = p.n_sub / p.n_split, rem = p.n_sub - base * p.n_split;
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_bf16_kernel(const MhaFwdParams
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const uint32_t hsh = drop_pair_hash(drop_rk, (uint32_t)(k0 + kw + 32 * sb + mfma32_row(2 * i, h)) >> 1);
-            const bool k0b = (hsh & 0xFFFFu) >= p.drop.thr, k1b = (hsh >> 16) >= p.drop.thr;
+            const bool k0b = (uint16_t)hsh >= thr16, k1b = (uint16_t)(hsh >> 16) >= thr16;     // SDWA half-word compares: no extraction
             S[sb][2 * i] = k0b ? S[sb][2 * i] : 0.f;
             S[sb][2 * i + 1] = k1b ? S[sb][2 * i + 1] : 0.f;
             bal[2 * i] = __builtin_amdgcn_ballot_w64(k0b);

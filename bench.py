@@ -242,6 +242,7 @@ def extra_workload(workload, dev, num_query, steps, warmup):
             leg['mha_bwd_cross'] = {'mean_launch_us': us, 'achieved': round(ach, 2), 'frac': round(ach / peak, 4)}
         res[mode] = leg
     head.attn_dtype = 'fp32'
+    head.release()             # its side streams must not outlive it (the next workload's streams would share their queues)
     del head, feats, g_cls, g_box
     torch.cuda.empty_cache()
     return res
@@ -536,6 +537,7 @@ def main():
     workloads = None
     if rank == 0 and world == 1 and not args.fwd_only and not args.no_extra_workloads and args.workload == 'c5' \
             and args.batch == 1 and not args.eval_mode:
+        head.release()
         del head, feats, g_cls, g_box
         torch.cuda.empty_cache()
         workloads = {}

@@ -441,6 +441,18 @@ class PETRHead(nn.Module):
         st.pop('_grad_views', None)
         return st
 
+    def release(self):
+        """Give back the process-local GPU resources now: the side streams / events of the stream context and the pooled
+        workspaces.  The head stays usable (both are re-created on the next forward).  Streams that outlive their head
+        keep their hardware queues: a process that builds several heads one after the other (bench.py's workloads) should
+        not leave it to the garbage collector."""
+        ctx, self._ctx = getattr(self, '_ctx', None), None
+        if ctx is not None:
+            torch.cuda.synchronize()
+            _C.lib().petr_ctx_destroy(ctx)
+        self._runs, self._free_ws, self._rings = {}, {}, {}
+        self._last_run = None
+
     def __del__(self):
         ctx = getattr(self, '_ctx', None)
         if ctx is not None:

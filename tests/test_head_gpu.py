@@ -730,3 +730,21 @@ def test_head_autograd_guards_and_deepcopy(pa):
         twin.input_proj.weight.mul_(2.0)                      # independent storage
         c = head([feats], metas)
     assert torch.equal(a['all_cls_scores'], c['all_cls_scores'])
+
+
+def test_head_release_gives_back_streams_and_workspaces(pa):
+    """release(): the stream context and the pooled workspaces go away now (a process that builds several heads one after
+    the other must not leave live side streams behind - they would share hardware queues with the next head's), and the
+    head keeps working: the next forward re-creates both and returns the same bits (eval forward is reproducible)."""
+    oracle = O.seeded_head(2, 77, num_query=16)
+    head = make_pair(pa, oracle, num_query=16).eval()
+    metas = O.synthetic_img_metas(1, 2, (128, 192), (100, 150), seed=5)
+    feats = torch.randn(1, 2, 256, 4, 6, generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        a = head([feats], metas)
+        assert head._ctx is not None
+        head.release()
+        assert head._ctx is None and not head._runs and not head._free_ws
+        b = head([feats], metas)
+    assert head._ctx is not None
+    assert torch.equal(a['all_cls_scores'], b['all_cls_scores']) and torch.equal(a['all_bbox_preds'], b['all_bbox_preds'])

@@ -16,3 +16,7 @@ d=json.load(open('gpurun_out/final_bench_c5.json'))
 print('c5', d['value'], d['ms_per_step'], d['fwd_ms'], d['roofline']['frac'], d['bf16']['ms_per_step'])
 for n,w in d['workloads'].items(): print(n, w['fp32']['ms_per_step'], w['bf16']['ms_per_step'], w['bf16']['mha_bwd_cross'])
 "
+# one step of the headline and of the largest bf16 workload as per-queue timelines
+bash scripts/trace_step.sh c5 fp32 > /dev/null && python3 scripts/trace_print.py "gpurun_out/trace_c5_fp32/*/*kernel_trace.csv" > gpurun_out/final_trace_c5_fp32_step.txt
+bash scripts/trace_step.sh p4_1600 bf16 > /dev/null && python3 scripts/trace_print.py "gpurun_out/trace_p4_1600_bf16/*/*kernel_trace.csv" > gpurun_out/final_trace_p4_1600_bf16_step.txt
+tail -1 gpurun_out/final_trace_c5_fp32_step.txt; tail -1 gpurun_out/final_trace_p4_1600_bf16_step.txt

@@ -2,7 +2,7 @@
 # per-(kernel, grid) durations inside the bench's training steps (rocprofv3 kernel trace): bash scripts/step_breakdown.sh [bench args]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace -d /tmp/stepbd -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --fwd-only-off --steps 20 --warmup 5 "$@" > /tmp/stepbd.log 2>&1 || rocprofv3 --kernel-trace -d /tmp/stepbd -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 "$@" > /tmp/stepbd.log 2>&1
+rocprofv3 --kernel-trace -d /tmp/stepbd -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --timed-only --steps 20 --warmup 5 "$@" > /tmp/stepbd.log 2>&1
 f=$(find /tmp/stepbd -name '*kernel_trace.csv' | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections

@@ -253,6 +253,10 @@ typedef struct {
   uint32_t* drop_bits;   /* out, optional with drop.p > 0: petr_dropout_bits_words(B*H, Q, L) words; the kernel leaves the
                           * dropout mask it applied there, packed key-major (the bits_k layout of petr_dropout_bits), for
                           * petr_mha_bwd's drop_bits: the backward then tests one bit per probability instead of hashing it */
+  int defer_merge;       /* 1 (needs an explicit n_split and ws): with n_split > 1 the L-split partials stay in ws -
+                          * o_part [n_split][B*H][Q][32] floats, then ml_part [n_split][B*H][Q][2] (running maximum in
+                          * log2 units, sum) - and o / lse are NOT written: the consumer merges them
+                          * (petr_attn_out_ln does, in its prologue).  n_split == 1 writes o / lse as always. */
 } petr_mha_fwd_args;
 size_t petr_mha_fwd_workspace_bytes(int B, int H, int Q, int L, int n_split);
 int petr_mha_choose_split(int B, int H, int Q, int L);
@@ -277,9 +281,40 @@ typedef struct {
   petr_dropout drop;
   int* sched;
   uint32_t* drop_bits;   /* as petr_mha_fwd_args.drop_bits */
+  int defer_merge;       /* as petr_mha_fwd_args.defer_merge */
 } petr_mha_fwd_bf16_args;
 size_t petr_mha_fwd_bf16_workspace_bytes(int B, int H, int Q, int L, int n_split);
+int petr_mha_fwd_bf16_choose_split(int B, int H, int Q, int L);   /* what n_split = 0 selects */
 int petr_mha_fwd_bf16(const petr_mha_fwd_bf16_args* a, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Attention output block of a decoder layer in ONE launch (C = 256 = 8 heads x 32):
+ *     ao = merge of the attention's L-split partials (or the attention output itself)
+ *     z  = drop(ao W^T + bias) + residual ,  y = LayerNorm(z) * gamma + beta ,  y2 = y + add2 (optional),
+ *     out2 = y2 W2^T + bias2 (optional: the next attention's query projection)
+ *   replaces, per attention of petr_transformer.py:357-367 / mmcv MultiheadAttention + the following norm of
+ *   multi_atten_decoder_layer.py:204-293, FOUR launches of the 900-row chain: the partial merge, the out-projection
+ *   contraction (+ residual), and the LayerNorm (+ dropout, + query_pos add).  One workgroup owns 16 full rows: merge
+ *   -> LDS, 16 x 256 x 256 on v_mfma_f32_16x16x4_f32 with W streamed from L2, row statistics across the eight waves.
+ *   a: [M, 256] attention output when n_split <= 1; else it is WRITTEN with the merged output (the backward needs it) from
+ *   o_part / ml_part (layout: petr_mha_fwd_args.defer_merge), lse [B*H*Q] is written too, attn_scale = the attention
+ *   dropout's 1/(1-p) (1 without).  rows m = b*Q + q.  z, mean, rstd are written when non-NULL (training needs them).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  float* a;                               /* [M, 256]: in (n_split <= 1) or out (merged attention output) */
+  const float* o_part; const float* ml_part; int n_split; int B, H, Q; float attn_scale; float* lse;
+  const float* w; const float* bias;      /* [256, 256] (nn.Linear layout), [256] */
+  const float* residual;                  /* [M, 256] */
+  petr_dropout drop;                      /* of the projection's output, before the residual is added */
+  const float* gamma; const float* beta; float eps;
+  float* z; float* mean; float* rstd;     /* optional outputs: pre-norm sum [M, 256], row statistics [M] */
+  float* y;                               /* [M, 256] */
+  float* y2; const float* add2; int add2_rows;   /* optional: y2 = y + add2[row % add2_rows] */
+  int M;
+  const float* w2; const float* bias2; float* out2;   /* optional second projection of the same rows:
+                                                       * out2 = (y2 if requested, else y) w2^T + bias2, [M, 256] */
+} petr_attn_out_ln_args;
+int petr_attn_out_ln(const petr_attn_out_ln_args* a, void* stream);
+
 /* y[i] = bf16(x[i]) (round to nearest even), n elements, both 16-byte aligned: produces the bf16 K/V operands
  * from the fp32 projections (the tensor .to(bfloat16) an autocast reference run would do) */
 int petr_cast_bf16(const float* x, uint16_t* y, long n, void* stream);

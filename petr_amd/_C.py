@@ -90,7 +90,18 @@ class MhaFwdArgs(C.Structure):
         ('lse', C.c_void_p), ('kpm', C.c_void_p),
         ('B', C.c_int), ('H', C.c_int), ('Q', C.c_int), ('L', C.c_int), ('scale', C.c_float),
         ('n_split', C.c_int), ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('drop', Dropout), ('sched', C.c_void_p),
-        ('drop_bits', C.c_void_p))
+        ('drop_bits', C.c_void_p), ('defer_merge', C.c_int))
+
+
+class AttnOutLnArgs(C.Structure):
+    _fields_ = _fields(
+        ('a', C.c_void_p), ('o_part', C.c_void_p), ('ml_part', C.c_void_p), ('n_split', C.c_int),
+        ('B', C.c_int), ('H', C.c_int), ('Q', C.c_int), ('attn_scale', C.c_float), ('lse', C.c_void_p),
+        ('w', C.c_void_p), ('bias', C.c_void_p), ('residual', C.c_void_p), ('drop', Dropout),
+        ('gamma', C.c_void_p), ('beta', C.c_void_p), ('eps', C.c_float),
+        ('z', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('y', C.c_void_p),
+        ('y2', C.c_void_p), ('add2', C.c_void_p), ('add2_rows', C.c_int), ('M', C.c_int),
+        ('w2', C.c_void_p), ('bias2', C.c_void_p), ('out2', C.c_void_p))
 
 
 class MhaBwdArgs(C.Structure):
@@ -207,6 +218,7 @@ def lib():
     L.petr_mha_fwd_workspace_bytes.restype = C.c_size_t
     L.petr_mha_choose_split.argtypes = [C.c_int] * 4
     L.petr_mha_fwd.argtypes = [C.POINTER(MhaFwdArgs), C.c_void_p]
+    L.petr_mha_fwd_bf16_choose_split.argtypes = [C.c_int] * 4
     L.petr_mha_fwd_bf16_workspace_bytes.argtypes = [C.c_int] * 5
     L.petr_mha_fwd_bf16_workspace_bytes.restype = C.c_size_t
     L.petr_mha_fwd_bf16.argtypes = [C.POINTER(MhaFwdArgs), C.c_void_p]   # same block, k / v are bf16
@@ -260,7 +272,7 @@ EXPORTS = [
     'petr_posemb3d_fwd', 'petr_posemb3d_bwd', 'petr_gemm', 'petr_colsum_workspace_bytes', 'petr_colsum',
     'petr_layernorm_fwd', 'petr_layernorm_bwd_workspace_bytes', 'petr_layernorm_bwd',
     'petr_mha_fwd_workspace_bytes', 'petr_mha_choose_split', 'petr_mha_fwd', 'petr_mha_fwd_bf16_workspace_bytes',
-    'petr_mha_fwd_bf16', 'petr_cast_bf16', 'petr_add_rows_bf16', 'petr_mha_bwd_workspace_bytes',
+    'petr_mha_fwd_bf16', 'petr_mha_fwd_bf16_choose_split', 'petr_attn_out_ln', 'petr_cast_bf16', 'petr_add_rows_bf16', 'petr_mha_bwd_workspace_bytes',
     'petr_mha_bwd', 'petr_mha_bwd_bf16_workspace_bytes', 'petr_mha_bwd_bf16', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows', 'petr_gate_fwd', 'petr_gate_bwd', 'petr_prof_begin', 'petr_prof_end',
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',

@@ -1,0 +1,255 @@
+// Attention output block of a decoder layer in one launch (petr_attn_out_ln, petr_hip.h):
+//   ao = merge of the attention's L-split partials          (was: mha_combine_kernel)
+//   z  = drop(ao W^T + bias) + residual                     (was: the out-projection contraction, gemm.hip)
+//   y  = LayerNorm(z) gamma + beta,  y2 = y + add2          (was: layernorm_fwd_kernel)
+// reference: the tail of nn.MultiheadAttention (out_proj) called at petr_transformer.py:357-367 / mmcv
+// MultiheadAttention (identity + dropout_layer(proj_drop(out))) and the `norm` that follows it in
+// multi_atten_decoder_layer.py:204-293.  These were four dependent links of the B = 1 chain (6 + 12 + 5 us and their
+// launch gaps for 0.12 GFLOP); one workgroup of eight waves now owns 16 FULL rows:
+//   prologue   the 16 x 256 attention rows are merged from the split partials (or read), normalised, written back as the
+//              attention output the backward needs, and kept in LDS;
+//   product    wave w computes columns 32 w .. + 31 on v_mfma_f32_16x16x4_f32 (exact fp32): per 16-deep K group a lane
+//              takes one float4 of the A row block from LDS and one float4 of W per column tile straight from L2 (lane
+//              (n, q) holds k = 16 g + 4 q .. + 3; step j of the group multiplies element j of both - the k order inside
+//              a group only has to agree between the operands); the W loads of the next groups are in flight under the
+//              MFMAs of the current one;
+//   epilogue   bias, dropout, residual; row sums of the 16 rows across the 16 lanes of a row group (xor shuffles) and
+//              the eight waves (LDS), two passes (mean, then centred squares) like layernorm_fwd_kernel;
+//   optional   a second 256 x 256 projection of the normalised rows (+ the query_pos addend): the NEXT attention's query
+//              projection (petr_transformer.py:341-362: q = (x + query_pos) Wq^T + bq) - the rows go back to LDS, the same
+//              product runs again.  One more link of the chain in the same launch.
+// 57 workgroups at 900 rows: 2 x 128 dependent 32-cycle MFMAs per wave (3.4 us) are the floor of the product.
+#include "common.h"
+
+namespace {
+
+constexpr int AO_C = 256, AO_ROWS = 16, AO_PITCH = AO_C + 4;
+constexpr float AO_LN2 = 0.6931471805599453f;
+
+struct AoParams {
+  petr_attn_out_ln_args a;
+  DropDev drop;
+};
+
+__global__ __launch_bounds__(512) void attn_out_ln_kernel(const AoParams p) {
+  __shared__ __attribute__((aligned(16))) float As[AO_ROWS * AO_PITCH];
+  __shared__ float red[2][8][AO_ROWS];
+  const petr_attn_out_ln_args& a = p.a;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int m0 = blockIdx.x * AO_ROWS;
+
+  // W fragments of the first four K groups: requested before the prologue so that their latency runs under the merge
+  const int nl = lane & 15, q4 = lane >> 4;
+  const float* w0 = a.w + (long)(32 * wave + nl) * AO_C + 4 * q4;        // column tile 0 of this wave; tile 1: + 16 rows of W
+  const float* w1 = w0 + 16 * AO_C;
+  float4 wq[4][2];                       // W fragments of four K groups in flight
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    wq[g][0] = *reinterpret_cast<const float4*>(w0 + 16 * g);
+    wq[g][1] = *reinterpret_cast<const float4*>(w1 + 16 * g);
+  }
+
+  // ---- prologue: the A row block (thread: row t >> 5, head (t >> 2) & 7, 8 channels 8 (t & 3) .. + 7) ----
+  {
+    const int r = t >> 5, hd = (t >> 2) & 7, d0 = 8 * (t & 3);
+    const int m = min(m0 + r, a.M - 1);
+    float4 v0, v1;
+    if (a.n_split > 1) {
+      const int b = m / a.Q, q = m - b * a.Q;
+      const long rows = (long)a.B * a.H * a.Q;
+      const long row = ((long)b * a.H + hd) * a.Q + q;
+      float M = -INFINITY, L = 0.f;
+      v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      auto add = [&](const float2 ml, const float4 x0, const float4 x1) {
+        // M == -inf (every key of the row masked): exp2(-inf - -inf) = NaN, propagating like the reference
+        const float wgt = __builtin_amdgcn_exp2f(ml.x - M);
+        L += ml.y * wgt;
+        v0.x += x0.x * wgt; v0.y += x0.y * wgt; v0.z += x0.z * wgt; v0.w += x0.w * wgt;
+        v1.x += x1.x * wgt; v1.y += x1.y * wgt; v1.z += x1.z * wgt; v1.w += x1.w * wgt;
+      };
+      if (a.n_split <= 8) {        // block-uniform: every partial of the row requested before the first is used
+        float2 ml[8];
+        float4 x0[8], x1[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int sc = min(s, a.n_split - 1);
+          ml[s] = *reinterpret_cast<const float2*>(a.ml_part + ((long)sc * rows + row) * 2);
+          const float4* o = reinterpret_cast<const float4*>(a.o_part + ((long)sc * rows + row) * 32 + d0);
+          x0[s] = o[0]; x1[s] = o[1];
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) M = s < a.n_split ? fmaxf(M, ml[s].x) : M;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          if (s < a.n_split) add(ml[s], x0[s], x1[s]);
+      } else {
+        for (int s = 0; s < a.n_split; ++s) M = fmaxf(M, a.ml_part[((long)s * rows + row) * 2]);
+        for (int s = 0; s < a.n_split; ++s) {
+          const float4* o = reinterpret_cast<const float4*>(a.o_part + ((long)s * rows + row) * 32 + d0);
+          add(*reinterpret_cast<const float2*>(a.ml_part + ((long)s * rows + row) * 2), o[0], o[1]);
+        }
+      }
+      const float inv = a.attn_scale / L;
+      v0.x *= inv; v0.y *= inv; v0.z *= inv; v0.w *= inv;
+      v1.x *= inv; v1.y *= inv; v1.z *= inv; v1.w *= inv;
+      if (m0 + r < a.M) {
+        float4* dst = reinterpret_cast<float4*>(a.a + (long)m * AO_C + 32 * hd + d0);
+        dst[0] = v0; dst[1] = v1;
+        if (a.lse && (t & 3) == 0) a.lse[row] = (M + log2f(L)) * AO_LN2;
+      }
+    } else {
+      const float4* src = reinterpret_cast<const float4*>(a.a + (long)m * AO_C + 32 * hd + d0);
+      v0 = src[0]; v1 = src[1];
+    }
+    float4* ls = reinterpret_cast<float4*>(As + r * AO_PITCH + 32 * hd + d0);
+    ls[0] = v0; ls[1] = v1;
+  }
+
+  // ---- product: wave = 16 rows x 32 columns, K = 256 in 16 groups of 16 ----
+  __syncthreads();
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const float* arow = As + nl * AO_PITCH + 4 * q4;
+  auto product = [&](const float* wa, const float* wb) {      // acc += As (16 x 256) x W[32 wave .. + 31][:]^T; wq holds groups 0..3
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const float4 af = *reinterpret_cast<const float4*>(arow + 16 * g);
+      const float4 b0 = wq[g & 3][0], b1 = wq[g & 3][1];
+      if (g + 4 < 16) {
+        wq[g & 3][0] = *reinterpret_cast<const float4*>(wa + 16 * (g + 4));
+        wq[g & 3][1] = *reinterpret_cast<const float4*>(wb + 16 * (g + 4));
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b0.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b1.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b0.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b0.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b1.w, acc1, 0, 0, 0);
+    }
+  };
+  product(w0, w1);
+  // second projection (optional): its first W groups are requested now, their latency runs under the epilogue
+  const float* v0 = a.w2 ? a.w2 + (long)(32 * wave + nl) * AO_C + 4 * q4 : w0;
+  const float* v1 = v0 + 16 * AO_C;
+  if (a.w2) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      wq[g][0] = *reinterpret_cast<const float4*>(v0 + 16 * g);
+      wq[g][1] = *reinterpret_cast<const float4*>(v1 + 16 * g);
+    }
+  }
+
+  // ---- epilogue: lane holds rows 4 q4 + i (i = 0..3), columns 32 wave + nl (acc0) and + 16 (acc1) ----
+  const int c0 = 32 * wave + nl, c1 = c0 + 16;
+  const float bia0 = a.bias ? a.bias[c0] : 0.f, bia1 = a.bias ? a.bias[c1] : 0.f;
+  float z0[4], z1[4], part[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + 4 * q4 + i;
+    const int mc = min(m, a.M - 1);
+    float u0 = acc0[i] + bia0, u1 = acc1[i] + bia1;
+    if (p.drop.thr) {       // dropout of the sub-layer output, before the identity is added (as layernorm_fwd_kernel)
+      const uint32_t rk = drop_row_key(p.drop, (uint32_t)mc);
+      u0 = drop_keep(rk, (uint32_t)c0, p.drop.thr) ? u0 * p.drop.scale : 0.f;
+      u1 = drop_keep(rk, (uint32_t)c1, p.drop.thr) ? u1 * p.drop.scale : 0.f;
+    }
+    if (a.residual) {
+      u0 += a.residual[(long)mc * AO_C + c0];
+      u1 += a.residual[(long)mc * AO_C + c1];
+    }
+    z0[i] = u0; z1[i] = u1;
+    part[i] = u0 + u1;
+  }
+  auto row_reduce = [&](float (&v)[4], int slot) -> void {      // v[i] <- sum over the 256 columns of row 4 q4 + i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x = v[i];
+      x += __shfl_xor(x, 1, 64);
+      x += __shfl_xor(x, 2, 64);
+      x += __shfl_xor(x, 4, 64);
+      x += __shfl_xor(x, 8, 64);
+      if (nl == 0) red[slot][wave][4 * q4 + i] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) x += red[slot][w][4 * q4 + i];
+      v[i] = x;
+    }
+  };
+  row_reduce(part, 0);
+  float mean[4], sq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mean[i] = part[i] * (1.f / AO_C);
+    const float d0 = z0[i] - mean[i], d1 = z1[i] - mean[i];
+    sq[i] = d0 * d0 + d1 * d1;
+  }
+  row_reduce(sq, 1);
+  const float g0 = a.gamma[c0], g1 = a.gamma[c1], be0 = a.beta[c0], be1 = a.beta[c1];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + 4 * q4 + i;
+    if (m >= a.M) continue;
+    const float rstd = 1.f / sqrtf(sq[i] * (1.f / AO_C) + a.eps);
+    const float y0 = (z0[i] - mean[i]) * rstd * g0 + be0, y1 = (z1[i] - mean[i]) * rstd * g1 + be1;
+    const long o = (long)m * AO_C;
+    if (a.z) { a.z[o + c0] = z0[i]; a.z[o + c1] = z1[i]; }
+    a.y[o + c0] = y0; a.y[o + c1] = y1;
+    float u0 = y0, u1 = y1;
+    if (a.y2) {
+      const long o2 = (long)(a.add2_rows > 0 ? m % a.add2_rows : m) * AO_C;
+      u0 = y0 + a.add2[o2 + c0];
+      u1 = y1 + a.add2[o2 + c1];
+      a.y2[o + c0] = u0;
+      a.y2[o + c1] = u1;
+    }
+    if (a.w2) {            // operand rows of the second projection (every wave is past its reads of As: two barriers ago)
+      As[(4 * q4 + i) * AO_PITCH + c0] = u0;
+      As[(4 * q4 + i) * AO_PITCH + c1] = u1;
+    }
+    if (wave == 0 && nl == 0) {
+      if (a.mean) a.mean[m] = mean[i];
+      if (a.rstd) a.rstd[m] = rstd;
+    }
+  }
+  // ---- second projection: out2 = (y2, or y) W2^T + bias2 - the next attention's query projection of the same rows ----
+  if (!a.w2) return;
+  __syncthreads();
+  acc0 = acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  product(v0, v1);
+  const float bb0 = a.bias2 ? a.bias2[c0] : 0.f, bb1 = a.bias2 ? a.bias2[c1] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + 4 * q4 + i;
+    if (m >= a.M) continue;
+    a.out2[(long)m * AO_C + c0] = acc0[i] + bb0;
+    a.out2[(long)m * AO_C + c1] = acc1[i] + bb1;
+  }
+}
+
+}  // namespace
+
+extern "C" int petr_attn_out_ln(const petr_attn_out_ln_args* ap, void* stream) {
+  PETR_CHECK(ap && ap->a && ap->w && ap->gamma && ap->beta && ap->y && ap->M > 0, PETR_ERR_INVALID, "attn_out_ln: null pointer");
+  const petr_attn_out_ln_args& a = *ap;
+  PETR_CHECK(aligned16(a.a) && aligned16(a.w), PETR_ERR_INVALID, "attn_out_ln: a / w must be 16-byte aligned");
+  if (a.n_split > 1) {
+    PETR_CHECK(a.o_part && a.ml_part && a.B > 0 && a.H == 8 && a.Q > 0 && a.M == a.B * a.Q && aligned16(a.o_part) &&
+                   (((uintptr_t)a.ml_part) & 7) == 0,
+               PETR_ERR_INVALID, "attn_out_ln: merging needs o_part / ml_part, H == 8 and M == B * Q");
+  }
+  PETR_CHECK(!a.y2 || a.add2, PETR_ERR_INVALID, "attn_out_ln: y2 without add2");
+  PETR_CHECK(!a.w2 || (a.out2 && aligned16(a.w2)), PETR_ERR_INVALID, "attn_out_ln: w2 needs out2 (and 16-byte alignment)");
+  PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "attn_out_ln: dropout p=%g outside [0,1)", (double)a.drop.p);
+  AoParams p;
+  p.a = a;
+  p.drop = make_drop(a.drop);
+  if (!(a.attn_scale > 0.f)) p.a.attn_scale = 1.f;
+  hipLaunchKernelGGL(attn_out_ln_kernel, dim3((unsigned)cdiv(a.M, AO_ROWS)), dim3(512), 0, (hipStream_t)stream, p);
+  PETR_LAUNCH_CHECK("attn_out_ln");
+  return PETR_OK;
+}

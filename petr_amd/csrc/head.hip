@@ -505,6 +505,22 @@ static int ln_fwd(const float* x, int np, long pstride, const float* bias, const
   return petr_layernorm_fwd(&a, s);
 }
 
+// merge of the attention partials + out-projection + dropout + residual + LayerNorm (+ query_pos add) in one launch
+static int attn_out_ln(float* ao, const float* ws, int n_split, const Dims& d, float attn_scale, float* lse, const float* w,
+                       const float* bias, const float* res, const petr_dropout* drop, const float* g, const float* b, float* z,
+                       float* mean, float* rstd, float* y, float* y2, const float* add2, int add2_rows, void* s,
+                       const float* w2 = nullptr, const float* bias2 = nullptr, float* out2 = nullptr) {
+  petr_attn_out_ln_args a;
+  memset(&a, 0, sizeof a);
+  a.a = ao; a.n_split = n_split; a.B = d.B; a.H = d.NH; a.Q = d.Q; a.attn_scale = attn_scale; a.lse = lse;
+  if (n_split > 1) { a.o_part = ws; a.ml_part = ws + (long)n_split * d.B * d.NH * d.Q * 32; }
+  a.w = w; a.bias = bias; a.residual = res;
+  if (drop) a.drop = *drop;
+  a.gamma = g; a.beta = b; a.eps = 1e-5f; a.z = z; a.mean = mean; a.rstd = rstd; a.y = y; a.y2 = y2; a.add2 = add2;
+  a.add2_rows = add2_rows; a.M = (int)d.BQ; a.w2 = w2; a.bias2 = bias2; a.out2 = out2;
+  return petr_attn_out_ln(&a, s);
+}
+
 static int ln_bwd(const float* z, const float* mean, const float* rstd, const float* g, const float* dy, const float* y,
                   float* dz, float* dg, float* db, long M, int C, int flags, int accumulate, void* s, int dy_partials = 1,
                   long dy_pstride = 0, const float* dy_res = nullptr, float* dz_drop = nullptr,
@@ -520,7 +536,7 @@ static int ln_bwd(const float* z, const float* mean, const float* rstd, const fl
 
 static int mha_f(const float* q, long q_bs, long q_rs, const float* k, long k_bs, long k_rs, const float* v, float* o,
                  float* lse, const uint8_t* kpm, const Dims& d, int L, float* ws, size_t ws_bytes, int* sched, void* s,
-                 const petr_dropout* drop = nullptr, uint32_t* bits = nullptr) {
+                 const petr_dropout* drop = nullptr, uint32_t* bits = nullptr, int n_split = 0, int defer_merge = 0) {
   petr_mha_fwd_args a;
   memset(&a, 0, sizeof a);
   if (drop) a.drop = *drop;
@@ -530,14 +546,14 @@ static int mha_f(const float* q, long q_bs, long q_rs, const float* k, long k_bs
   a.o = o; a.o_bs = (long)d.Q * d.C; a.o_hs = 32; a.o_rs = d.C;
   a.lse = lse; a.kpm = kpm; a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
   a.scale = 1.0f / sqrtf(32.f);
-  a.n_split = 0; a.ws = ws; a.ws_bytes = ws_bytes; a.sched = sched; a.drop_bits = bits;
+  a.n_split = n_split; a.ws = ws; a.ws_bytes = ws_bytes; a.sched = sched; a.drop_bits = bits; a.defer_merge = defer_merge;
   return petr_mha_fwd(&a, s);
 }
 
 // cross-attention with bf16 K/V (io->attn_bf16)
 static int mha_f_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, long k_bs, long k_rs, const uint16_t* v,
                       float* o, float* lse, const uint8_t* kpm, const Dims& d, int L, float* ws, size_t ws_bytes, void* s,
-                      const petr_dropout* drop = nullptr, uint32_t* bits = nullptr) {
+                      const petr_dropout* drop = nullptr, uint32_t* bits = nullptr, int n_split = 0, int defer_merge = 0) {
   petr_mha_fwd_bf16_args a;
   memset(&a, 0, sizeof a);
   if (drop) a.drop = *drop;
@@ -547,7 +563,7 @@ static int mha_f_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, l
   a.o = o; a.o_bs = (long)d.Q * d.C; a.o_hs = 32; a.o_rs = d.C;
   a.lse = lse; a.kpm = kpm; a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
   a.scale = 1.0f / sqrtf(32.f);
-  a.n_split = 0; a.ws = ws; a.ws_bytes = ws_bytes; a.drop_bits = bits;
+  a.n_split = n_split; a.ws = ws; a.ws_bytes = ws_bytes; a.drop_bits = bits; a.defer_merge = defer_merge;
   return petr_mha_fwd_bf16(&a, s);
 }
 
@@ -958,6 +974,11 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   auto bits_ptr = [&](int l, int self) -> uint32_t* {
     return bits0 + (long)l * (W.bits_cross_n + W.bits_self_n) + (self ? W.bits_cross_n : 0);
   };
+  // PETR_FUSE_OUT_LN=0: the four separate launches (merge, out-projection, LayerNorm) per attention
+  static const bool fuse_env = env_on("PETR_FUSE_OUT_LN");
+  const bool fuse_out = fuse_env && C == 256 && d.NH == 8;
+  const int ns_self = petr_mha_choose_split(d.B, d.NH, d.Q, d.Q);
+  const int ns_cross = attn_bf16 ? petr_mha_fwd_bf16_choose_split(d.B, d.NH, d.Q, (int)d.L) : petr_mha_choose_split(d.B, d.NH, d.Q, (int)d.L);
   for (int l = 0; l < d.NL; ++l) {
     const LayerP& lp = P.lay[l];
     const LayerW& lw = W.lay[l];
@@ -967,6 +988,17 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     petr_gemm_args g = lin_fwd(x_in, Pm + lp.sa_in_w, Pm + lp.sa_in_b, Wm + lw.qkv, d.BQ, 3 * C, C);
     g.a2 = E; g.a2_rows = d.Q; g.a2_ncols = 2 * C;
     RUN(petr_gemm(&g, s));
+    if (fuse_out) {
+      // attention with its L-split partials left in the workspace, then ONE launch: merge + out-projection + dropout +
+      // identity (petr_transformer.py:367) + LayerNorm + query_pos add
+      RUN(mha_f(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
+                Wm + lw.ao_s, Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, sched, s, training ? &dr_sp : nullptr,
+                use_bits ? bits_ptr(l, 1) : nullptr, ns_self, 1));
+      RUN(attn_out_ln(Wm + lw.ao_s, mws, ns_self, d, training ? hidden_drop_scale(dr_sp) : 1.f, Wm + lw.lse_s, Pm + lp.sa_out_w,
+                      Pm + lp.sa_out_b, x_in, training ? &dr_so : nullptr, Pm + lp.n_g[0], Pm + lp.n_b[0], Wm + lw.z0,
+                      Wm + lw.mean0, Wm + lw.rstd0, Wm + lw.x1, Wm + lw.xe1, E, d.Q, s,
+                      Pm + lp.ca_in_w, Pm + lp.ca_in_b, Wm + lw.qc));      // + the cross-attention's query projection
+    } else {
     RUN(mha_f(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
               Wm + lw.ao_s, Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, sched, s, training ? &dr_sp : nullptr,
               use_bits ? bits_ptr(l, 1) : nullptr));
@@ -976,9 +1008,12 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     RUN(ln_fwd(Wm + lw.z0, 1, 0, nullptr, training ? x_in : nullptr, Pm + lp.n_g[0], Pm + lp.n_b[0], Wm + lw.x1,
                training ? Wm + lw.z0 : nullptr, Wm + lw.mean0, Wm + lw.rstd0, d.BQ, C, 0, Wm + lw.xe1, E, d.Q, s,
                training ? &dr_so : nullptr));
+    }
     // cross-attention: q = x1 + query_pos, k = mem + pos, v = mem (petr_transformer.py:341-362)
-    g = lin_fwd(Wm + lw.xe1, Pm + lp.ca_in_w, Pm + lp.ca_in_b, Wm + lw.qc, d.BQ, C, C);
-    RUN(petr_gemm(&g, s));
+    if (!fuse_out) {
+      g = lin_fwd(Wm + lw.xe1, Pm + lp.ca_in_w, Pm + lp.ca_in_b, Wm + lw.qc, d.BQ, C, C);
+      RUN(petr_gemm(&g, s));
+    }
     if (l == 0) {          // K/V come from the side streams: layer 0's now, the other layers' before layer 1
       if (ev_k0) {
         (void)hipStreamWaitEvent(ln.main, ev_k0, 0);
@@ -994,17 +1029,23 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     if (attn_bf16)
       RUN(mha_f_bf16(Wm + lw.qc, (long)d.Q * C, C, k16 + (long)l * d.L * C, (long)d.NL * d.L * C, C,
                      v16 + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, s,
-                     training ? &dr_cp : nullptr, use_bits ? bits_ptr(l, 0) : nullptr));
+                     training ? &dr_cp : nullptr, use_bits ? bits_ptr(l, 0) : nullptr, fuse_out ? ns_cross : 0, fuse_out ? 1 : 0));
     else
     RUN(mha_f(Wm + lw.qc, (long)d.Q * C, C, Wm + W.k_all + (long)l * d.L * C, (long)d.NL * d.L * C, C,
               Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, sched, s,
-              training ? &dr_cp : nullptr, use_bits ? bits_ptr(l, 0) : nullptr));
+              training ? &dr_cp : nullptr, use_bits ? bits_ptr(l, 0) : nullptr, fuse_out ? ns_cross : 0, fuse_out ? 1 : 0));
+    if (fuse_out) {
+      RUN(attn_out_ln(Wm + lw.ao_c, mws, ns_cross, d, training ? hidden_drop_scale(dr_cp) : 1.f, Wm + lw.lse_c, Pm + lp.ca_out_w,
+                      Pm + lp.ca_out_b, Wm + lw.x1, training ? &dr_co : nullptr, Pm + lp.n_g[1], Pm + lp.n_b[1], Wm + lw.z1,
+                      Wm + lw.mean1, Wm + lw.rstd1, Wm + lw.x2, nullptr, nullptr, 0, s));
+    } else {
     g = lin_fwd(Wm + lw.ao_c, Pm + lp.ca_out_w, Pm + lp.ca_out_b, Wm + lw.z1, d.BQ, C, C);
     if (!training) { g.r = Wm + lw.x1; g.ldr = C; }
     RUN(petr_gemm(&g, s));
     RUN(ln_fwd(Wm + lw.z1, 1, 0, nullptr, training ? Wm + lw.x1 : nullptr, Pm + lp.n_g[1], Pm + lp.n_b[1], Wm + lw.x2,
                training ? Wm + lw.z1 : nullptr, Wm + lw.mean1, Wm + lw.rstd1, d.BQ, C, 0, nullptr, nullptr, 0, s,
                training ? &dr_co : nullptr));
+    }
     // FFN (mmcv FFN): x + W2 relu(W1 x + b1) + b2 ; second contraction split over K
     // bf16 mode: both FFN contractions on the bf16 matrix cores with the bf16 weight copy, as autocast runs them
     // (900 x 2048 x 256 alone: 21.8 -> 11.8 us; PETR_FFN16=0: fp32)

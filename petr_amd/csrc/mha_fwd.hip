@@ -875,7 +875,7 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
     default: launch(mha_fwd_kernel<true, true, true, true>); break;
   }
   PETR_LAUNCH_CHECK("mha_fwd");
-  if (ns > 1) {
+  if (ns > 1 && !a.defer_merge) {
     const long n = (long)a.B * a.H * a.Q * 8;
     hipLaunchKernelGGL(mha_combine_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, p);
     PETR_LAUNCH_CHECK("mha_combine");
@@ -892,6 +892,8 @@ static int bf16_split(int B, int H, int Q, int L) {
   if (ns > 64) ns = 64;
   return ns < 1 ? 1 : (int)ns;
 }
+
+extern "C" int petr_mha_fwd_bf16_choose_split(int B, int H, int Q, int L) { return bf16_split(B, H, Q, L); }
 
 extern "C" size_t petr_mha_fwd_bf16_workspace_bytes(int B, int H, int Q, int L, int n_split) {
   if (n_split <= 0) n_split = bf16_split(B, H, Q, L);
@@ -950,7 +952,7 @@ extern "C" int petr_mha_fwd_bf16(const petr_mha_fwd_bf16_args* ap, void* stream)
     default: launch(mha_fwd_bf16_kernel<true, true>); break;
   }
   PETR_LAUNCH_CHECK("mha_fwd_bf16");
-  if (ns > 1) {
+  if (ns > 1 && !a.defer_merge) {
     const long n = (long)a.B * a.H * a.Q * 8;
     hipLaunchKernelGGL(mha_combine_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, p);
     PETR_LAUNCH_CHECK("mha_combine");

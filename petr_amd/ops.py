@@ -117,6 +117,31 @@ def dropout_mask(drop, rows, cols, device='cuda'):
     return keep.bool()
 
 
+def attn_out_ln(a, w, bias, residual, gamma, beta, partials=None, n_split=1, BHQ=None, attn_scale=1.0, drop=None, add2=None,
+                add2_rows=0, eps=1e-5, w2=None, bias2=None):
+    """petr_attn_out_ln: [merge of the attention partials ->] a W^T + bias -> dropout -> + residual -> LayerNorm (-> + add2).
+    ``a``: [M, 256] attention output (n_split <= 1) or an uninitialised [M, 256] buffer that receives the merged output.
+    Returns (y, y2 or None, z, mean, rstd, lse or None)."""
+    L = _C.lib()
+    M = a.shape[0]
+    y, z = torch.empty_like(a), torch.empty_like(a)
+    y2 = torch.empty_like(a) if add2 is not None else None
+    mean, rstd = torch.empty(M, device=a.device), torch.empty(M, device=a.device)
+    B, H, Q = BHQ if BHQ is not None else (1, 8, M)
+    lse = torch.empty(B * H * Q, device=a.device) if n_split > 1 else None
+    o_part = partials if n_split > 1 else None
+    ml_part = partials[n_split * B * H * Q * 32:] if n_split > 1 else None
+    args = _C.AttnOutLnArgs(_ptr(a), _ptr(o_part), _ptr(ml_part), n_split, B, H, Q, float(attn_scale), _ptr(lse), _ptr(w), _ptr(bias),
+                            _ptr(residual), _C.dropout(drop), _ptr(gamma), _ptr(beta), float(eps), _ptr(z), _ptr(mean), _ptr(rstd),
+                            _ptr(y), _ptr(y2), _ptr(add2), add2_rows, M, _ptr(w2), _ptr(bias2), None)
+    out2 = torch.empty_like(a) if w2 is not None else None
+    args.out2 = _ptr(out2)
+    _C.check(L.petr_attn_out_ln(C.byref(args), _stream()), 'petr_attn_out_ln')
+    if w2 is not None:
+        return y, y2, z, mean, rstd, lse, out2
+    return y, y2, z, mean, rstd, lse
+
+
 def dropout_bits(drop, BH, Q, L, device='cuda'):
     """The attention-dropout mask of ``dropout_mask(drop, BH * Q, L)`` packed for the attention kernels:
     (query-major words for ``mha_fwd*``, key-major words for ``mha_bwd*``), both int32 [petr_dropout_bits_words]."""
@@ -196,7 +221,8 @@ def _bhsd(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
-def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True, dynamic=False, drop=None, drop_bits=None):
+def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True, dynamic=False, drop=None, drop_bits=None,
+            defer_merge=False):
     """softmax(scale q k^T + mask) v for [B,H,S,32] (strided) views.  Returns (o [B,H,Q,32], lse [B,H,Q]).
     ``dynamic``: the L-split workers draw K/V tiles from per-query-block ticket counters (zeroed here)."""
     L = _C.lib()
@@ -211,8 +237,11 @@ def mha_fwd(q, k, v, key_padding_mask=None, scale=None, n_split=0, need_lse=True
     kpm = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
     sched = torch.zeros(B * H * ((Q + 127) // 128), dtype=torch.int32, device=q.device) if dynamic else None
     a = _C.MhaFwdArgs(_ptr(_f32(q)), *_bhsd(q), _ptr(_f32(k)), *_bhsd(k), _ptr(_f32(v)), *_bhsd(v), _ptr(o), *_bhsd(o),
-                      _ptr(lse), _ptr(kpm), B, H, Q, Lk, scale, ns, _ptr(ws), nbytes, _C.dropout(drop), _ptr(sched), _ptr(drop_bits))
+                      _ptr(lse), _ptr(kpm), B, H, Q, Lk, scale, ns, _ptr(ws), nbytes, _C.dropout(drop), _ptr(sched), _ptr(drop_bits),
+                      int(defer_merge))
     _C.check(L.petr_mha_fwd(C.byref(a), _stream()), 'petr_mha_fwd')
+    if defer_merge:
+        return ws, ns          # the L-split partials (o_part, then ml_part) and their count; o / lse are not written
     return o, lse
 
 

@@ -757,3 +757,43 @@ def test_attention_backward_reads_the_mask_the_forward_left(ops, B, H, Q, L, spl
         g1 = bwd(q, kk, vv, o0, do, l0, kpm, drop=drop, drop_bits=bits)
         for a, b in zip(g0, g1):
             assert (a - b).abs().max().item() <= 1e-5 * (1 + a.abs().max().item())
+
+
+@pytest.mark.parametrize('B,Q,L,split,training', [(1, 900, 4224, 0, True), (2, 70, 333, 3, False), (1, 900, 900, 0, True),
+                                                   (1, 37, 40, 1, True)])
+def test_attn_out_ln_equals_its_four_separate_launches(ops, B, Q, L, split, training):
+    """petr_attn_out_ln (merge of the L-split partials + out-projection + dropout + residual + LayerNorm + query_pos add in
+    one launch) against the chain it replaces: mha_fwd (with its merge kernel) -> linear -> layernorm, to fp32 rounding
+    (the 256-deep dot products are summed in a different order)."""
+    g = torch.Generator().manual_seed(B * 1000 + Q + L)
+    H, C = 8, 256
+    q, k, v = (dev(torch.randn(B, n, C, generator=g)).view(B, n, H, 32).permute(0, 2, 1, 3) for n in (Q, L, L))
+    w, bias, res = dev(torch.randn(C, C, generator=g) * 0.06), dev(torch.randn(C, generator=g)), dev(torch.randn(B * Q, C, generator=g))
+    gamma, beta, pos = dev(torch.rand(C, generator=g) + 0.5), dev(torch.randn(C, generator=g)), dev(torch.randn(Q, C, generator=g))
+    pdrop = (77, 2, 0.1) if training else None           # attention probabilities
+    odrop = (77, 3, 0.1) if training else None           # projection output
+    o, lse = ops.mha_fwd(q, k, v, n_split=split, drop=pdrop)
+    ao = o.permute(0, 2, 1, 3).reshape(B * Q, C).contiguous()
+    lin = ops.linear(ao, w, bias)
+    y_ref, z_ref, mean_ref, rstd_ref = ops.layernorm(lin, gamma, beta, residual=res, save_stats=True, drop=odrop)
+    # fused
+    parts, ns = ops.mha_fwd(q, k, v, n_split=split, drop=pdrop, defer_merge=True)
+    a = torch.full((B * Q, C), float('nan'), device='cuda') if ns > 1 else ao.clone()
+    scale = 1.0 / (1.0 - round(0.1 * 65536) / 65536) if training else 1.0
+    y, y2, z, mean, rstd, lse2 = ops.attn_out_ln(a, w, bias, res, gamma, beta, partials=parts, n_split=ns, BHQ=(B, H, Q),
+                                                 attn_scale=scale, drop=odrop, add2=pos, add2_rows=Q)
+    if ns > 1:        # same partials, same summation order; the compiler may contract the multiply-adds differently
+        assert relerr(a, ao) < 1e-6
+        assert (lse2.view(B, H, Q) - lse).abs().max().item() < 1e-5
+    assert relerr(z, z_ref) < 2e-6 and relerr(y, y_ref) < 5e-6
+    assert relerr(mean, mean_ref) < 1e-5 and relerr(rstd, rstd_ref) < 1e-5
+    assert relerr(y2, y_ref + pos.repeat(B, 1)) < 5e-6
+    if training:          # the same elements are dropped
+        assert torch.equal((z - res) == 0, (z_ref - res) == 0) or ((z - res == 0) != (z_ref - res == 0)).float().mean() < 1e-4
+    # with the optional second projection (the next attention's query projection of y2)
+    w2, b2 = dev(torch.randn(C, C, generator=g) * 0.06), dev(torch.randn(C, generator=g))
+    a2 = torch.full((B * Q, C), float('nan'), device='cuda') if ns > 1 else ao.clone()
+    out = ops.attn_out_ln(a2, w, bias, res, gamma, beta, partials=parts, n_split=ns, BHQ=(B, H, Q), attn_scale=scale, drop=odrop,
+                          add2=pos, add2_rows=Q, w2=w2, bias2=b2)
+    assert torch.equal(out[0], y) and torch.equal(out[1], y2)
+    assert relerr(out[6], ops.linear(y2, w2, b2)) < 5e-6

@@ -315,6 +315,23 @@ typedef struct {
 } petr_attn_out_ln_args;
 int petr_attn_out_ln(const petr_attn_out_ln_args* a, void* stream);
 
+/* The LayerNorm that closes a decoder layer AND the projections that read it, one launch (C = 256):
+ *     z = drop(sum_p x[p] + bias) + residual,  y = LN(z) gamma + beta,  y2 = y + add2[row % add2_rows]
+ *     out2[:, 256 j .. + 255] = (j < n2_pos ? y2 : y) w2[256 j .. + 255, :]^T + bias2,   j = 0 .. n2-1,  out2 [M, 256 n2]
+ *   = petr_layernorm_fwd (same prologue: split-K slabs of the FFN's second contraction, bias, dropout, residual) + the next
+ *   layer's self-attention in-projection (multi_atten_decoder_layer.py:223-237: q, k from x + query_pos -> n2_pos = 2,
+ *   v from x; w2 = in_proj_weight [768, 256], n2 = 3). */
+typedef struct {
+  const float* x; int n_partials; long partial_stride;   /* [P][M, 256] */
+  const float* bias; const float* residual; petr_dropout drop;
+  const float* gamma; const float* beta; float eps;
+  float* z; float* mean; float* rstd; float* y;
+  float* y2; const float* add2; int add2_rows;
+  int M;
+  const float* w2; const float* bias2; float* out2; int n2, n2_pos;
+} petr_ln_proj_args;
+int petr_ln_proj(const petr_ln_proj_args* a, void* stream);
+
 /* y[i] = bf16(x[i]) (round to nearest even), n elements, both 16-byte aligned: produces the bf16 K/V operands
  * from the fp32 projections (the tensor .to(bfloat16) an autocast reference run would do) */
 int petr_cast_bf16(const float* x, uint16_t* y, long n, void* stream);

@@ -231,7 +231,164 @@ __global__ __launch_bounds__(512) void attn_out_ln_kernel(const AoParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// petr_ln_proj: the LayerNorm that closes a decoder layer - sum of the FFN's split-K slabs + bias, dropout, residual, norm,
+// query_pos add (layernorm_fwd_kernel's job) - AND the projection(s) that read its result: the next layer's self-attention
+// in-projection (multi_atten_decoder_layer.py:223-237: q, k from x + query_pos, v from x).  grid = (row blocks of 16,
+// column blocks of 256): every workgroup re-derives the 16 normalised rows (16 x 256 x n_partials loads - nothing next to
+// a 256-deep product), block 0 writes them, each multiplies them by its own 256 rows of W.  One launch instead of two, and
+// the projection's operand never leaves the chip.
+// ---------------------------------------------------------------------------------------------------------------
+struct LpParams {
+  petr_ln_proj_args a;
+  DropDev drop;
+};
+
+__global__ __launch_bounds__(512) void ln_proj_kernel(const LpParams p) {
+  __shared__ __attribute__((aligned(16))) float As[AO_ROWS * AO_PITCH];
+  __shared__ float red[2][8][AO_ROWS];
+  const petr_ln_proj_args& a = p.a;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int m0 = blockIdx.x * AO_ROWS, jb = blockIdx.y;
+  const int nl = lane & 15, q4 = lane >> 4;
+  const float* w0 = a.w2 + ((long)256 * jb + 32 * wave + nl) * AO_C + 4 * q4;
+  const float* w1 = w0 + 16 * AO_C;
+  float4 wq[4][2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    wq[g][0] = *reinterpret_cast<const float4*>(w0 + 16 * g);
+    wq[g][1] = *reinterpret_cast<const float4*>(w1 + 16 * g);
+  }
+  const int c0 = 32 * wave + nl, c1 = c0 + 16;
+  const float bia0 = a.bias ? a.bias[c0] : 0.f, bia1 = a.bias ? a.bias[c1] : 0.f;
+  float z0[4], z1[4], part[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mc = min(m0 + 4 * q4 + i, a.M - 1);
+    float u0 = 0.f, u1 = 0.f;
+    for (int sp = 0; sp < a.n_partials; ++sp) {
+      const float* x = a.x + (long)sp * a.partial_stride + (long)mc * AO_C;
+      u0 += x[c0];
+      u1 += x[c1];
+    }
+    u0 += bia0; u1 += bia1;
+    if (p.drop.thr) {
+      const uint32_t rk = drop_row_key(p.drop, (uint32_t)mc);
+      u0 = drop_keep(rk, (uint32_t)c0, p.drop.thr) ? u0 * p.drop.scale : 0.f;
+      u1 = drop_keep(rk, (uint32_t)c1, p.drop.thr) ? u1 * p.drop.scale : 0.f;
+    }
+    if (a.residual) {
+      u0 += a.residual[(long)mc * AO_C + c0];
+      u1 += a.residual[(long)mc * AO_C + c1];
+    }
+    z0[i] = u0; z1[i] = u1;
+    part[i] = u0 + u1;
+  }
+  auto row_reduce = [&](float (&v)[4], int slot) -> void {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x = v[i];
+      x += __shfl_xor(x, 1, 64);
+      x += __shfl_xor(x, 2, 64);
+      x += __shfl_xor(x, 4, 64);
+      x += __shfl_xor(x, 8, 64);
+      if (nl == 0) red[slot][wave][4 * q4 + i] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) x += red[slot][w][4 * q4 + i];
+      v[i] = x;
+    }
+  };
+  row_reduce(part, 0);
+  float mean[4], sq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mean[i] = part[i] * (1.f / AO_C);
+    const float d0 = z0[i] - mean[i], d1 = z1[i] - mean[i];
+    sq[i] = d0 * d0 + d1 * d1;
+  }
+  row_reduce(sq, 1);
+  const float g0 = a.gamma[c0], g1 = a.gamma[c1], be0 = a.beta[c0], be1 = a.beta[c1];
+  const bool writer = jb == 0;
+  const bool with_pos = jb < a.n2_pos;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + 4 * q4 + i;
+    const int mc = min(m, a.M - 1);
+    const float rstd = 1.f / sqrtf(sq[i] * (1.f / AO_C) + a.eps);
+    const float y0 = (z0[i] - mean[i]) * rstd * g0 + be0, y1 = (z1[i] - mean[i]) * rstd * g1 + be1;
+    float u0 = y0, u1 = y1;
+    if (a.add2) {
+      const long o2 = (long)(a.add2_rows > 0 ? mc % a.add2_rows : mc) * AO_C;
+      u0 = y0 + a.add2[o2 + c0];
+      u1 = y1 + a.add2[o2 + c1];
+    }
+    if (writer && m < a.M) {
+      const long o = (long)m * AO_C;
+      if (a.z) { a.z[o + c0] = z0[i]; a.z[o + c1] = z1[i]; }
+      a.y[o + c0] = y0; a.y[o + c1] = y1;
+      if (a.y2) { a.y2[o + c0] = u0; a.y2[o + c1] = u1; }
+      if (wave == 0 && nl == 0) {
+        if (a.mean) a.mean[m] = mean[i];
+        if (a.rstd) a.rstd[m] = rstd;
+      }
+    }
+    As[(4 * q4 + i) * AO_PITCH + c0] = with_pos ? u0 : y0;
+    As[(4 * q4 + i) * AO_PITCH + c1] = with_pos ? u1 : y1;
+  }
+  __syncthreads();
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const float* arow = As + nl * AO_PITCH + 4 * q4;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const float4 af = *reinterpret_cast<const float4*>(arow + 16 * g);
+    const float4 b0 = wq[g & 3][0], b1 = wq[g & 3][1];
+    if (g + 4 < 16) {
+      wq[g & 3][0] = *reinterpret_cast<const float4*>(w0 + 16 * (g + 4));
+      wq[g & 3][1] = *reinterpret_cast<const float4*>(w1 + 16 * (g + 4));
+    }
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b0.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b0.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b1.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b0.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b1.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b0.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b1.w, acc1, 0, 0, 0);
+  }
+  const int n0 = 256 * jb + c0, n1 = n0 + 16;
+  const float bb0 = a.bias2 ? a.bias2[n0] : 0.f, bb1 = a.bias2 ? a.bias2[n1] : 0.f;
+  const long ld2 = 256L * a.n2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + 4 * q4 + i;
+    if (m >= a.M) continue;
+    a.out2[(long)m * ld2 + n0] = acc0[i] + bb0;
+    a.out2[(long)m * ld2 + n1] = acc1[i] + bb1;
+  }
+}
+
 }  // namespace
+
+extern "C" int petr_ln_proj(const petr_ln_proj_args* ap, void* stream) {
+  PETR_CHECK(ap && ap->x && ap->gamma && ap->beta && ap->y && ap->w2 && ap->out2 && ap->M > 0 && ap->n_partials > 0 && ap->n2 > 0,
+             PETR_ERR_INVALID, "ln_proj: bad arguments");
+  const petr_ln_proj_args& a = *ap;
+  PETR_CHECK(aligned16(a.w2), PETR_ERR_INVALID, "ln_proj: w2 must be 16-byte aligned");
+  PETR_CHECK(!a.y2 || a.add2, PETR_ERR_INVALID, "ln_proj: y2 without add2");
+  PETR_CHECK(a.n2_pos >= 0 && a.n2_pos <= a.n2 && (a.n2_pos == 0 || a.add2), PETR_ERR_INVALID, "ln_proj: n2_pos needs add2");
+  PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "ln_proj: dropout p=%g outside [0,1)", (double)a.drop.p);
+  LpParams p;
+  p.a = a;
+  p.drop = make_drop(a.drop);
+  hipLaunchKernelGGL(ln_proj_kernel, dim3((unsigned)cdiv(a.M, AO_ROWS), (unsigned)a.n2), dim3(512), 0, (hipStream_t)stream, p);
+  PETR_LAUNCH_CHECK("ln_proj");
+  return PETR_OK;
+}
 
 extern "C" int petr_attn_out_ln(const petr_attn_out_ln_args* ap, void* stream) {
   PETR_CHECK(ap && ap->a && ap->w && ap->gamma && ap->beta && ap->y && ap->M > 0, PETR_ERR_INVALID, "attn_out_ln: null pointer");

@@ -987,7 +987,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     // self-attention: q = k = x + query_pos, v = x  (multi_atten_decoder_layer.py:223-237)
     petr_gemm_args g = lin_fwd(x_in, Pm + lp.sa_in_w, Pm + lp.sa_in_b, Wm + lw.qkv, d.BQ, 3 * C, C);
     g.a2 = E; g.a2_rows = d.Q; g.a2_ncols = 2 * C;
-    RUN(petr_gemm(&g, s));
+    if (l == 0 || !fuse_out) RUN(petr_gemm(&g, s));       // layers 1..: done by the previous layer's closing petr_ln_proj
     if (fuse_out) {
       // attention with its L-split partials left in the workspace, then ONE launch: merge + out-projection + dropout +
       // identity (petr_transformer.py:367) + LayerNorm + query_pos add
@@ -1060,7 +1060,21 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     if (W.ffn_split == 1 && !training) { g.bias = Pm + lp.f2_b; g.r = Wm + lw.x2; g.ldr = C; g.c = Wm + lw.z2; }
     RUN(petr_gemm(&g, s));
     float* xe_next = l + 1 < d.NL ? Wm + W.lay[l + 1].xe_in : nullptr;
-    if (W.ffn_split == 1 && !training) {
+    if (fuse_out && l + 1 < d.NL) {
+      // closing LayerNorm (slab sum + bias + dropout + residual + norm + query_pos add) AND the next layer's self-attention
+      // in-projection in one launch
+      petr_ln_proj_args q;
+      memset(&q, 0, sizeof q);
+      const bool slabs = !(W.ffn_split == 1 && !training);
+      q.x = slabs ? Wm + W.ffn_part : Wm + lw.z2; q.n_partials = slabs ? W.ffn_split : 1; q.partial_stride = d.BQ * C;
+      q.bias = slabs ? Pm + lp.f2_b : nullptr; q.residual = slabs ? Wm + lw.x2 : nullptr;
+      if (slabs && training) q.drop = dr_fo;
+      q.gamma = Pm + lp.n_g[2]; q.beta = Pm + lp.n_b[2]; q.eps = 1e-5f;
+      q.z = slabs ? Wm + lw.z2 : nullptr; q.mean = Wm + lw.mean2; q.rstd = Wm + lw.rstd2; q.y = xs_l;
+      q.y2 = xe_next; q.add2 = E; q.add2_rows = d.Q; q.M = (int)d.BQ;
+      q.w2 = Pm + P.lay[l + 1].sa_in_w; q.bias2 = Pm + P.lay[l + 1].sa_in_b; q.out2 = Wm + W.lay[l + 1].qkv; q.n2 = 3; q.n2_pos = 2;
+      RUN(petr_ln_proj(&q, s));
+    } else if (W.ffn_split == 1 && !training) {
       RUN(ln_fwd(Wm + lw.z2, 1, 0, nullptr, nullptr, Pm + lp.n_g[2], Pm + lp.n_b[2], xs_l, nullptr, Wm + lw.mean2,
                  Wm + lw.rstd2, d.BQ, C, 0, xe_next, E, d.Q, s));
     } else {

@@ -142,6 +142,26 @@ def attn_out_ln(a, w, bias, residual, gamma, beta, partials=None, n_split=1, BHQ
     return y, y2, z, mean, rstd, lse
 
 
+def ln_proj(x, gamma, beta, w2, bias2=None, bias=None, residual=None, drop=None, add2=None, add2_rows=0, n2_pos=0, eps=1e-5):
+    """petr_ln_proj: LN(drop(sum_p x[p] + bias) + residual) and the projections of its result in one launch.
+    x [M,256] or [P,M,256]; w2 [256 n2, 256].  Returns (y, y2 or None, z, mean, rstd, out2 [M, 256 n2])."""
+    L = _C.lib()
+    if x.dim() == 3:
+        P, M, Cc = x.shape
+    else:
+        P, (M, Cc) = 1, x.shape
+    n2 = w2.shape[0] // 256
+    y, z = torch.empty((M, Cc), device=x.device), torch.empty((M, Cc), device=x.device)
+    y2 = torch.empty_like(y) if add2 is not None else None
+    mean, rstd = torch.empty(M, device=x.device), torch.empty(M, device=x.device)
+    out2 = torch.empty((M, 256 * n2), device=x.device)
+    a = _C.LnProjArgs(_ptr(_f32(x)), P, M * Cc, _ptr(bias), _ptr(residual), _C.dropout(drop), _ptr(gamma), _ptr(beta), float(eps),
+                      _ptr(z), _ptr(mean), _ptr(rstd), _ptr(y), _ptr(y2), _ptr(add2), add2_rows, M, _ptr(w2), _ptr(bias2), _ptr(out2),
+                      n2, n2_pos)
+    _C.check(L.petr_ln_proj(C.byref(a), _stream()), 'petr_ln_proj')
+    return y, y2, z, mean, rstd, out2
+
+
 def dropout_bits(drop, BH, Q, L, device='cuda'):
     """The attention-dropout mask of ``dropout_mask(drop, BH * Q, L)`` packed for the attention kernels:
     (query-major words for ``mha_fwd*``, key-major words for ``mha_bwd*``), both int32 [petr_dropout_bits_words]."""

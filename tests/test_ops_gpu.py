@@ -797,3 +797,27 @@ def test_attn_out_ln_equals_its_four_separate_launches(ops, B, Q, L, split, trai
                           add2=pos, add2_rows=Q, w2=w2, bias2=b2)
     assert torch.equal(out[0], y) and torch.equal(out[1], y2)
     assert relerr(out[6], ops.linear(y2, w2, b2)) < 5e-6
+
+
+@pytest.mark.parametrize('M,P,training', [(900, 4, True), (1800, 1, False), (37, 2, True)])
+def test_ln_proj_equals_layernorm_then_in_projection(ops, M, P, training):
+    """petr_ln_proj against the two launches it replaces: layernorm (split-K slabs + bias + dropout + residual, query_pos add)
+    and the next layer's self-attention in-projection (q, k rows from y + query_pos, v rows from y)."""
+    g = torch.Generator().manual_seed(M + P)
+    C = 256
+    x = dev(torch.randn(P, M, C, generator=g))
+    bias, res = dev(torch.randn(C, generator=g)), dev(torch.randn(M, C, generator=g))
+    gamma, beta = dev(torch.rand(C, generator=g) + 0.5), dev(torch.randn(C, generator=g))
+    Q = 900 if M % 900 == 0 else M
+    pos = dev(torch.randn(Q, C, generator=g))
+    w_in, b_in = dev(torch.randn(3 * C, C, generator=g) * 0.06), dev(torch.randn(3 * C, generator=g))
+    drop = (5, 6, 0.1) if training else None
+    y_ref, z_ref, mean_ref, rstd_ref = ops.layernorm(x, gamma, beta, bias=bias, residual=res, save_stats=True, drop=drop)
+    y2_ref = y_ref + pos.repeat(M // Q, 1)
+    qk = ops.linear(y2_ref, w_in[:2 * C], b_in[:2 * C])
+    vv = ops.linear(y_ref, w_in[2 * C:], b_in[2 * C:])
+    y, y2, z, mean, rstd, out2 = ops.ln_proj(x, gamma, beta, w_in, b_in, bias=bias, residual=res, drop=drop, add2=pos, add2_rows=Q,
+                                             n2_pos=2)
+    assert relerr(z, z_ref) < 2e-6 and relerr(y, y_ref) < 5e-6 and relerr(y2, y2_ref) < 5e-6
+    assert relerr(mean, mean_ref) < 1e-5 and relerr(rstd, rstd_ref) < 1e-5
+    assert relerr(out2[:, :2 * C], qk) < 5e-6 and relerr(out2[:, 2 * C:], vv) < 5e-6

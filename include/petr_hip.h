@@ -332,6 +332,21 @@ typedef struct {
 } petr_ln_proj_args;
 int petr_ln_proj(const petr_ln_proj_args* a, void* stream);
 
+/* LayerNorm backward AND the input gradient of the linear layer behind the normalised sum's sub-layer branch, one launch
+ * (C = 256): petr_layernorm_bwd semantics for dz / dz_drop / dgamma / dbeta (float atomics), then
+ *     out[:, 256 j .. + 255] = mask( alpha * (dz_drop if dropout else dz) wT[256 j .. + 255, :]^T ),  j = 0 .. n2-1
+ *   wT [256 n2, 256] = the TRANSPOSE of the nn.Linear weight W [256, 256 n2] (dx = dy W), relu_mask [M, 256 n2] optional
+ *   (out is zeroed where relu_mask <= 0: the FFN hidden).  Replaces layernorm_bwd + the out-projection / FFN2 input
+ *   gradient of multi_atten_decoder_layer.py:204-293's backward. */
+typedef struct {
+  const float* z; const float* mean; const float* rstd; const float* gamma;
+  const float* dy; int dy_partials; long dy_partial_stride; const float* dy_residual;
+  float* dz; float* dz_drop; petr_dropout drop; float* dgamma; float* dbeta;
+  int M;
+  const float* wT; int n2; float alpha; const float* relu_mask; float* out;
+} petr_ln_bwd_proj_args;
+int petr_ln_bwd_proj(const petr_ln_bwd_proj_args* a, void* stream);
+
 /* y[i] = bf16(x[i]) (round to nearest even), n elements, both 16-byte aligned: produces the bf16 K/V operands
  * from the fp32 projections (the tensor .to(bfloat16) an autocast reference run would do) */
 int petr_cast_bf16(const float* x, uint16_t* y, long n, void* stream);

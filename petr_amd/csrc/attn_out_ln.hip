@@ -38,13 +38,13 @@ __global__ __launch_bounds__(512) void attn_out_ln_kernel(const AoParams p) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int m0 = blockIdx.x * AO_ROWS;
 
-  // W fragments of the first four K groups: requested before the prologue so that their latency runs under the merge
+  // W fragments of the first eight K groups: requested before the prologue so that their latency runs under the merge
   const int nl = lane & 15, q4 = lane >> 4;
   const float* w0 = a.w + (long)(32 * wave + nl) * AO_C + 4 * q4;        // column tile 0 of this wave; tile 1: + 16 rows of W
   const float* w1 = w0 + 16 * AO_C;
-  float4 wq[4][2];                       // W fragments of four K groups in flight
+  float4 wq[8][2];                       // W fragments of eight K groups in flight
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
+  for (int g = 0; g < 8; ++g) {
     wq[g][0] = *reinterpret_cast<const float4*>(w0 + 16 * g);
     wq[g][1] = *reinterpret_cast<const float4*>(w1 + 16 * g);
   }
@@ -113,10 +113,10 @@ __global__ __launch_bounds__(512) void attn_out_ln_kernel(const AoParams p) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const float4 af = *reinterpret_cast<const float4*>(arow + 16 * g);
-      const float4 b0 = wq[g & 3][0], b1 = wq[g & 3][1];
-      if (g + 4 < 16) {
-        wq[g & 3][0] = *reinterpret_cast<const float4*>(wa + 16 * (g + 4));
-        wq[g & 3][1] = *reinterpret_cast<const float4*>(wb + 16 * (g + 4));
+      const float4 b0 = wq[g & 7][0], b1 = wq[g & 7][1];
+      if (g + 8 < 16) {
+        wq[g & 7][0] = *reinterpret_cast<const float4*>(wa + 16 * (g + 8));
+        wq[g & 7][1] = *reinterpret_cast<const float4*>(wb + 16 * (g + 8));
       }
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b0.x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b1.x, acc1, 0, 0, 0);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512) void attn_out_ln_kernel(const AoParams p) {
   const float* v1 = v0 + 16 * AO_C;
   if (a.w2) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < 8; ++g) {
       wq[g][0] = *reinterpret_cast<const float4*>(v0 + 16 * g);
       wq[g][1] = *reinterpret_cast<const float4*>(v1 + 16 * g);
     }
@@ -253,9 +253,9 @@ __global__ __launch_bounds__(512) void ln_proj_kernel(const LpParams p) {
   const int nl = lane & 15, q4 = lane >> 4;
   const float* w0 = a.w2 + ((long)256 * jb + 32 * wave + nl) * AO_C + 4 * q4;
   const float* w1 = w0 + 16 * AO_C;
-  float4 wq[4][2];
+  float4 wq[8][2];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
+  for (int g = 0; g < 8; ++g) {
     wq[g][0] = *reinterpret_cast<const float4*>(w0 + 16 * g);
     wq[g][1] = *reinterpret_cast<const float4*>(w1 + 16 * g);
   }
@@ -346,10 +346,10 @@ __global__ __launch_bounds__(512) void ln_proj_kernel(const LpParams p) {
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const float4 af = *reinterpret_cast<const float4*>(arow + 16 * g);
-    const float4 b0 = wq[g & 3][0], b1 = wq[g & 3][1];
-    if (g + 4 < 16) {
-      wq[g & 3][0] = *reinterpret_cast<const float4*>(w0 + 16 * (g + 4));
-      wq[g & 3][1] = *reinterpret_cast<const float4*>(w1 + 16 * (g + 4));
+    const float4 b0 = wq[g & 7][0], b1 = wq[g & 7][1];
+    if (g + 8 < 16) {
+      wq[g & 7][0] = *reinterpret_cast<const float4*>(w0 + 16 * (g + 8));
+      wq[g & 7][1] = *reinterpret_cast<const float4*>(w1 + 16 * (g + 8));
     }
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b0.x, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b1.x, acc1, 0, 0, 0);
@@ -372,7 +372,167 @@ __global__ __launch_bounds__(512) void ln_proj_kernel(const LpParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// petr_ln_bwd_proj: LayerNorm backward (petr_layernorm_bwd's job: dz = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma,
+// with the split-K slab / identity-path prologue, the dropped copy of dz for the sub-layer branch, dgamma / dbeta by float
+// atomics) AND the input gradient of the linear layer behind that branch - out = (dz_drop or dz) W, read through the
+// transposed weight wT[K_in][256] - in one launch.  Same shape as ln_proj_kernel: grid = (row blocks of 16, blocks of 256
+// output columns), every workgroup re-derives the 16 gradient rows, block 0 writes them and adds the column sums.
+// Three of the eleven links of a decoder layer's backward chain (LN2 + FFN2, LN1 + cross out-proj, LN0 + self out-proj).
+// ---------------------------------------------------------------------------------------------------------------
+struct LbParams {
+  petr_ln_bwd_proj_args a;
+  DropDev drop;
+};
+
+__global__ __launch_bounds__(512) void ln_bwd_proj_kernel(const LbParams p) {
+  __shared__ __attribute__((aligned(16))) float As[AO_ROWS * AO_PITCH];
+  __shared__ float red[2][8][AO_ROWS];
+  const petr_ln_bwd_proj_args& a = p.a;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int m0 = blockIdx.x * AO_ROWS, jb = blockIdx.y;
+  const int nl = lane & 15, q4 = lane >> 4;
+  const float* w0 = a.wT + ((long)256 * jb + 32 * wave + nl) * AO_C + 4 * q4;
+  const float* w1 = w0 + 16 * AO_C;
+  float4 wq[8][2];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    wq[g][0] = *reinterpret_cast<const float4*>(w0 + 16 * g);
+    wq[g][1] = *reinterpret_cast<const float4*>(w1 + 16 * g);
+  }
+  const int c0 = 32 * wave + nl, c1 = c0 + 16;
+  const float gm0 = a.gamma[c0], gm1 = a.gamma[c1];
+  float xh0[4], xh1[4], g0[4], g1[4], s1[4], s2[4], rs[4];
+  float cg0 = 0.f, cg1 = 0.f, cb0 = 0.f, cb1 = 0.f;         // column sums over this lane's four rows
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + 4 * q4 + i;
+    const int mc = min(m, a.M - 1);
+    const long o = (long)mc * AO_C;
+    float d0 = 0.f, d1 = 0.f;
+    for (int sp = 0; sp < a.dy_partials; ++sp) {
+      const float* x = a.dy + (long)sp * a.dy_partial_stride + o;
+      d0 += x[c0];
+      d1 += x[c1];
+    }
+    if (a.dy_residual) { d0 += a.dy_residual[o + c0]; d1 += a.dy_residual[o + c1]; }
+    if (m >= a.M) d0 = d1 = 0.f;                              // padding rows add nothing to the column sums
+    const float mean = a.mean[mc], rstd = a.rstd[mc];
+    rs[i] = rstd;
+    xh0[i] = (a.z[o + c0] - mean) * rstd;
+    xh1[i] = (a.z[o + c1] - mean) * rstd;
+    g0[i] = d0 * gm0; g1[i] = d1 * gm1;
+    s1[i] = g0[i] + g1[i];
+    s2[i] = g0[i] * xh0[i] + g1[i] * xh1[i];
+    cg0 += d0 * xh0[i]; cg1 += d1 * xh1[i];
+    cb0 += d0; cb1 += d1;
+  }
+  auto row_reduce = [&](float (&v)[4], int slot) -> void {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x = v[i];
+      x += __shfl_xor(x, 1, 64);
+      x += __shfl_xor(x, 2, 64);
+      x += __shfl_xor(x, 4, 64);
+      x += __shfl_xor(x, 8, 64);
+      if (nl == 0) red[slot][wave][4 * q4 + i] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) x += red[slot][w][4 * q4 + i];
+      v[i] = x;
+    }
+  };
+  row_reduce(s1, 0);
+  row_reduce(s2, 1);
+  const bool writer = jb == 0;
+  if (writer && (a.dgamma || a.dbeta)) {      // the 16 rows' column sums: across the four row groups of the wave, then atomics
+    cg0 += __shfl_xor(cg0, 16, 64); cg0 += __shfl_xor(cg0, 32, 64);
+    cg1 += __shfl_xor(cg1, 16, 64); cg1 += __shfl_xor(cg1, 32, 64);
+    cb0 += __shfl_xor(cb0, 16, 64); cb0 += __shfl_xor(cb0, 32, 64);
+    cb1 += __shfl_xor(cb1, 16, 64); cb1 += __shfl_xor(cb1, 32, 64);
+    if (q4 == 0) {
+      if (a.dgamma) { atomicAdd(a.dgamma + c0, cg0); atomicAdd(a.dgamma + c1, cg1); }
+      if (a.dbeta) { atomicAdd(a.dbeta + c0, cb0); atomicAdd(a.dbeta + c1, cb1); }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + 4 * q4 + i;
+    const int mc = min(m, a.M - 1);
+    const float m1 = s1[i] * (1.f / AO_C), m2 = s2[i] * (1.f / AO_C);
+    const float d0 = rs[i] * (g0[i] - m1 - xh0[i] * m2), d1 = rs[i] * (g1[i] - m1 - xh1[i] * m2);
+    float e0 = d0, e1 = d1;
+    if (p.drop.thr) {                         // gradient of the dropped branch of z = drop(f) + residual
+      const uint32_t rk = drop_row_key(p.drop, (uint32_t)mc);
+      e0 = drop_keep(rk, (uint32_t)c0, p.drop.thr) ? d0 * p.drop.scale : 0.f;
+      e1 = drop_keep(rk, (uint32_t)c1, p.drop.thr) ? d1 * p.drop.scale : 0.f;
+    }
+    if (writer && m < a.M) {
+      const long o = (long)m * AO_C;
+      a.dz[o + c0] = d0; a.dz[o + c1] = d1;
+      if (a.dz_drop) { a.dz_drop[o + c0] = e0; a.dz_drop[o + c1] = e1; }
+    }
+    As[(4 * q4 + i) * AO_PITCH + c0] = e0;
+    As[(4 * q4 + i) * AO_PITCH + c1] = e1;
+  }
+  __syncthreads();
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const float* arow = As + nl * AO_PITCH + 4 * q4;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const float4 af = *reinterpret_cast<const float4*>(arow + 16 * g);
+    const float4 b0 = wq[g & 7][0], b1 = wq[g & 7][1];
+    if (g + 8 < 16) {
+      wq[g & 7][0] = *reinterpret_cast<const float4*>(w0 + 16 * (g + 8));
+      wq[g & 7][1] = *reinterpret_cast<const float4*>(w1 + 16 * (g + 8));
+    }
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b0.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b0.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b1.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b0.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b1.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b0.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b1.w, acc1, 0, 0, 0);
+  }
+  const int n0 = 256 * jb + c0, n1 = n0 + 16;
+  const long ld2 = 256L * a.n2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + 4 * q4 + i;
+    if (m >= a.M) continue;
+    float v0 = acc0[i] * a.alpha, v1 = acc1[i] * a.alpha;
+    if (a.relu_mask) {
+      v0 = a.relu_mask[(long)m * ld2 + n0] > 0.f ? v0 : 0.f;
+      v1 = a.relu_mask[(long)m * ld2 + n1] > 0.f ? v1 : 0.f;
+    }
+    a.out[(long)m * ld2 + n0] = v0;
+    a.out[(long)m * ld2 + n1] = v1;
+  }
+}
+
 }  // namespace
+
+extern "C" int petr_ln_bwd_proj(const petr_ln_bwd_proj_args* ap, void* stream) {
+  PETR_CHECK(ap && ap->z && ap->mean && ap->rstd && ap->gamma && ap->dy && ap->dz && ap->wT && ap->out && ap->M > 0 &&
+                 ap->dy_partials > 0 && ap->n2 > 0,
+             PETR_ERR_INVALID, "ln_bwd_proj: bad arguments");
+  const petr_ln_bwd_proj_args& a = *ap;
+  PETR_CHECK(aligned16(a.wT), PETR_ERR_INVALID, "ln_bwd_proj: wT must be 16-byte aligned");
+  PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "ln_bwd_proj: dropout p=%g outside [0,1)", (double)a.drop.p);
+  PETR_CHECK(!(a.drop.p > 0.f) || a.dz_drop, PETR_ERR_INVALID, "ln_bwd_proj: dropout needs dz_drop");
+  LbParams p;
+  p.a = a;
+  p.drop = make_drop(a.drop);
+  if (a.alpha == 0.f) p.a.alpha = 1.f;
+  hipLaunchKernelGGL(ln_bwd_proj_kernel, dim3((unsigned)cdiv(a.M, AO_ROWS), (unsigned)a.n2), dim3(512), 0, (hipStream_t)stream, p);
+  PETR_LAUNCH_CHECK("ln_bwd_proj");
+  return PETR_OK;
+}
 
 extern "C" int petr_ln_proj(const petr_ln_proj_args* ap, void* stream) {
   PETR_CHECK(ap && ap->x && ap->gamma && ap->beta && ap->y && ap->w2 && ap->out2 && ap->M > 0 && ap->n_partials > 0 && ap->n2 > 0,

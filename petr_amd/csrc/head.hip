@@ -534,6 +534,19 @@ static int ln_bwd(const float* z, const float* mean, const float* rstd, const fl
   return petr_layernorm_bwd(&a, s);
 }
 
+// LayerNorm backward + the input gradient of the branch's linear layer (through its transposed weight) in one launch
+static int ln_bwd_proj(const float* z, const float* mean, const float* rstd, const float* g, const float* dy, int dy_partials,
+                       long dy_pstride, const float* dy_res, float* dz, float* dz_drop, const petr_dropout* drop, float* dg,
+                       float* db, long M, const float* wT, int n2, float alpha, const float* relu_mask, float* out, void* s) {
+  petr_ln_bwd_proj_args a;
+  memset(&a, 0, sizeof a);
+  a.z = z; a.mean = mean; a.rstd = rstd; a.gamma = g; a.dy = dy; a.dy_partials = dy_partials; a.dy_partial_stride = dy_pstride;
+  a.dy_residual = dy_res; a.dz = dz; a.dz_drop = dz_drop;
+  if (drop && dz_drop) a.drop = *drop;
+  a.dgamma = dg; a.dbeta = db; a.M = (int)M; a.wT = wT; a.n2 = n2; a.alpha = alpha; a.relu_mask = relu_mask; a.out = out;
+  return petr_ln_bwd_proj(&a, s);
+}
+
 static int mha_f(const float* q, long q_bs, long q_rs, const float* k, long k_bs, long k_rs, const float* v, float* o,
                  float* lse, const uint8_t* kpm, const Dims& d, int L, float* ws, size_t ws_bytes, int* sched, void* s,
                  const petr_dropout* drop = nullptr, uint32_t* bits = nullptr, int n_split = 0, int defer_merge = 0) {
@@ -1180,6 +1193,9 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   static const bool defer_env = env_on("PETR_WGRAD_DEFER");
   static const bool dgrad_t = env_on("PETR_DGRAD_T");        // PETR_DGRAD_T=0: input gradients read W itself (K-major operand)
   hipEvent_t ev_tr = nullptr;
+  // LayerNorm backward + the following input gradient in one launch (needs the transposed weights; PETR_FUSE_LN_BWD=0: separate)
+  static const bool fuse_bwd_env = env_on("PETR_FUSE_LN_BWD");
+  const bool fuse_bwd = fuse_bwd_env && dgrad_t && C == 256;
   int wg_rr = 0, n_pend = 0;
   bool defer = false;
   petr_gemm_args pend[24];
@@ -1386,17 +1402,29 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // LN2 / FFN
       float* d_z2 = Wm + lg.d_z2;
       float* d_f2 = training ? Wm + lg.d_zd[2] : d_z2;          // gradient of the second FFN contraction's output
+      float* d_h = Wm + lg.d_h;                                 // [BQ, F]
+      const WOff::LayerT& wt = W.wt[l];
+      petr_gemm_args g;
+      // stored hidden = relu(.) * keep/(1-p): (hidden > 0) is relu-mask AND keep; the 1/(1-p) rides on alpha
+      // (the fused form also exists for this site - LayerNorm backward + the FFN2 input gradient with its ReLU mask, 8 column
+      // blocks - but measured 64-77 us against 10 + 40 for the two kernels: eight re-derivations of the rows and a scalar
+      // mask epilogue; PETR_FUSE_LN_BWD=2 selects it)
+      static const bool fuse_ffn2 = getenv("PETR_FUSE_LN_BWD") && atoi(getenv("PETR_FUSE_LN_BWD")) == 2;
+      if (fuse_bwd && fuse_ffn2 && d.F % 256 == 0) {
+        RUN(ln_bwd_proj(Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, Pm + lp.n_g[2], G, 1, 0, nullptr, d_z2,
+                        training ? d_f2 : nullptr, training ? &dr[5] : nullptr, Gp + lp.n_g[2], Gp + lp.n_b[2], d.BQ, Wm + wt.f2,
+                        d.F / 256, training ? hidden_drop_scale(dr[4]) : 1.f, Wm + lw.hff, d_h, s));
+        RUN(wgrad(lin_wgrad(d_f2, C, Wm + lw.hff, d.F, Gp + lp.f2_w, Gp + lp.f2_b, d.BQ, C, d.F)));
+      } else {
       RUN(ln_bwd(Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, Pm + lp.n_g[2], G, nullptr, d_z2, Gp + lp.n_g[2], Gp + lp.n_b[2],
                  d.BQ, C, 0, 0, s, 1, 0, nullptr, training ? d_f2 : nullptr, &dr[5]));
       RUN(wgrad(lin_wgrad(d_f2, C, Wm + lw.hff, d.F, Gp + lp.f2_w, Gp + lp.f2_b, d.BQ, C, d.F)));
-      float* d_h = Wm + lg.d_h;                                 // [BQ, F]
-      const WOff::LayerT& wt = W.wt[l];
-      petr_gemm_args g = dgrad_t ? lin_dgrad_t(d_f2, Wm + wt.f2, d_h, d.BQ, C, d.F) : lin_dgrad(d_f2, Pm + lp.f2_w, d_h, d.BQ, C, d.F);
+      g = dgrad_t ? lin_dgrad_t(d_f2, Wm + wt.f2, d_h, d.BQ, C, d.F) : lin_dgrad(d_f2, Pm + lp.f2_w, d_h, d.BQ, C, d.F);
       if (ffn16) g = lin_dgrad(d_f2, Wp(lp.f2_w), d_h, d.BQ, C, d.F);     // bf16 route: the bf16 weight, read K-major
-      // stored hidden = relu(.) * keep/(1-p): (hidden > 0) is relu-mask AND keep; the 1/(1-p) rides on alpha
       g.flags = PETR_GEMM_RELU_MASK | (ffn16 ? PETR_GEMM_BF16 | wflag : 0); g.r = Wm + lw.hff; g.ldr = d.F;
       if (training) g.alpha = hidden_drop_scale(dr[4]);
       RUN(petr_gemm(&g, s));
+      }
       RUN(wgrad(lin_wgrad(d_h, d.F, Wm + lw.x2, C, Gp + lp.f1_w, Gp + lp.f1_b, d.BQ, d.F, C)));
       // d_x2 = d_h @ W1 + d_z2 (identity path): K = F is long and there are only BQ/64 x 4 output tiles, so the
       // contraction is split over K into slabs that the LayerNorm backward sums in its prologue
@@ -1410,12 +1438,19 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // LN1 / cross-attention
       float* d_z1 = Wm + lg.d_z1;
       float* d_f1 = training ? Wm + lg.d_zd[1] : d_z1;          // gradient of the cross-attention out-projection's output
+      float* d_ao = Wm + lg.d_ao;
+      if (fuse_bwd) {
+        RUN(ln_bwd_proj(Wm + lw.z1, Wm + lw.mean1, Wm + lw.rstd1, Pm + lp.n_g[1], d_x2, sk, d.BQ * C, sk > 1 ? d_z2 : nullptr, d_z1,
+                        training ? d_f1 : nullptr, training ? &dr[3] : nullptr, Gp + lp.n_g[1], Gp + lp.n_b[1], d.BQ, Wm + wt.ca_out,
+                        1, 1.f, nullptr, d_ao, s));
+        RUN(wgrad(lin_wgrad(d_f1, C, Wm + lw.ao_c, C, Gp + lp.ca_out_w, Gp + lp.ca_out_b, d.BQ, C, C)));
+      } else {
       RUN(ln_bwd(Wm + lw.z1, Wm + lw.mean1, Wm + lw.rstd1, Pm + lp.n_g[1], d_x2, nullptr, d_z1, Gp + lp.n_g[1],
                  Gp + lp.n_b[1], d.BQ, C, 0, 0, s, sk, d.BQ * C, sk > 1 ? d_z2 : nullptr, training ? d_f1 : nullptr, &dr[3]));
       RUN(wgrad(lin_wgrad(d_f1, C, Wm + lw.ao_c, C, Gp + lp.ca_out_w, Gp + lp.ca_out_b, d.BQ, C, C)));
-      float* d_ao = Wm + lg.d_ao;
       g = dgrad_t ? lin_dgrad_t(d_f1, Wm + wt.ca_out, d_ao, d.BQ, C, C) : lin_dgrad(d_f1, Pm + lp.ca_out_w, d_ao, d.BQ, C, C);
       RUN(petr_gemm(&g, s));
+      }
       float* d_qc = Wm + W.d_qc + (long)l * d.BQ * C;
       if (bf16)
         RUN(mha_b_bf16(Wm + lw.qc, (long)d.Q * C, C, k16 + (long)l * d.L * C, (long)d.NL * d.L * C, C,
@@ -1478,12 +1513,19 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // LN0 / self-attention
       float* d_z0 = Wm + lg.d_z0;
       float* d_f0 = training ? Wm + lg.d_zd[0] : d_z0;          // gradient of the self-attention out-projection's output
+      float* d_ao_s = Wm + lg.d_ao_s;
+      if (fuse_bwd) {
+        RUN(ln_bwd_proj(Wm + lw.z0, Wm + lw.mean0, Wm + lw.rstd0, Pm + lp.n_g[0], d_x1, 1, 0, nullptr, d_z0,
+                        training ? d_f0 : nullptr, training ? &dr[1] : nullptr, Gp + lp.n_g[0], Gp + lp.n_b[0], d.BQ, Wm + wt.sa_out,
+                        1, 1.f, nullptr, d_ao_s, s));
+        RUN(wgrad(lin_wgrad(d_f0, C, Wm + lw.ao_s, C, Gp + lp.sa_out_w, Gp + lp.sa_out_b, d.BQ, C, C)));
+      } else {
       RUN(ln_bwd(Wm + lw.z0, Wm + lw.mean0, Wm + lw.rstd0, Pm + lp.n_g[0], d_x1, nullptr, d_z0, Gp + lp.n_g[0],
                  Gp + lp.n_b[0], d.BQ, C, 0, 0, s, 1, 0, nullptr, training ? d_f0 : nullptr, &dr[1]));
       RUN(wgrad(lin_wgrad(d_f0, C, Wm + lw.ao_s, C, Gp + lp.sa_out_w, Gp + lp.sa_out_b, d.BQ, C, C)));
-      float* d_ao_s = Wm + lg.d_ao_s;
       g = dgrad_t ? lin_dgrad_t(d_f0, Wm + wt.sa_out, d_ao_s, d.BQ, C, C) : lin_dgrad(d_f0, Pm + lp.sa_out_w, d_ao_s, d.BQ, C, C);
       RUN(petr_gemm(&g, s));
+      }
       float* d_qkv = Wm + W.d_qkv + (long)l * d.BQ * 3 * C;
       RUN(mha_b(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
                 Wm + lw.ao_s, d_ao_s, Wm + lw.lse_s, nullptr, d_qkv, d_qkv + C, d_qkv + 2 * C, d, d.Q, mws, W.mha_ws_bytes, s,

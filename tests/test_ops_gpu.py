@@ -821,3 +821,32 @@ def test_ln_proj_equals_layernorm_then_in_projection(ops, M, P, training):
     assert relerr(z, z_ref) < 2e-6 and relerr(y, y_ref) < 5e-6 and relerr(y2, y2_ref) < 5e-6
     assert relerr(mean, mean_ref) < 1e-5 and relerr(rstd, rstd_ref) < 1e-5
     assert relerr(out2[:, :2 * C], qk) < 5e-6 and relerr(out2[:, 2 * C:], vv) < 5e-6
+
+
+@pytest.mark.parametrize('M,P,F,training', [(900, 1, 256, True), (900, 4, 256, False), (900, 1, 2048, True), (37, 2, 512, True)])
+def test_ln_bwd_proj_equals_layernorm_bwd_then_input_gradient(ops, M, P, F, training):
+    """petr_ln_bwd_proj against the two launches it replaces: layernorm_bwd (slab sum + identity path, dropped copy, dgamma /
+    dbeta) and the input-gradient contraction dx = dz_drop @ W (with the FFN's ReLU mask and dropout scale when F > 256)."""
+    g = torch.Generator().manual_seed(M + P + F)
+    C = 256
+    x = dev(torch.randn(M, C, generator=g))
+    gamma, beta = dev(torch.rand(C, generator=g) + 0.5), dev(torch.randn(C, generator=g))
+    _, z, mean, rstd = ops.layernorm(x, gamma, beta, save_stats=True)
+    dy = dev(torch.randn(P, M, C, generator=g))
+    res = dev(torch.randn(M, C, generator=g)) if P > 1 else None
+    w = dev(torch.randn(C, F, generator=g) * 0.06)                 # nn.Linear(F -> 256) weight [256, F]
+    drop = (3, 4, 0.1) if training else None
+    mask = dev(torch.randn(M, F, generator=g)) if F > 256 else None
+    alpha = 1.25 if F > 256 else 1.0
+    dy_sum = dy.sum(0) + (res if res is not None else 0)
+    ref = ops.layernorm_bwd(z, mean, rstd, gamma, dy_sum, drop=drop)
+    a_ref = ref[3] if training else ref[0]
+    out_ref = (a_ref.double() @ w.double()) * alpha
+    if mask is not None:
+        out_ref = out_ref * (mask > 0)
+    dz, dzd, dg, db, out = ops.ln_bwd_proj(z, mean, rstd, gamma, dy if P > 1 else dy[0], w, dy_residual=res, drop=drop, alpha=alpha,
+                                           relu_mask=mask)
+    assert relerr(dz, ref[0]) < 5e-6 and relerr(dg, ref[1]) < 2e-5 and relerr(db, ref[2]) < 2e-5
+    if training:
+        assert relerr(dzd, ref[3]) < 5e-6
+    assert relerr(out, out_ref) < 1e-5

@@ -344,6 +344,10 @@ typedef struct {
   float* dz; float* dz_drop; petr_dropout drop; float* dgamma; float* dbeta;
   int M;
   const float* wT; int n2; float alpha; const float* relu_mask; float* out;
+  const float* pre_a; const float* pre_wT;   /* optional leading product: the upstream gradient is
+                                              * pre_a [M,256] pre_wT[256,256]^T + sum of the dy slabs (dy_partials may be 0)
+                                              * + dy_residual - the input gradient of the projection that read the
+                                              * normalised rows (pre_wT = that weight, transposed) */
 } petr_ln_bwd_proj_args;
 int petr_ln_bwd_proj(const petr_ln_bwd_proj_args* a, void* stream);
 

@@ -118,7 +118,8 @@ class LnBwdProjArgs(C.Structure):
         ('z', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('gamma', C.c_void_p),
         ('dy', C.c_void_p), ('dy_partials', C.c_int), ('dy_partial_stride', C.c_long), ('dy_residual', C.c_void_p),
         ('dz', C.c_void_p), ('dz_drop', C.c_void_p), ('drop', Dropout), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p),
-        ('M', C.c_int), ('wT', C.c_void_p), ('n2', C.c_int), ('alpha', C.c_float), ('relu_mask', C.c_void_p), ('out', C.c_void_p))
+        ('M', C.c_int), ('wT', C.c_void_p), ('n2', C.c_int), ('alpha', C.c_float), ('relu_mask', C.c_void_p), ('out', C.c_void_p),
+        ('pre_a', C.c_void_p), ('pre_wT', C.c_void_p))
 
 
 class MhaBwdArgs(C.Structure):

@@ -401,6 +401,46 @@ __global__ __launch_bounds__(512) void ln_bwd_proj_kernel(const LbParams p) {
     wq[g][1] = *reinterpret_cast<const float4*>(w1 + 16 * g);
   }
   const int c0 = 32 * wave + nl, c1 = c0 + 16;
+  // optional leading product: dy = pre_a pre_wT^T (+ dy_residual) - the input gradient of the projection that consumed the
+  // normalised rows (the cross-attention's query projection), computed here instead of by a launch of its own; its
+  // accumulators fall in exactly the (row, column) layout the LayerNorm backward below works in
+  f32x4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f};
+  if (a.pre_a) {
+    {
+      const int r = t >> 5, cc = 8 * (t & 31);
+      const float4* src = reinterpret_cast<const float4*>(a.pre_a + (long)min(m0 + r, a.M - 1) * AO_C + cc);
+      float4* ls = reinterpret_cast<float4*>(As + r * AO_PITCH + cc);
+      ls[0] = src[0]; ls[1] = src[1];
+    }
+    const float* u0 = a.pre_wT + (long)(32 * wave + nl) * AO_C + 4 * q4;
+    const float* u1 = u0 + 16 * AO_C;
+    float4 uq[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uq[g][0] = *reinterpret_cast<const float4*>(u0 + 16 * g);
+      uq[g][1] = *reinterpret_cast<const float4*>(u1 + 16 * g);
+    }
+    __syncthreads();
+    const float* arow0 = As + nl * AO_PITCH + 4 * q4;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const float4 af = *reinterpret_cast<const float4*>(arow0 + 16 * g);
+      const float4 b0 = uq[g & 3][0], b1 = uq[g & 3][1];
+      if (g + 4 < 16) {
+        uq[g & 3][0] = *reinterpret_cast<const float4*>(u0 + 16 * (g + 4));
+        uq[g & 3][1] = *reinterpret_cast<const float4*>(u1 + 16 * (g + 4));
+      }
+      pre0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b0.x, pre0, 0, 0, 0);
+      pre1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b1.x, pre1, 0, 0, 0);
+      pre0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b0.y, pre0, 0, 0, 0);
+      pre1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b1.y, pre1, 0, 0, 0);
+      pre0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b0.z, pre0, 0, 0, 0);
+      pre1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b1.z, pre1, 0, 0, 0);
+      pre0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b0.w, pre0, 0, 0, 0);
+      pre1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b1.w, pre1, 0, 0, 0);
+    }
+    __syncthreads();                       // As is rewritten below
+  }
   const float gm0 = a.gamma[c0], gm1 = a.gamma[c1];
   float xh0[4], xh1[4], g0[4], g1[4], s1[4], s2[4], rs[4];
   float cg0 = 0.f, cg1 = 0.f, cb0 = 0.f, cb1 = 0.f;         // column sums over this lane's four rows
@@ -409,7 +449,7 @@ __global__ __launch_bounds__(512) void ln_bwd_proj_kernel(const LbParams p) {
     const int m = m0 + 4 * q4 + i;
     const int mc = min(m, a.M - 1);
     const long o = (long)mc * AO_C;
-    float d0 = 0.f, d1 = 0.f;
+    float d0 = pre0[i], d1 = pre1[i];
     for (int sp = 0; sp < a.dy_partials; ++sp) {
       const float* x = a.dy + (long)sp * a.dy_partial_stride + o;
       d0 += x[c0];
@@ -518,9 +558,11 @@ __global__ __launch_bounds__(512) void ln_bwd_proj_kernel(const LbParams p) {
 }  // namespace
 
 extern "C" int petr_ln_bwd_proj(const petr_ln_bwd_proj_args* ap, void* stream) {
-  PETR_CHECK(ap && ap->z && ap->mean && ap->rstd && ap->gamma && ap->dy && ap->dz && ap->wT && ap->out && ap->M > 0 &&
-                 ap->dy_partials > 0 && ap->n2 > 0,
+  PETR_CHECK(ap && ap->z && ap->mean && ap->rstd && ap->gamma && ap->dz && ap->wT && ap->out && ap->M > 0 && ap->n2 > 0 &&
+                 ((ap->dy && ap->dy_partials > 0) || (ap->pre_a && ap->pre_wT && ap->dy_partials == 0)),
              PETR_ERR_INVALID, "ln_bwd_proj: bad arguments");
+  PETR_CHECK(!ap->pre_a || (ap->pre_wT && aligned16(ap->pre_a) && aligned16(ap->pre_wT)), PETR_ERR_INVALID,
+             "ln_bwd_proj: pre_a needs pre_wT, both 16-byte aligned");
   const petr_ln_bwd_proj_args& a = *ap;
   PETR_CHECK(aligned16(a.wT), PETR_ERR_INVALID, "ln_bwd_proj: wT must be 16-byte aligned");
   PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "ln_bwd_proj: dropout p=%g outside [0,1)", (double)a.drop.p);

@@ -537,13 +537,15 @@ static int ln_bwd(const float* z, const float* mean, const float* rstd, const fl
 // LayerNorm backward + the input gradient of the branch's linear layer (through its transposed weight) in one launch
 static int ln_bwd_proj(const float* z, const float* mean, const float* rstd, const float* g, const float* dy, int dy_partials,
                        long dy_pstride, const float* dy_res, float* dz, float* dz_drop, const petr_dropout* drop, float* dg,
-                       float* db, long M, const float* wT, int n2, float alpha, const float* relu_mask, float* out, void* s) {
+                       float* db, long M, const float* wT, int n2, float alpha, const float* relu_mask, float* out, void* s,
+                       const float* pre_a = nullptr, const float* pre_wT = nullptr) {
   petr_ln_bwd_proj_args a;
   memset(&a, 0, sizeof a);
   a.z = z; a.mean = mean; a.rstd = rstd; a.gamma = g; a.dy = dy; a.dy_partials = dy_partials; a.dy_partial_stride = dy_pstride;
   a.dy_residual = dy_res; a.dz = dz; a.dz_drop = dz_drop;
   if (drop && dz_drop) a.drop = *drop;
   a.dgamma = dg; a.dbeta = db; a.M = (int)M; a.wT = wT; a.n2 = n2; a.alpha = alpha; a.relu_mask = relu_mask; a.out = out;
+  a.pre_a = pre_a; a.pre_wT = pre_wT;
   return petr_ln_bwd_proj(&a, s);
 }
 
@@ -1507,17 +1509,20 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       RUN(wgrad(dgrad_t ? lin_dgrad_t(d_qc, Wm + wt.ca_q, Wm + W.d_e_slab + (long)l * d.BQ * C, d.BQ, C, C)
                         : lin_dgrad(d_qc, Pm + lp.ca_in_w, Wm + W.d_e_slab + (long)l * d.BQ * C, d.BQ, C, C)));
       float* d_x1 = Wm + lg.d_x1;
-      g = dgrad_t ? lin_dgrad_t(d_qc, Wm + wt.ca_q, d_x1, d.BQ, C, C) : lin_dgrad(d_qc, Pm + lp.ca_in_w, d_x1, d.BQ, C, C);
-      g.r = d_z1; g.ldr = C;
-      RUN(petr_gemm(&g, s));
+      if (!fuse_bwd) {       // (fused: the leading product of the LayerNorm-0 backward kernel below)
+        g = dgrad_t ? lin_dgrad_t(d_qc, Wm + wt.ca_q, d_x1, d.BQ, C, C) : lin_dgrad(d_qc, Pm + lp.ca_in_w, d_x1, d.BQ, C, C);
+        g.r = d_z1; g.ldr = C;
+        RUN(petr_gemm(&g, s));
+      }
       // LN0 / self-attention
       float* d_z0 = Wm + lg.d_z0;
       float* d_f0 = training ? Wm + lg.d_zd[0] : d_z0;          // gradient of the self-attention out-projection's output
       float* d_ao_s = Wm + lg.d_ao_s;
       if (fuse_bwd) {
-        RUN(ln_bwd_proj(Wm + lw.z0, Wm + lw.mean0, Wm + lw.rstd0, Pm + lp.n_g[0], d_x1, 1, 0, nullptr, d_z0,
+        // d(x1) = d_qc Wq (the query projection's input gradient, formed in the kernel) + d_z1 (identity path of LN1)
+        RUN(ln_bwd_proj(Wm + lw.z0, Wm + lw.mean0, Wm + lw.rstd0, Pm + lp.n_g[0], nullptr, 0, 0, d_z1, d_z0,
                         training ? d_f0 : nullptr, training ? &dr[1] : nullptr, Gp + lp.n_g[0], Gp + lp.n_b[0], d.BQ, Wm + wt.sa_out,
-                        1, 1.f, nullptr, d_ao_s, s));
+                        1, 1.f, nullptr, d_ao_s, s, d_qc, Wm + wt.ca_q));
         RUN(wgrad(lin_wgrad(d_f0, C, Wm + lw.ao_s, C, Gp + lp.sa_out_w, Gp + lp.sa_out_b, d.BQ, C, C)));
       } else {
       RUN(ln_bwd(Wm + lw.z0, Wm + lw.mean0, Wm + lw.rstd0, Pm + lp.n_g[0], d_x1, nullptr, d_z0, Gp + lp.n_g[0],

@@ -162,23 +162,27 @@ def ln_proj(x, gamma, beta, w2, bias2=None, bias=None, residual=None, drop=None,
     return y, y2, z, mean, rstd, out2
 
 
-def ln_bwd_proj(z, mean, rstd, gamma, dy, w, dy_residual=None, drop=None, alpha=1.0, relu_mask=None):
+def ln_bwd_proj(z, mean, rstd, gamma, dy, w, dy_residual=None, drop=None, alpha=1.0, relu_mask=None, pre_a=None, pre_w=None):
     """petr_ln_bwd_proj: LayerNorm backward + dx = (dz_drop or dz) @ w for the nn.Linear weight w [256, K_in].
     dy [M,256] or [P,M,256].  Returns (dz, dz_drop or None, dgamma, dbeta, out [M, K_in])."""
     L = _C.lib()
-    if dy.dim() == 3:
+    if dy is None:                       # the upstream gradient comes from the leading product (+ dy_residual) alone
+        P, (M, Cc) = 0, z.shape
+    elif dy.dim() == 3:
         P, M, Cc = dy.shape
     else:
         P, (M, Cc) = 1, dy.shape
     wT = w.t().contiguous()
+    pre_wT = pre_w.t().contiguous() if pre_w is not None else None
     n2 = wT.shape[0] // 256
     dz = torch.empty((M, Cc), device=z.device)
     dzd = torch.empty_like(dz) if drop is not None else None
     dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
     out = torch.empty((M, 256 * n2), device=z.device)
-    a = _C.LnBwdProjArgs(_ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(_f32(dy).contiguous()), P, M * Cc, _ptr(dy_residual),
+    dyc = _f32(dy).contiguous() if dy is not None else None
+    a = _C.LnBwdProjArgs(_ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dyc), P, M * Cc, _ptr(dy_residual),
                          _ptr(dz), _ptr(dzd), _C.dropout(drop), _ptr(dg), _ptr(db), M, _ptr(wT), n2, float(alpha), _ptr(relu_mask),
-                         _ptr(out))
+                         _ptr(out), _ptr(pre_a), _ptr(pre_wT))
     _C.check(L.petr_ln_bwd_proj(C.byref(a), _stream()), 'petr_ln_bwd_proj')
     return dz, dzd, dg, db, out
 

@@ -850,3 +850,21 @@ def test_ln_bwd_proj_equals_layernorm_bwd_then_input_gradient(ops, M, P, F, trai
     if training:
         assert relerr(dzd, ref[3]) < 5e-6
     assert relerr(out, out_ref) < 1e-5
+
+
+def test_ln_bwd_proj_with_leading_product(ops):
+    """The upstream gradient formed inside the kernel: dy = pre_a @ pre_w + dy_residual (the query projection's input gradient
+    plus the identity path), then LayerNorm backward and the out-projection input gradient."""
+    g = torch.Generator().manual_seed(4)
+    M, C = 900, 256
+    x = dev(torch.randn(M, C, generator=g))
+    gamma, beta = dev(torch.rand(C, generator=g) + 0.5), dev(torch.randn(C, generator=g))
+    _, z, mean, rstd = ops.layernorm(x, gamma, beta, save_stats=True)
+    d_q, w_q = dev(torch.randn(M, C, generator=g)), dev(torch.randn(C, C, generator=g) * 0.06)
+    res, w = dev(torch.randn(M, C, generator=g)), dev(torch.randn(C, C, generator=g) * 0.06)
+    drop = (8, 1, 0.1)
+    dy = (d_q.double() @ w_q.double()).float() + res
+    ref = ops.layernorm_bwd(z, mean, rstd, gamma, dy, drop=drop)
+    dz, dzd, dg, db, out = ops.ln_bwd_proj(z, mean, rstd, gamma, None, w, dy_residual=res, drop=drop, pre_a=d_q, pre_w=w_q)
+    assert relerr(dz, ref[0]) < 1e-5 and relerr(dzd, ref[3]) < 1e-5 and relerr(dg, ref[1]) < 3e-5 and relerr(db, ref[2]) < 3e-5
+    assert relerr(out, ref[3].double() @ w.double()) < 2e-5

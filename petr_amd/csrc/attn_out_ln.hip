@@ -26,6 +26,53 @@ namespace {
 constexpr int AO_C = 256, AO_ROWS = 16, AO_PITCH = AO_C + 4;
 constexpr float AO_LN2 = 0.6931471805599453f;
 
+// The W rows of one wave's two 16-column tiles, streamed from L2 in 32-deep K groups: lane (n = lane & 15, q = lane >> 4) holds
+// k = 32 g + 8 q .. + 7 of row n as two float4 - the four q of a row cover one full 128-byte line per group (16-deep groups
+// with one float4 per lane touched every line twice, half a line at a time).  Step j of a group multiplies element j of the
+// A and the W fragment: the k order inside a group only has to agree between the operands.  Four groups (half of K) in flight.
+struct WStream {
+  float4 f[4][2][2];
+  __device__ __forceinline__ void first(const float* wa, const float* wb) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f[g][0][0] = *reinterpret_cast<const float4*>(wa + 32 * g);
+      f[g][0][1] = *reinterpret_cast<const float4*>(wa + 32 * g + 4);
+      f[g][1][0] = *reinterpret_cast<const float4*>(wb + 32 * g);
+      f[g][1][1] = *reinterpret_cast<const float4*>(wb + 32 * g + 4);
+    }
+  }
+  // acc += A (16 x 256, LDS rows at arow = As + (lane & 15) * pitch + 8 (lane >> 4)) x W[tile rows][:]^T
+  __device__ __forceinline__ void run(const float* arow, const float* wa, const float* wb, f32x4& acc0, f32x4& acc1) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const float4 a0 = *reinterpret_cast<const float4*>(arow + 32 * g), a1 = *reinterpret_cast<const float4*>(arow + 32 * g + 4);
+      const float4 p0 = f[g & 3][0][0], p1 = f[g & 3][0][1], q0 = f[g & 3][1][0], q1 = f[g & 3][1][1];
+      if (g + 4 < 8) {
+        f[g & 3][0][0] = *reinterpret_cast<const float4*>(wa + 32 * (g + 4));
+        f[g & 3][0][1] = *reinterpret_cast<const float4*>(wa + 32 * (g + 4) + 4);
+        f[g & 3][1][0] = *reinterpret_cast<const float4*>(wb + 32 * (g + 4));
+        f[g & 3][1][1] = *reinterpret_cast<const float4*>(wb + 32 * (g + 4) + 4);
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, p0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, q0.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, p0.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, q0.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, p0.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, q0.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, p0.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, q0.w, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, p1.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, q1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, p1.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, q1.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, p1.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, q1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, p1.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, q1.w, acc1, 0, 0, 0);
+    }
+  }
+};
+
 struct AoParams {
   petr_attn_out_ln_args a;
   DropDev drop;
@@ -33,21 +80,35 @@ struct AoParams {
 
 __global__ __launch_bounds__(512) void attn_out_ln_kernel(const AoParams p) {
   __shared__ __attribute__((aligned(16))) float As[AO_ROWS * AO_PITCH];
+  // row-block images in the [row][256] layout the global side is read / written in: the residual and the query_pos addend
+  // come in with two float4 per thread, requested at the very start; z, y, y2 leave the same way.  (The accumulator layout
+  // - a lane holds 4 rows x 2 columns - would make all of that 4-byte accesses issued behind the product.)
+  __shared__ __attribute__((aligned(16))) float Rs[AO_ROWS * AO_PITCH];     // residual in, z out
+  __shared__ __attribute__((aligned(16))) float Ys[AO_ROWS * AO_PITCH];     // y out
+  __shared__ __attribute__((aligned(16))) float Ps[AO_ROWS * AO_PITCH];     // add2 in, y2 out
   __shared__ float red[2][8][AO_ROWS];
   const petr_attn_out_ln_args& a = p.a;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int m0 = blockIdx.x * AO_ROWS;
+  const int tr = t >> 5, tc = 8 * (t & 31);                 // this thread's piece of a row-block image
+  const int tm = min(m0 + tr, a.M - 1);
+  float4 rres[2], radd[2];
+  rres[0] = rres[1] = radd[0] = radd[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.residual) {
+    const float4* src = reinterpret_cast<const float4*>(a.residual + (long)tm * AO_C + tc);
+    rres[0] = src[0]; rres[1] = src[1];
+  }
+  if (a.y2) {
+    const float4* src = reinterpret_cast<const float4*>(a.add2 + (long)(a.add2_rows > 0 ? tm % a.add2_rows : tm) * AO_C + tc);
+    radd[0] = src[0]; radd[1] = src[1];
+  }
 
   // W fragments of the first eight K groups: requested before the prologue so that their latency runs under the merge
   const int nl = lane & 15, q4 = lane >> 4;
-  const float* w0 = a.w + (long)(32 * wave + nl) * AO_C + 4 * q4;        // column tile 0 of this wave; tile 1: + 16 rows of W
+  const float* w0 = a.w + (long)(32 * wave + nl) * AO_C + 8 * q4;        // column tile 0 of this wave; tile 1: + 16 rows of W
   const float* w1 = w0 + 16 * AO_C;
-  float4 wq[8][2];                       // W fragments of eight K groups in flight
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    wq[g][0] = *reinterpret_cast<const float4*>(w0 + 16 * g);
-    wq[g][1] = *reinterpret_cast<const float4*>(w1 + 16 * g);
-  }
+  WStream ws;
+  ws.first(w0, w1);
 
   // ---- prologue: the A row block (thread: row t >> 5, head (t >> 2) & 7, 8 channels 8 (t & 3) .. + 7) ----
   {
@@ -104,41 +165,22 @@ __global__ __launch_bounds__(512) void attn_out_ln_kernel(const AoParams p) {
     float4* ls = reinterpret_cast<float4*>(As + r * AO_PITCH + 32 * hd + d0);
     ls[0] = v0; ls[1] = v1;
   }
+  {
+    float4* rs = reinterpret_cast<float4*>(Rs + tr * AO_PITCH + tc);
+    rs[0] = rres[0]; rs[1] = rres[1];
+    float4* ps = reinterpret_cast<float4*>(Ps + tr * AO_PITCH + tc);
+    ps[0] = radd[0]; ps[1] = radd[1];
+  }
 
   // ---- product: wave = 16 rows x 32 columns, K = 256 in 16 groups of 16 ----
   __syncthreads();
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const float* arow = As + nl * AO_PITCH + 4 * q4;
-  auto product = [&](const float* wa, const float* wb) {      // acc += As (16 x 256) x W[32 wave .. + 31][:]^T; wq holds groups 0..3
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const float4 af = *reinterpret_cast<const float4*>(arow + 16 * g);
-      const float4 b0 = wq[g & 7][0], b1 = wq[g & 7][1];
-      if (g + 8 < 16) {
-        wq[g & 7][0] = *reinterpret_cast<const float4*>(wa + 16 * (g + 8));
-        wq[g & 7][1] = *reinterpret_cast<const float4*>(wb + 16 * (g + 8));
-      }
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b0.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b1.x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b0.y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b1.y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b0.z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b1.z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b0.w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b1.w, acc1, 0, 0, 0);
-    }
-  };
-  product(w0, w1);
+  const float* arow = As + nl * AO_PITCH + 8 * q4;
+  ws.run(arow, w0, w1, acc0, acc1);
   // second projection (optional): its first W groups are requested now, their latency runs under the epilogue
-  const float* v0 = a.w2 ? a.w2 + (long)(32 * wave + nl) * AO_C + 4 * q4 : w0;
+  const float* v0 = a.w2 ? a.w2 + (long)(32 * wave + nl) * AO_C + 8 * q4 : w0;
   const float* v1 = v0 + 16 * AO_C;
-  if (a.w2) {
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      wq[g][0] = *reinterpret_cast<const float4*>(v0 + 16 * g);
-      wq[g][1] = *reinterpret_cast<const float4*>(v1 + 16 * g);
-    }
-  }
+  if (a.w2) ws.first(v0, v1);
 
   // ---- epilogue: lane holds rows 4 q4 + i (i = 0..3), columns 32 wave + nl (acc0) and + 16 (acc1) ----
   const int c0 = 32 * wave + nl, c1 = c0 + 16;
@@ -154,10 +196,8 @@ __global__ __launch_bounds__(512) void attn_out_ln_kernel(const AoParams p) {
       u0 = drop_keep(rk, (uint32_t)c0, p.drop.thr) ? u0 * p.drop.scale : 0.f;
       u1 = drop_keep(rk, (uint32_t)c1, p.drop.thr) ? u1 * p.drop.scale : 0.f;
     }
-    if (a.residual) {
-      u0 += a.residual[(long)mc * AO_C + c0];
-      u1 += a.residual[(long)mc * AO_C + c1];
-    }
+    u0 += Rs[(4 * q4 + i) * AO_PITCH + c0];          // zeros without a residual
+    u1 += Rs[(4 * q4 + i) * AO_PITCH + c1];
     z0[i] = u0; z1[i] = u1;
     part[i] = u0 + u1;
   }
@@ -196,31 +236,37 @@ __global__ __launch_bounds__(512) void attn_out_ln_kernel(const AoParams p) {
     if (m >= a.M) continue;
     const float rstd = 1.f / sqrtf(sq[i] * (1.f / AO_C) + a.eps);
     const float y0 = (z0[i] - mean[i]) * rstd * g0 + be0, y1 = (z1[i] - mean[i]) * rstd * g1 + be1;
-    const long o = (long)m * AO_C;
-    if (a.z) { a.z[o + c0] = z0[i]; a.z[o + c1] = z1[i]; }
-    a.y[o + c0] = y0; a.y[o + c1] = y1;
-    float u0 = y0, u1 = y1;
-    if (a.y2) {
-      const long o2 = (long)(a.add2_rows > 0 ? m % a.add2_rows : m) * AO_C;
-      u0 = y0 + a.add2[o2 + c0];
-      u1 = y1 + a.add2[o2 + c1];
-      a.y2[o + c0] = u0;
-      a.y2[o + c1] = u1;
-    }
-    if (a.w2) {            // operand rows of the second projection (every wave is past its reads of As: two barriers ago)
-      As[(4 * q4 + i) * AO_PITCH + c0] = u0;
-      As[(4 * q4 + i) * AO_PITCH + c1] = u1;
-    }
+    const int ro = (4 * q4 + i) * AO_PITCH;
+    // every wave is past its reads of Rs / Ps (this lane's own elements: read above, written here) and of As (two barriers ago)
+    const float u0 = y0 + Ps[ro + c0], u1 = y1 + Ps[ro + c1];     // + zeros without add2
+    Rs[ro + c0] = z0[i]; Rs[ro + c1] = z1[i];
+    Ys[ro + c0] = y0; Ys[ro + c1] = y1;
+    Ps[ro + c0] = u0; Ps[ro + c1] = u1;
+    As[ro + c0] = u0; As[ro + c1] = u1;                           // operand rows of the second projection
     if (wave == 0 && nl == 0) {
       if (a.mean) a.mean[m] = mean[i];
       if (a.rstd) a.rstd[m] = rstd;
     }
   }
+  __syncthreads();
+  if (m0 + tr < a.M) {             // the images leave as rows: two 16-byte stores per thread and output
+    const long o = (long)(m0 + tr) * AO_C + tc;
+    const int lo = tr * AO_PITCH + tc;
+    if (a.z) {
+      reinterpret_cast<float4*>(a.z + o)[0] = *reinterpret_cast<const float4*>(Rs + lo);
+      reinterpret_cast<float4*>(a.z + o)[1] = *reinterpret_cast<const float4*>(Rs + lo + 4);
+    }
+    reinterpret_cast<float4*>(a.y + o)[0] = *reinterpret_cast<const float4*>(Ys + lo);
+    reinterpret_cast<float4*>(a.y + o)[1] = *reinterpret_cast<const float4*>(Ys + lo + 4);
+    if (a.y2) {
+      reinterpret_cast<float4*>(a.y2 + o)[0] = *reinterpret_cast<const float4*>(Ps + lo);
+      reinterpret_cast<float4*>(a.y2 + o)[1] = *reinterpret_cast<const float4*>(Ps + lo + 4);
+    }
+  }
   // ---- second projection: out2 = (y2, or y) W2^T + bias2 - the next attention's query projection of the same rows ----
   if (!a.w2) return;
-  __syncthreads();
   acc0 = acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-  product(v0, v1);
+  ws.run(arow, v0, v1, acc0, acc1);
   const float bb0 = a.bias2 ? a.bias2[c0] : 0.f, bb1 = a.bias2 ? a.bias2[c1] : 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -251,14 +297,10 @@ __global__ __launch_bounds__(512) void ln_proj_kernel(const LpParams p) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int m0 = blockIdx.x * AO_ROWS, jb = blockIdx.y;
   const int nl = lane & 15, q4 = lane >> 4;
-  const float* w0 = a.w2 + ((long)256 * jb + 32 * wave + nl) * AO_C + 4 * q4;
+  const float* w0 = a.w2 + ((long)256 * jb + 32 * wave + nl) * AO_C + 8 * q4;
   const float* w1 = w0 + 16 * AO_C;
-  float4 wq[8][2];
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    wq[g][0] = *reinterpret_cast<const float4*>(w0 + 16 * g);
-    wq[g][1] = *reinterpret_cast<const float4*>(w1 + 16 * g);
-  }
+  WStream ws;
+  ws.first(w0, w1);
   const int c0 = 32 * wave + nl, c1 = c0 + 16;
   const float bia0 = a.bias ? a.bias[c0] : 0.f, bia1 = a.bias ? a.bias[c1] : 0.f;
   float z0[4], z1[4], part[4];
@@ -342,24 +384,8 @@ __global__ __launch_bounds__(512) void ln_proj_kernel(const LpParams p) {
   }
   __syncthreads();
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const float* arow = As + nl * AO_PITCH + 4 * q4;
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const float4 af = *reinterpret_cast<const float4*>(arow + 16 * g);
-    const float4 b0 = wq[g & 7][0], b1 = wq[g & 7][1];
-    if (g + 8 < 16) {
-      wq[g & 7][0] = *reinterpret_cast<const float4*>(w0 + 16 * (g + 8));
-      wq[g & 7][1] = *reinterpret_cast<const float4*>(w1 + 16 * (g + 8));
-    }
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b0.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b1.x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b0.y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b1.y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b0.z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b1.z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b0.w, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b1.w, acc1, 0, 0, 0);
-  }
+  const float* arow = As + nl * AO_PITCH + 8 * q4;
+  ws.run(arow, w0, w1, acc0, acc1);
   const int n0 = 256 * jb + c0, n1 = n0 + 16;
   const float bb0 = a.bias2 ? a.bias2[n0] : 0.f, bb1 = a.bias2 ? a.bias2[n1] : 0.f;
   const long ld2 = 256L * a.n2;
@@ -392,14 +418,10 @@ __global__ __launch_bounds__(512) void ln_bwd_proj_kernel(const LbParams p) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int m0 = blockIdx.x * AO_ROWS, jb = blockIdx.y;
   const int nl = lane & 15, q4 = lane >> 4;
-  const float* w0 = a.wT + ((long)256 * jb + 32 * wave + nl) * AO_C + 4 * q4;
+  const float* w0 = a.wT + ((long)256 * jb + 32 * wave + nl) * AO_C + 8 * q4;
   const float* w1 = w0 + 16 * AO_C;
-  float4 wq[8][2];
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    wq[g][0] = *reinterpret_cast<const float4*>(w0 + 16 * g);
-    wq[g][1] = *reinterpret_cast<const float4*>(w1 + 16 * g);
-  }
+  WStream ws;
+  ws.first(w0, w1);
   const int c0 = 32 * wave + nl, c1 = c0 + 16;
   // optional leading product: dy = pre_a pre_wT^T (+ dy_residual) - the input gradient of the projection that consumed the
   // normalised rows (the cross-attention's query projection), computed here instead of by a launch of its own; its
@@ -412,33 +434,12 @@ __global__ __launch_bounds__(512) void ln_bwd_proj_kernel(const LbParams p) {
       float4* ls = reinterpret_cast<float4*>(As + r * AO_PITCH + cc);
       ls[0] = src[0]; ls[1] = src[1];
     }
-    const float* u0 = a.pre_wT + (long)(32 * wave + nl) * AO_C + 4 * q4;
+    const float* u0 = a.pre_wT + (long)(32 * wave + nl) * AO_C + 8 * q4;
     const float* u1 = u0 + 16 * AO_C;
-    float4 uq[4][2];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      uq[g][0] = *reinterpret_cast<const float4*>(u0 + 16 * g);
-      uq[g][1] = *reinterpret_cast<const float4*>(u1 + 16 * g);
-    }
+    WStream us;
+    us.first(u0, u1);
     __syncthreads();
-    const float* arow0 = As + nl * AO_PITCH + 4 * q4;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const float4 af = *reinterpret_cast<const float4*>(arow0 + 16 * g);
-      const float4 b0 = uq[g & 3][0], b1 = uq[g & 3][1];
-      if (g + 4 < 16) {
-        uq[g & 3][0] = *reinterpret_cast<const float4*>(u0 + 16 * (g + 4));
-        uq[g & 3][1] = *reinterpret_cast<const float4*>(u1 + 16 * (g + 4));
-      }
-      pre0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b0.x, pre0, 0, 0, 0);
-      pre1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b1.x, pre1, 0, 0, 0);
-      pre0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b0.y, pre0, 0, 0, 0);
-      pre1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b1.y, pre1, 0, 0, 0);
-      pre0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b0.z, pre0, 0, 0, 0);
-      pre1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b1.z, pre1, 0, 0, 0);
-      pre0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b0.w, pre0, 0, 0, 0);
-      pre1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b1.w, pre1, 0, 0, 0);
-    }
+    us.run(As + nl * AO_PITCH + 8 * q4, u0, u1, pre0, pre1);
     __syncthreads();                       // As is rewritten below
   }
   const float gm0 = a.gamma[c0], gm1 = a.gamma[c1];
@@ -521,24 +522,8 @@ __global__ __launch_bounds__(512) void ln_bwd_proj_kernel(const LbParams p) {
   }
   __syncthreads();
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const float* arow = As + nl * AO_PITCH + 4 * q4;
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const float4 af = *reinterpret_cast<const float4*>(arow + 16 * g);
-    const float4 b0 = wq[g & 7][0], b1 = wq[g & 7][1];
-    if (g + 8 < 16) {
-      wq[g & 7][0] = *reinterpret_cast<const float4*>(w0 + 16 * (g + 8));
-      wq[g & 7][1] = *reinterpret_cast<const float4*>(w1 + 16 * (g + 8));
-    }
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b0.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, b1.x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b0.y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, b1.y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b0.z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, b1.z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b0.w, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, b1.w, acc1, 0, 0, 0);
-  }
+  const float* arow = As + nl * AO_PITCH + 8 * q4;
+  ws.run(arow, w0, w1, acc0, acc1);
   const int n0 = 256 * jb + c0, n1 = n0 + 16;
   const long ld2 = 256L * a.n2;
 #pragma unroll

@@ -353,6 +353,10 @@ def test_head_p4_1408_forward(pa):
 # CPU oracle, stated separately from the fp32 bar (SURVEY 8(d) config 3 expected ~1e-2 rel; the head-level outputs turn
 # out far tighter than the operator-level bound in tests/test_ops_gpu.py, so the bar here is 1e-3).
 REL_BF16 = 1e-3      # measured 7e-5 (cls) / 5e-5 (bbox) at p4-1408: the rounding noise averages out over 16 896 keys
+# the bf16 TRAINING step also runs the FFN contractions (2048-wide hidden) and the token-side activations / weights in bf16, as
+# autocast does: measured 1.0e-3 (cls) at c5 with dropout, 3e-4 ... 6e-4 at the larger workloads; still 3x inside SURVEY 8(d)'s
+# expected ~1e-2 for this configuration
+REL_BF16_TRAIN = 3e-3
 
 
 def test_head_p4_1408_forward_bf16_attention(pa):
@@ -384,7 +388,7 @@ def test_head_p4_1408_forward_bf16_attention(pa):
 # is identically zero (softmax shift invariance) or below 1e-3 of the largest gradient entry: absolute error <= 1e-3 of
 # that entry.
 def _bf16_grad_case(pa, head, oracle, feats, metas, g_cls, g_box, masks=None, l2_bar=0.25, cos_bar=0.97, flat_bar=0.10,
-                    out_bar=REL_BF16):
+                    out_bar=REL_BF16_TRAIN):
     want, wgrads, wfeat = _oracle_grads(oracle, feats, metas, g_cls, g_box, torch.float64, masks)
     head.attn_dtype = 'bf16'
     head.zero_grad_flat()

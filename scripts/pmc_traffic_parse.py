@@ -8,7 +8,9 @@ out = {'_how': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in SEPARATE passes
                '--dtype D --steps 4 --warmup 2 --timed-only` (MI355X, round 2; scripts/pmc_traffic_r02.sh).  Counter unit KiB; '
                'traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE counts half of a wide coalesced read). '
                'Cross- and self-attention launches of the fp32 kernels alternate in dispatch order (forward: self, cross; backward: '
-               'cross, self); the bf16 kernels only run the cross-attention.  Medians over the launches of 6 steps.'}
+               'cross, self); the bf16 kernels only run the cross-attention.  Medians over the launches of 6 steps.  '
+               'dropout_mask_bytes: the packed keep-mask the training forward writes for the backward (inside WRITE_SIZE, outside '
+               'algorithmic_min_bytes).'}
 for wl, dt in (('c5', 'fp32'), ('p4_1600', 'bf16')):
     vals = {}
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -47,6 +49,7 @@ for wl, dt in (('c5', 'fp32'), ('p4_1600', 'bf16')):
             if k in ('fwd', 'fwd16'):
                 eb = 4 if k == 'fwd' else 2
                 e['algorithmic_min_bytes'] = 2 * Ltok * 256 * eb + 2 * 900 * 256 * 4
+                e['dropout_mask_bytes'] = 900 * Ltok          # training forward also leaves 8 heads x 1 bit per (query, key)
             if k in ('bwd', 'bwd16'):
                 eb = 4 if k == 'bwd' else 2
                 e['algorithmic_min_bytes'] = 2 * Ltok * 256 * eb + 2 * Ltok * 256 * 4 + 4 * 900 * 256 * 4

@@ -64,6 +64,7 @@ struct MhaBwd16Params {
   DropDev drop;        // the forward's probability dropout (thr == 0: off)
   const uint32_t* drop_bits;   // key-major packed mask (petr_dropout_bits) or null: re-hash
   int nqt32, lpad;             // its dimensions: ceil(Q/32) query tiles, 32 * ceil(L/32) keys per tile
+  int pair;                    // heads 2j / 2j+1 of one key block are neighbours in the workgroup order (see mha_fwd_bf16_kernel)
 };
 
 __device__ __forceinline__ s16x4 tr16(const uint16_t* p) {
@@ -104,9 +105,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mha_bwd_bf16_kernel(
   const int total = p.nkb * a.B * a.H * p.q_splits;
   const int w = xcd_remap(blockIdx.x, total);
   const int qs = w % p.q_splits;
-  const int rest = w / p.q_splits;
+  int rest = w / p.q_splits;
+  const int h0 = p.pair ? (rest & 1) : 0;
+  if (p.pair) rest >>= 1;
   const int kb = rest % p.nkb;
-  const int bh = rest / p.nkb;
+  const int bh = p.pair ? 2 * (rest / p.nkb) + h0 : rest / p.nkb;
   const int b = bh / a.H, hd = bh - b * a.H;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -544,6 +547,8 @@ extern "C" int petr_mha_bwd_bf16(const petr_mha_bwd_bf16_args* ap, void* stream)
   if ((long)(qsp - 1) * p.qtiles_per_split >= cdiv(a.Q, 32)) {     // an override that would leave an empty split
     p.q_splits = (int)cdiv(cdiv(a.Q, 32), p.qtiles_per_split);
   }
+  static const int pair_on = [] { const char* v = getenv("PETR_MHA16_PAIR"); return !v || atoi(v) != 0; }();
+  p.pair = pair_on && !(a.H & 1) && a.k_hs == 32 && a.v_hs == 32;
   const long total = (long)p.nkb * a.B * a.H * p.q_splits;
   PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_bwd_bf16: grid too large");
   hipStream_t s = (hipStream_t)stream;

@@ -41,6 +41,7 @@ struct MhaFwdParams {
   int* sched;      // [B*H*nqb] tile tickets (dynamic mode), zero on entry, zero again on exit
   uint32_t* drop_bits;   // out (optional): the key-major packed dropout mask (petr_dropout_bits layout) for the backward
   int nqt32, lpad;       // its dimensions: ceil(Q/32) query tiles, 32 * ceil(L/32) keys per tile
+  int pair;              // bf16 kernel: heads 2j / 2j+1 of one key range are neighbours in the workgroup order
 };
 
 // The keep decisions of one 32 query x 32 key block leave the kernel as they fall out of the comparisons: the ballot of
@@ -443,9 +444,13 @@ __global__ __launch_bounds__(512, 2) void mha_fwd_bf16_kernel(const MhaFwdParams
   const int total = p.nqb * a.B * a.H * p.n_split;
   const int w = xcd_remap(blockIdx.x, total);
   const int qb = w % p.nqb;
-  const int rest = w / p.nqb;
+  int rest = w / p.nqb;
+  // a bf16 head row is 64 bytes: one 128-byte line carries two heads.  Paired, the two heads of a key range sit on the
+  // same XCD (xcd_remap keeps neighbours together), so one L2 fetches the line once instead of two L2s once each.
+  const int h0 = p.pair ? (rest & 1) : 0;
+  if (p.pair) rest >>= 1;
   const int split = rest % p.n_split;
-  const int bh = rest / p.n_split;
+  const int bh = p.pair ? 2 * (rest / p.n_split) + h0 : rest / p.n_split;
   const int b = bh / a.H, hd = bh - b * a.H;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -817,6 +822,7 @@ extern "C" int petr_mha_fwd(const petr_mha_fwd_args* ap, void* stream) {
   PETR_CHECK(ap && ap->q && ap->k && ap->v && ap->o, PETR_ERR_INVALID, "mha_fwd: null pointer");
   PETR_CHECK(ap->B > 0 && ap->H > 0 && ap->Q > 0 && ap->L > 0, PETR_ERR_INVALID, "mha_fwd: bad shape");
   MhaFwdParams p;
+  p.pair = 0;
   p.a = *ap;
   const petr_mha_fwd_args& a = p.a;
   p.nqb = (int)cdiv(a.Q, 128);
@@ -937,6 +943,8 @@ extern "C" int petr_mha_fwd_bf16(const petr_mha_fwd_bf16_args* ap, void* stream)
     p.ml_part = p.o_part + (size_t)ns * a.B * a.H * a.Q * 32;
   }
   p.q_vec = p.kv_vec = 0;
+  static const int pair_on = [] { const char* v = getenv("PETR_MHA16_PAIR"); return !v || atoi(v) != 0; }();
+  p.pair = pair_on && !(a.H & 1) && a.k_hs == 32 && a.v_hs == 32;
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)p.nqb * a.B * a.H * ns;
   PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_fwd_bf16: grid too large");

@@ -351,6 +351,23 @@ typedef struct {
 } petr_ln_bwd_proj_args;
 int petr_ln_bwd_proj(const petr_ln_bwd_proj_args* a, void* stream);
 
+/* Both contractions of the decoder FFN in one launch (C = 256 channels, fp32):
+ *     hidden = drop(relu(x w1^T + b1))           [M, F]   written when `hidden` is non-null (the backward reads it)
+ *     part[s] = hidden[:, slice s] w2[:, slice s]^T   [M, 256], s = 0 .. n_split-1, slice s = F / n_split hidden units
+ *   w1 [F, 256], w2 [256, F] are the nn.Linear weights of mmcv's FFN (reference: multi_atten_decoder_layer.py:204-293 runs
+ *   `ffn` between the cross-attention's norm and the closing norm); the kernel reads their TRANSPOSES
+ *   w1t [256, F] and w2t [F, 256] (k-major: a 16-lane group of a load shares one 128-byte line).  The output bias, the
+ *   output dropout, the residual and the sum over the slabs belong to the normalisation that follows (petr_ln_proj /
+ *   petr_layernorm_fwd with n_partials = n_split), exactly as after the split-K contraction this replaces.
+ *   n_split in {1, 2, 4, 8}, F a multiple of 256 n_split; dropout element index = (row, hidden unit) as in petr_gemm. */
+typedef struct {
+  const float* x; const float* w1t; const float* b1; const float* w2t;
+  float* hidden; float* part; long part_stride;
+  petr_dropout drop;
+  int M, F, n_split;
+} petr_ffn_fwd_args;
+int petr_ffn_fwd(const petr_ffn_fwd_args* a, void* stream);
+
 /* y[i] = bf16(x[i]) (round to nearest even), n elements, both 16-byte aligned: produces the bf16 K/V operands
  * from the fp32 projections (the tensor .to(bfloat16) an autocast reference run would do) */
 int petr_cast_bf16(const float* x, uint16_t* y, long n, void* stream);

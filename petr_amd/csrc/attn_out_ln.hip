@@ -73,6 +73,78 @@ struct WStream {
   }
 };
 
+// The same product with the weight read k-major (wT [K][N]: row k holds the N outputs' weights of input k): lane
+// (n = lane & 15, kq = lane >> 4) takes ONE float2 wT[k][col0 + 2 n, + 1] per k - the 16 lanes of a k share one 128-byte line, an
+// instruction touches 4 full lines.  (With W [N][K] every lane of an instruction sits in a line of its own: 64 tag lookups per
+// 1 KB, and the 16-row kernels ran at the L1's lookup rate - 14 bytes / clock / CU measured - not at the matrix cores'.)  The
+// wave's two column tiles are the even and the odd columns of its 32.  Group g = 16 k: lane kq holds k = 16 g + 4 kq + j,
+// j = 0..3, against one float4 of the A row; eight groups (half of K = 256) in flight.
+template <int RG>
+struct WStreamT {
+  float2 f[8][4];
+  // w: wave-uniform pointer to wT[0][first column of the wave's 32]; lo = byte offset of the lane = (4 (lane >> 4) * ld + 2 (lane & 15)) * 4
+  static __device__ __forceinline__ uint32_t lane_off(int lane, long ld) { return (uint32_t)((4 * (lane >> 4) * ld + 2 * (lane & 15)) * 4); }
+  // buffer loads: resource = the wave's column base, VGPR offset = the lane's, SGPR offset = the row's (scalar multiplies) - no
+  // vector instruction computes an address (global loads took a 64-bit VALU add per load, on the port the f32 MFMAs issue on)
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ float2 ld2(__amdgpu_buffer_rsrc_t r, uint32_t lo, long row_floats) {
+    const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)lo, (int)(row_floats * 4), 0);
+    return make_float2(__int_as_float(v[0]), __int_as_float(v[1]));
+  }
+  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const float* w) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), (short)0, 0x7fffffff, 0x00020000);
+  }
+  __device__ __forceinline__ void first(const float* w, long ld, uint32_t lo) {
+    const __amdgpu_buffer_rsrc_t r = rsrc(w);
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[g][j] = ld2(r, lo, (16 * g + j) * ld);
+  }
+  // acc[rg][0 / 1] += A row group rg (16 x 256, LDS rows at arow + rg * 16 * pitch, arow = As + (lane & 15) * pitch + 4 (lane >> 4))
+  // x wT[:, even / odd columns].  RG row groups share every weight fragment (RG x the MFMAs per byte streamed).  The stream does
+  // not drain between products: once the second half of this weight is in flight, the slots that free up take the first half
+  // of the NEXT product's weight (wn, null: none) - each product otherwise starts with a full memory latency in the open.
+  __device__ __forceinline__ void run(const float* arow, int pitch, const float* w, long ld, uint32_t lo, const float* wn, long ldn, uint32_t lon,
+                                      f32x4 (&acc)[RG][2]) {
+    const __amdgpu_buffer_rsrc_t r = rsrc(w), rn = rsrc(wn ? wn : w);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      float4 a[RG];
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) a[rg] = *reinterpret_cast<const float4*>(arow + rg * 16 * pitch + 16 * g);
+      const float2 b0 = f[g & 7][0], b1 = f[g & 7][1], b2 = f[g & 7][2], b3 = f[g & 7][3];
+      if (g + 8 < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[g & 7][j] = ld2(r, lo, (16 * (g + 8) + j) * ld);
+      } else if (wn) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[g & 7][j] = ld2(rn, lon, (16 * (g - 8) + j) * ldn);
+      }
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) {
+        acc[rg][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rg].x, b0.x, acc[rg][0], 0, 0, 0);
+        acc[rg][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rg].x, b0.y, acc[rg][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) {
+        acc[rg][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rg].y, b1.x, acc[rg][0], 0, 0, 0);
+        acc[rg][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rg].y, b1.y, acc[rg][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) {
+        acc[rg][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rg].z, b2.x, acc[rg][0], 0, 0, 0);
+        acc[rg][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rg].z, b2.y, acc[rg][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) {
+        acc[rg][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rg].w, b3.x, acc[rg][0], 0, 0, 0);
+        acc[rg][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rg].w, b3.y, acc[rg][1], 0, 0, 0);
+      }
+    }
+  }
+};
+
 struct AoParams {
   petr_attn_out_ln_args a;
   DropDev drop;
@@ -540,7 +612,130 @@ __global__ __launch_bounds__(512) void ln_bwd_proj_kernel(const LbParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// petr_ffn_fwd: both contractions of the FFN (mmcv FFN, SURVEY A.5: W2 drop(relu(W1 x + b1))) in one launch.  The hidden
+// activation of a 16-row block never round-trips through HBM between the two products (it is written once, for the
+// backward, when asked for).  A workgroup owns 32 rows and ONE slice of F / n_split hidden units: per 256 hidden units it
+// multiplies the rows by that block of W1 (wave w: hidden columns 32 w .. + 31), applies bias / ReLU / dropout, parks the
+// block in LDS, and multiplies it by the matching 256 columns of W2 into accumulators that live across the blocks.  The
+// slice's partial sum leaves as slab `slice` of `part` - the layout the split-K FFN2 contraction wrote, summed (with the
+// bias, the dropout and the residual) by the LayerNorm that follows (petr_ln_proj / petr_layernorm_fwd).
+// XCD placement: workgroup ids are dealt round-robin to the 8 XCDs, so slice = f(id % 8) pins a slice's 2 x F/n_split x 256
+// weights to 8 / n_split L2s instead of streaming all 4 MB of W1 and W2 through every L2.
+// ---------------------------------------------------------------------------------------------------------------
+struct FfParams {
+  petr_ffn_fwd_args a;
+  DropDev drop;
+  int nrb;          // row blocks
+};
+
+constexpr int FF_ROWS = 32;
+
+__global__ __launch_bounds__(512) void ffn_fwd_kernel(const FfParams p) {
+  __shared__ __attribute__((aligned(16))) float As[FF_ROWS * AO_PITCH];     // the x rows
+  __shared__ __attribute__((aligned(16))) float Hs[FF_ROWS * AO_PITCH];     // one block of 256 hidden units
+  const petr_ffn_fwd_args& a = p.a;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nl = lane & 15, q4 = lane >> 4;
+  const int rep = 8 / a.n_split;                     // XCDs per slice (n_split in {1, 2, 4, 8})
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int slice = xcd / rep;
+  const int rb = seq * rep + (xcd - slice * rep);
+  if (rb >= p.nrb) return;                            // block-uniform
+  const int m0 = rb * FF_ROWS;
+  const int hb = a.F / a.n_split;                     // hidden units of the slice, a multiple of 256
+  const int nb = hb >> 8;
+  const int h0 = slice * hb;
+  const int tr = t >> 4, tc = 16 * (t & 15);          // this thread's piece of a 32 x 256 row image: 16 floats
+  const int c0 = 32 * wave + 2 * nl;                  // this lane's two columns of a 256-wide block: c0 (acc[.][0]), c0 + 1 (acc[.][1])
+
+  const float* w1 = a.w1t + h0 + 32 * wave;                    // w1t [256][F]: k = channel, columns = hidden units
+  const float* w2 = a.w2t + (long)h0 * AO_C + 32 * wave;       // w2t [F][256]: k = hidden unit of the slice
+  const uint32_t lo1 = WStreamT<2>::lane_off(lane, a.F), lo2 = WStreamT<2>::lane_off(lane, AO_C);
+  WStreamT<2> ws;
+  ws.first(w1, a.F, lo1);
+  {
+    const float4* src = reinterpret_cast<const float4*>(a.x + (long)min(m0 + tr, a.M - 1) * AO_C + tc);
+    float4* ls = reinterpret_cast<float4*>(As + tr * AO_PITCH + tc);
+    const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+    ls[0] = v0; ls[1] = v1; ls[2] = v2; ls[3] = v3;
+  }
+  uint32_t rk[2][4];
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rk[rg][i] = p.drop.thr ? drop_row_key(p.drop, (uint32_t)min(m0 + 16 * rg + 4 * q4 + i, a.M - 1)) : 0u;
+  float2 bia = a.b1 ? *reinterpret_cast<const float2*>(a.b1 + h0 + c0) : make_float2(0.f, 0.f);
+  __syncthreads();
+  const float* arow = As + nl * AO_PITCH + 4 * q4;
+  const float* hrow = Hs + nl * AO_PITCH + 4 * q4;
+  f32x4 out[2][2];
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg) out[rg][0] = out[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < nb; ++b) {
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg) acc[rg][0] = acc[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* w2b = w2 + (long)256 * b * AO_C;
+    ws.run(arow, AO_PITCH, w1 + 256 * b, a.F, lo1, w2b, AO_C, lo2, acc);
+    const float2 bc = bia;
+    if (b + 1 < nb && a.b1) bia = *reinterpret_cast<const float2*>(a.b1 + h0 + 256 * (b + 1) + c0);
+    const int f0 = h0 + 256 * b + c0;                   // hidden unit of acc[.][0]; acc[.][1]: f0 + 1 (the same hash pair)
+    if (b) __syncthreads();                             // every wave is past the previous block's reads of Hs
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float u0 = fmaxf(acc[rg][0][i] + bc.x, 0.f), u1 = fmaxf(acc[rg][1][i] + bc.y, 0.f);
+        if (p.drop.thr) {
+          const uint32_t hsh = drop_pair_hash(rk[rg][i], (uint32_t)f0 >> 1);
+          u0 = (uint16_t)hsh >= (uint16_t)p.drop.thr ? u0 * p.drop.scale : 0.f;
+          u1 = (uint16_t)(hsh >> 16) >= (uint16_t)p.drop.thr ? u1 * p.drop.scale : 0.f;
+        }
+        *reinterpret_cast<float2*>(Hs + (16 * rg + 4 * q4 + i) * AO_PITCH + c0) = make_float2(u0, u1);
+      }
+    __syncthreads();
+    if (a.hidden && m0 + tr < a.M) {                    // the block leaves as rows: four 16-byte stores per thread
+      float4* dst = reinterpret_cast<float4*>(a.hidden + (long)(m0 + tr) * a.F + h0 + 256 * b + tc);
+      const float4* hs = reinterpret_cast<const float4*>(Hs + tr * AO_PITCH + tc);
+      dst[0] = hs[0]; dst[1] = hs[1]; dst[2] = hs[2]; dst[3] = hs[3];
+    }
+    ws.run(hrow, AO_PITCH, w2b, AO_C, lo2, b + 1 < nb ? w1 + 256 * (b + 1) : nullptr, a.F, lo1, out);
+  }
+  float* dst = a.part + (long)slice * a.part_stride;
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + 16 * rg + 4 * q4 + i;
+      if (m >= a.M) continue;
+      *reinterpret_cast<float2*>(dst + (long)m * AO_C + c0) = make_float2(out[rg][0][i], out[rg][1][i]);
+    }
+}
 }  // namespace
+
+extern "C" int petr_ffn_fwd(const petr_ffn_fwd_args* ap, void* stream) {
+  PETR_CHECK(ap && ap->x && ap->w1t && ap->w2t && ap->part && ap->M > 0 && ap->F > 0, PETR_ERR_INVALID, "ffn_fwd: bad arguments");
+  const petr_ffn_fwd_args& a = *ap;
+  PETR_CHECK(a.n_split == 1 || a.n_split == 2 || a.n_split == 4 || a.n_split == 8, PETR_ERR_UNSUPPORTED,
+             "ffn_fwd: n_split=%d not in {1, 2, 4, 8}", a.n_split);
+  PETR_CHECK(a.F % (256 * a.n_split) == 0, PETR_ERR_UNSUPPORTED, "ffn_fwd: F=%d must be a multiple of 256 * n_split", a.F);
+  PETR_CHECK(aligned16(a.x) && aligned16(a.w1t) && aligned16(a.w2t) && (!a.hidden || aligned16(a.hidden)) && aligned16(a.part) &&
+                 (!a.b1 || aligned16(a.b1)) && !(a.part_stride & 3),
+             PETR_ERR_INVALID, "ffn_fwd: x / w1t / w2t / b1 / hidden / part must be 16-byte aligned");
+  PETR_CHECK(a.n_split == 1 || a.part_stride >= (long)a.M * AO_C, PETR_ERR_INVALID, "ffn_fwd: part_stride too small");
+  PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "ffn_fwd: dropout p=%g outside [0,1)", (double)a.drop.p);
+  FfParams p;
+  p.a = a;
+  p.drop = make_drop(a.drop);
+  p.nrb = (int)cdiv(a.M, FF_ROWS);
+  const int rep = 8 / a.n_split;
+  const long grid = cdiv(p.nrb, rep) * 8;
+  hipLaunchKernelGGL(ffn_fwd_kernel, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
+  PETR_LAUNCH_CHECK("ffn_fwd");
+  return PETR_OK;
+}
 
 extern "C" int petr_ln_bwd_proj(const petr_ln_bwd_proj_args* ap, void* stream) {
   PETR_CHECK(ap && ap->z && ap->mean && ap->rstd && ap->gamma && ap->dz && ap->wT && ap->out && ap->M > 0 && ap->n2 > 0 &&

@@ -260,7 +260,7 @@ struct WOff {
   long c1, c1_mean, c1_rstd, c1n, c2, c2_mean, c2_rstd, c2n, r1, r2, reg_raw;
   long th_h, pe1, fpe_h, fpe_u;          // PETRv2: task-head hiddens [G][5][RG,C]; SELayer buffers [BL,C]
   long d_th_h, d_pe1, d_fpe_h, d_fpe_u;
-  long ffn_part; int ffn_split;
+  long ffn_part; int ffn_split, ffn_fsplit;
   long mha_ws; size_t mha_ws_bytes;
   long mha_sched_n;
   // ---- backward scratch ----
@@ -367,7 +367,14 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
   // split-K of the second FFN contraction (K = F, only 4x15 output tiles otherwise)
   W.ffn_split = d.BQ <= 2048 ? 4 : 1;
   if (d.F / 32 < W.ffn_split) W.ffn_split = 1;
-  W.ffn_part = wb.add("ffn_partials", (long)W.ffn_split * d.BQ * C);
+  // petr_ffn_fwd (both contractions in one launch): 32-row blocks x hidden slices, about one workgroup per CU; 0 = not applicable
+  W.ffn_fsplit = 0;
+  if (C == 256) {
+    const long nrb = cdiv(d.BQ, 32);
+    for (int ns = 8; ns >= 1 && !W.ffn_fsplit; ns >>= 1)
+      if (d.F % (256 * ns) == 0 && (nrb * ns <= 256 || ns == 1)) W.ffn_fsplit = ns;
+  }
+  W.ffn_part = wb.add("ffn_partials", (long)(W.ffn_fsplit > W.ffn_split ? W.ffn_fsplit : W.ffn_split) * d.BQ * C);
   {
     size_t a = petr_mha_fwd_workspace_bytes(d.B, d.NH, d.Q, (int)d.L, 0);
     size_t b = petr_mha_fwd_workspace_bytes(d.B, d.NH, d.Q, d.Q, 0);
@@ -657,6 +664,38 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(const TrBatch b) {
     if (r < e.rows && c < e.cols) e.dst[(long)c * e.rows + r] = tile[tx][ty + 8 * j];
   }
 }
+// transposed copies of the decoder weights into W.wt (one launch): `ffn` = the two FFN matrices (read by petr_ffn_fwd in the
+// forward and by the FFN input gradients), `rest` = the attention projections (read by the backward's input gradients)
+template <class PL, class WL>
+static int launch_weight_transposes(const float* Pm, float* Wm, const PL& P, const WL& W, int NL, int C, int F, bool ffn, bool rest,
+                                    hipStream_t st) {
+  TrBatch tb;
+  tb.n = 0;
+  int tiles = 0;
+  auto add = [&](const float* src, long dst_off, int rows, int cols) {
+    TrEntry& en = tb.e[tb.n++];
+    en.src = src; en.dst = Wm + dst_off; en.ld = cols; en.rows = rows; en.cols = cols; en.tile0 = tiles;
+    tiles += (int)(cdiv(rows, 32) * cdiv(cols, 32));
+  };
+  for (int l = 0; l < NL; ++l) {
+    const auto& lp = P.lay[l];
+    const auto& t = W.wt[l];
+    if (ffn) {
+      add(Pm + lp.f2_w, t.f2, C, F);
+      add(Pm + lp.f1_w, t.f1, F, C);
+    }
+    if (rest) {
+      add(Pm + lp.ca_out_w, t.ca_out, C, C);
+      add(Pm + lp.ca_in_w, t.ca_q, C, C);            // q rows of the cross-attention in_proj
+      add(Pm + lp.sa_out_w, t.sa_out, C, C);
+      add(Pm + lp.sa_in_w, t.sa_in, 3 * C, C);
+    }
+  }
+  if (!tiles) return PETR_OK;
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles), dim3(256), 0, st, tb);
+  PETR_LAUNCH_CHECK("transpose_batch");
+  return PETR_OK;
+}
 // dx[M,K] = dy[M,N] @ w[N,K] through wT[K][N]: both operands K-contiguous, like a forward
 static petr_gemm_args lin_dgrad_t(const float* dy, const float* wT, float* dx, long M, int N, int K) {
   petr_gemm_args g = gemm0();
@@ -850,6 +889,10 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   };
   ln.fork(0);
   ln.fork(1);
+  // both FFN contractions in one launch (fp32 FFN; PETR_FFN_FUSED=0: two contractions): it reads the weights k-major
+  static const bool ffn_fused_env = env_on("PETR_FFN_FUSED");
+  const bool ffn_fused = ffn_fused_env && !ffn16 && W.ffn_fsplit > 0;
+  if (ffn_fused) RUN(launch_weight_transposes(Pm, Wm, P, W, d.NL, C, d.F, true, false, (hipStream_t)s));
   // ---- side 2: input_proj (petr_head.py:390) + sine 3D (positional_encoding.py:58-100) + adapt_pos3d hidden ----
   {
     petr_gemm_args g = gemm0();   // NCHW view [C_in][HW] read as an M-contiguous operand -> token-major memory
@@ -1064,6 +1107,18 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     // FFN (mmcv FFN): x + W2 relu(W1 x + b1) + b2 ; second contraction split over K
     // bf16 mode: both FFN contractions on the bf16 matrix cores with the bf16 weight copy, as autocast runs them
     // (900 x 2048 x 256 alone: 21.8 -> 11.8 us; PETR_FFN16=0: fp32)
+    float* xs_l = Wm + W.xs + (long)l * d.BQ * C;
+    const int n_slabs = ffn_fused ? W.ffn_fsplit : W.ffn_split;
+    const bool slabs = ffn_fused || !(W.ffn_split == 1 && !training);   // false: the second contraction wrote z2 itself
+    if (ffn_fused) {
+      petr_ffn_fwd_args f;
+      memset(&f, 0, sizeof f);
+      f.x = Wm + lw.x2; f.w1t = Wm + W.wt[l].f1; f.b1 = Pm + lp.f1_b; f.w2t = Wm + W.wt[l].f2;
+      f.hidden = Wm + lw.hff; f.part = Wm + W.ffn_part; f.part_stride = d.BQ * C;
+      if (training) f.drop = dr_fh;                                     // Linear, ReLU, Dropout (mmcv FFN)
+      f.M = (int)d.BQ; f.F = (int)d.F; f.n_split = n_slabs;
+      RUN(petr_ffn_fwd(&f, s));
+    } else {
     g = lin_fwd(Wm + lw.x2, ffn16 ? Wp(lp.f1_w) : Pm + lp.f1_w, Pm + lp.f1_b, Wm + lw.hff, d.BQ, d.F, C);
     g.flags = PETR_GEMM_RELU | (ffn16 ? wflag : 0);
     if (training) g.drop = dr_fh;                                       // Linear, ReLU, Dropout (mmcv FFN)
@@ -1071,17 +1126,16 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     g = lin_fwd(Wm + lw.hff, ffn16 ? Wp(lp.f2_w) : Pm + lp.f2_w, nullptr, Wm + W.ffn_part, d.BQ, C, d.F);
     if (ffn16) g.flags |= wflag;
     g.split_k = W.ffn_split; g.c_split_stride = d.BQ * C;
-    float* xs_l = Wm + W.xs + (long)l * d.BQ * C;
-    if (W.ffn_split == 1 && !training) { g.bias = Pm + lp.f2_b; g.r = Wm + lw.x2; g.ldr = C; g.c = Wm + lw.z2; }
+    if (!slabs) { g.bias = Pm + lp.f2_b; g.r = Wm + lw.x2; g.ldr = C; g.c = Wm + lw.z2; }
     RUN(petr_gemm(&g, s));
+    }
     float* xe_next = l + 1 < d.NL ? Wm + W.lay[l + 1].xe_in : nullptr;
     if (fuse_out && l + 1 < d.NL) {
       // closing LayerNorm (slab sum + bias + dropout + residual + norm + query_pos add) AND the next layer's self-attention
       // in-projection in one launch
       petr_ln_proj_args q;
       memset(&q, 0, sizeof q);
-      const bool slabs = !(W.ffn_split == 1 && !training);
-      q.x = slabs ? Wm + W.ffn_part : Wm + lw.z2; q.n_partials = slabs ? W.ffn_split : 1; q.partial_stride = d.BQ * C;
+      q.x = slabs ? Wm + W.ffn_part : Wm + lw.z2; q.n_partials = slabs ? n_slabs : 1; q.partial_stride = d.BQ * C;
       q.bias = slabs ? Pm + lp.f2_b : nullptr; q.residual = slabs ? Wm + lw.x2 : nullptr;
       if (slabs && training) q.drop = dr_fo;
       q.gamma = Pm + lp.n_g[2]; q.beta = Pm + lp.n_b[2]; q.eps = 1e-5f;
@@ -1089,11 +1143,11 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
       q.y2 = xe_next; q.add2 = E; q.add2_rows = d.Q; q.M = (int)d.BQ;
       q.w2 = Pm + P.lay[l + 1].sa_in_w; q.bias2 = Pm + P.lay[l + 1].sa_in_b; q.out2 = Wm + W.lay[l + 1].qkv; q.n2 = 3; q.n2_pos = 2;
       RUN(petr_ln_proj(&q, s));
-    } else if (W.ffn_split == 1 && !training) {
+    } else if (!slabs) {
       RUN(ln_fwd(Wm + lw.z2, 1, 0, nullptr, nullptr, Pm + lp.n_g[2], Pm + lp.n_b[2], xs_l, nullptr, Wm + lw.mean2,
                  Wm + lw.rstd2, d.BQ, C, 0, xe_next, E, d.Q, s));
     } else {
-      RUN(ln_fwd(Wm + W.ffn_part, W.ffn_split, d.BQ * C, Pm + lp.f2_b, Wm + lw.x2, Pm + lp.n_g[2], Pm + lp.n_b[2], xs_l,
+      RUN(ln_fwd(Wm + W.ffn_part, n_slabs, d.BQ * C, Pm + lp.f2_b, Wm + lw.x2, Pm + lp.n_g[2], Pm + lp.n_b[2], xs_l,
                  Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, d.BQ, C, 0, xe_next, E, d.Q, s, training ? &dr_fo : nullptr));
     }
     x_in = xs_l;
@@ -1223,6 +1277,8 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   const int wflag = tok16 ? PETR_GEMM_B_BF16 : 0;
   static const bool ffn16_env = env_on("PETR_FFN16");
   const bool ffn16 = tok16 && ffn16_env;
+  static const bool ffn_fused_env = env_on("PETR_FFN_FUSED");
+  const bool ffn_fused = ffn_fused_env && !ffn16 && W.ffn_fsplit > 0;   // the forward's condition (head_fwd)
   static const bool drop_bits_env = env_on("PETR_DROP_BITS");          // the forward generated them (same workspace)
   const bool use_bits = io->dropout_p > 0.f && drop_bits_env;
   const uint32_t* bits0 = reinterpret_cast<const uint32_t*>(Wm + W.bits);
@@ -1265,27 +1321,9 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       PETR_CHECK(e == hipSuccess, PETR_ERR_LAUNCH, "head_bwd: memset failed: %s", hipGetErrorString(e));
       // transposed decoder weights for the layer stages' input gradients: side stream 1, beside the branch backward
       if (dgrad_t) {
-        TrBatch tb;
-        tb.n = 0;
-        int tiles = 0;
-        auto add = [&](const float* src, long dst_off, int rows, int cols) {
-          TrEntry& en = tb.e[tb.n++];
-          en.src = src; en.dst = Wm + dst_off; en.ld = cols; en.rows = rows; en.cols = cols; en.tile0 = tiles;
-          tiles += (int)(cdiv(rows, 32) * cdiv(cols, 32));
-        };
-        for (int l = 0; l < d.NL; ++l) {
-          const LayerP& lp = P.lay[l];
-          const WOff::LayerT& t = W.wt[l];
-          add(Pm + lp.f2_w, t.f2, C, d.F);
-          add(Pm + lp.f1_w, t.f1, d.F, C);
-          add(Pm + lp.ca_out_w, t.ca_out, C, C);
-          add(Pm + lp.ca_in_w, t.ca_q, C, C);            // q rows of the cross-attention in_proj
-          add(Pm + lp.sa_out_w, t.sa_out, C, C);
-          add(Pm + lp.sa_in_w, t.sa_in, 3 * C, C);
-        }
         ln.fork(1);
-        hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)ln.side(1), tb);
-        PETR_LAUNCH_CHECK("transpose_batch");
+        // the FFN pair is already there when the forward ran petr_ffn_fwd (same parameters, same workspace)
+        RUN(launch_weight_transposes(Pm, Wm, P, W, d.NL, C, d.F, !ffn_fused, true, (hipStream_t)ln.side(1)));
         if (ln.ctx) {
           ev_tr = ln.next();
           (void)hipEventRecord(ev_tr, (hipStream_t)ln.side(1));

@@ -187,6 +187,20 @@ def ln_bwd_proj(z, mean, rstd, gamma, dy, w, dy_residual=None, drop=None, alpha=
     return dz, dzd, dg, db, out
 
 
+def ffn_fwd(x, w1, b1, w2, n_split=4, drop=None, store_hidden=True, transposed=None):
+    """petr_ffn_fwd: hidden = drop(relu(x w1^T + b1)) and the per-slice partial sums of hidden w2^T in one launch.
+    x [M,256], w1 [F,256], w2 [256,F] (nn.Linear layout; the kernel reads the transposes, made here unless ``transposed`` =
+    (w1t, w2t) is given).  Returns (hidden [M,F] or None, part [n_split, M, 256])."""
+    L = _C.lib()
+    M, F = x.shape[0], w1.shape[0]
+    w1t, w2t = transposed if transposed is not None else (w1.t().contiguous(), w2.t().contiguous())
+    hidden = torch.empty((M, F), device=x.device) if store_hidden else None
+    part = torch.empty((n_split, M, 256), device=x.device)
+    a = _C.FfnFwdArgs(_ptr(_f32(x)), _ptr(w1t), _ptr(b1), _ptr(w2t), _ptr(hidden), _ptr(part), M * 256, _C.dropout(drop), M, F, n_split)
+    _C.check(L.petr_ffn_fwd(C.byref(a), _stream()), 'petr_ffn_fwd')
+    return hidden, part
+
+
 def dropout_bits(drop, BH, Q, L, device='cuda'):
     """The attention-dropout mask of ``dropout_mask(drop, BH * Q, L)`` packed for the attention kernels:
     (query-major words for ``mha_fwd*``, key-major words for ``mha_bwd*``), both int32 [petr_dropout_bits_words]."""

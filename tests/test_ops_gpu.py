@@ -823,6 +823,32 @@ def test_ln_proj_equals_layernorm_then_in_projection(ops, M, P, training):
     assert relerr(out2[:, :2 * C], qk) < 5e-6 and relerr(out2[:, 2 * C:], vv) < 5e-6
 
 
+@pytest.mark.parametrize('M,F,n_split,training', [(900, 2048, 4, True), (900, 2048, 8, False), (1800, 2048, 2, True), (37, 512, 1, True),
+                                                   (37, 512, 2, False)])
+def test_ffn_fwd_equals_the_two_contractions(ops, M, F, n_split, training):
+    """petr_ffn_fwd against the two launches it replaces: Linear + ReLU + dropout (petr_gemm's epilogue: the same mask) and the
+    split-K second contraction; the slabs' sum against a float64 product of the stored hidden."""
+    g = torch.Generator().manual_seed(M + F + n_split)
+    C = 256
+    x = dev(torch.randn(M, C, generator=g))
+    w1, b1 = dev(torch.randn(F, C, generator=g) * 0.06), dev(torch.randn(F, generator=g) * 0.1)
+    w2 = dev(torch.randn(C, F, generator=g) * 0.03)
+    drop = (7, 8, 0.1) if training else None
+    h_ref = torch.relu(x.double() @ w1.double().t() + b1.double())
+    if training:
+        h_ref = h_ref * ops.dropout_mask(drop, M, F).double() / (1 - 6554 / 65536)
+    hidden, part = ops.ffn_fwd(x, w1, b1, w2, n_split=n_split, drop=drop)
+    assert relerr(hidden, h_ref) < 2e-6
+    if training:
+        assert torch.equal(hidden == 0, h_ref == 0)                       # ReLU zeros and dropped units: the same elements
+    hb = F // n_split
+    for s_ in range(n_split):
+        ref = hidden[:, s_ * hb:(s_ + 1) * hb].double() @ w2[:, s_ * hb:(s_ + 1) * hb].double().t()
+        assert relerr(part[s_], ref) < 2e-6, s_
+    _, part2 = ops.ffn_fwd(x, w1, b1, w2, n_split=n_split, drop=drop, store_hidden=False)
+    assert torch.equal(part, part2)
+
+
 @pytest.mark.parametrize('M,P,F,training', [(900, 1, 256, True), (900, 4, 256, False), (900, 1, 2048, True), (37, 2, 512, True)])
 def test_ln_bwd_proj_equals_layernorm_bwd_then_input_gradient(ops, M, P, F, training):
     """petr_ln_bwd_proj against the two launches it replaces: layernorm_bwd (slab sum + identity path, dropped copy, dgamma /

@@ -294,7 +294,9 @@ int petr_mha_fwd_bf16(const petr_mha_fwd_bf16_args* a, void* stream);
  *   replaces, per attention of petr_transformer.py:357-367 / mmcv MultiheadAttention + the following norm of
  *   multi_atten_decoder_layer.py:204-293, FOUR launches of the 900-row chain: the partial merge, the out-projection
  *   contraction (+ residual), and the LayerNorm (+ dropout, + query_pos add).  One workgroup owns 16 full rows: merge
- *   -> LDS, 16 x 256 x 256 on v_mfma_f32_16x16x4_f32 with W streamed from L2, row statistics across the eight waves.
+ *   -> LDS, 16 x 256 x 256 on v_mfma_f32_16x16x4_f32 with the weight streamed from L2, row statistics across the eight waves.
+ *   The kernel reads the weights TRANSPOSED (wT [in = 256][out], k-major: the 16 lanes of a load share one 128-byte line;
+ *   petr_head_fwd keeps transposed copies of the decoder weights in its workspace).
  *   a: [M, 256] attention output when n_split <= 1; else it is WRITTEN with the merged output (the backward needs it) from
  *   o_part / ml_part (layout: petr_mha_fwd_args.defer_merge), lse [B*H*Q] is written too, attn_scale = the attention
  *   dropout's 1/(1-p) (1 without).  rows m = b*Q + q.  z, mean, rstd are written when non-NULL (training needs them).
@@ -302,7 +304,7 @@ int petr_mha_fwd_bf16(const petr_mha_fwd_bf16_args* a, void* stream);
 typedef struct {
   float* a;                               /* [M, 256]: in (n_split <= 1) or out (merged attention output) */
   const float* o_part; const float* ml_part; int n_split; int B, H, Q; float attn_scale; float* lse;
-  const float* w; const float* bias;      /* [256, 256] (nn.Linear layout), [256] */
+  const float* wT; const float* bias;     /* [256 in, 256 out] = the nn.Linear weight transposed, [256] */
   const float* residual;                  /* [M, 256] */
   petr_dropout drop;                      /* of the projection's output, before the residual is added */
   const float* gamma; const float* beta; float eps;
@@ -310,8 +312,8 @@ typedef struct {
   float* y;                               /* [M, 256] */
   float* y2; const float* add2; int add2_rows;   /* optional: y2 = y + add2[row % add2_rows] */
   int M;
-  const float* w2; const float* bias2; float* out2;   /* optional second projection of the same rows:
-                                                       * out2 = (y2 if requested, else y) w2^T + bias2, [M, 256] */
+  const float* w2T; const float* bias2; float* out2;  /* optional second projection of the same rows: out2 = (y2 if
+                                                       * requested, else y) w2^T + bias2, [M, 256]; w2T = w2 transposed */
 } petr_attn_out_ln_args;
 int petr_attn_out_ln(const petr_attn_out_ln_args* a, void* stream);
 
@@ -320,7 +322,7 @@ int petr_attn_out_ln(const petr_attn_out_ln_args* a, void* stream);
  *     out2[:, 256 j .. + 255] = (j < n2_pos ? y2 : y) w2[256 j .. + 255, :]^T + bias2,   j = 0 .. n2-1,  out2 [M, 256 n2]
  *   = petr_layernorm_fwd (same prologue: split-K slabs of the FFN's second contraction, bias, dropout, residual) + the next
  *   layer's self-attention in-projection (multi_atten_decoder_layer.py:223-237: q, k from x + query_pos -> n2_pos = 2,
- *   v from x; w2 = in_proj_weight [768, 256], n2 = 3). */
+ *   v from x; w2 = in_proj_weight [768, 256], n2 = 3).  The kernel reads w2 TRANSPOSED: w2T [256, 256 n2] (k-major). */
 typedef struct {
   const float* x; int n_partials; long partial_stride;   /* [P][M, 256] */
   const float* bias; const float* residual; petr_dropout drop;
@@ -328,26 +330,26 @@ typedef struct {
   float* z; float* mean; float* rstd; float* y;
   float* y2; const float* add2; int add2_rows;
   int M;
-  const float* w2; const float* bias2; float* out2; int n2, n2_pos;
+  const float* w2T; const float* bias2; float* out2; int n2, n2_pos;
 } petr_ln_proj_args;
 int petr_ln_proj(const petr_ln_proj_args* a, void* stream);
 
 /* LayerNorm backward AND the input gradient of the linear layer behind the normalised sum's sub-layer branch, one launch
  * (C = 256): petr_layernorm_bwd semantics for dz / dz_drop / dgamma / dbeta (float atomics), then
- *     out[:, 256 j .. + 255] = mask( alpha * (dz_drop if dropout else dz) wT[256 j .. + 255, :]^T ),  j = 0 .. n2-1
- *   wT [256 n2, 256] = the TRANSPOSE of the nn.Linear weight W [256, 256 n2] (dx = dy W), relu_mask [M, 256 n2] optional
- *   (out is zeroed where relu_mask <= 0: the FFN hidden).  Replaces layernorm_bwd + the out-projection / FFN2 input
+ *     out = mask( alpha * (dz_drop if dropout else dz) w ),   out [M, 256 n2]
+ *   w [256, 256 n2] = the nn.Linear weight itself (dx = dy W: already k-major for this product), relu_mask [M, 256 n2]
+ *   optional (out is zeroed where relu_mask <= 0: the FFN hidden).  Replaces layernorm_bwd + the out-projection / FFN2 input
  *   gradient of multi_atten_decoder_layer.py:204-293's backward. */
 typedef struct {
   const float* z; const float* mean; const float* rstd; const float* gamma;
   const float* dy; int dy_partials; long dy_partial_stride; const float* dy_residual;
   float* dz; float* dz_drop; petr_dropout drop; float* dgamma; float* dbeta;
   int M;
-  const float* wT; int n2; float alpha; const float* relu_mask; float* out;
-  const float* pre_a; const float* pre_wT;   /* optional leading product: the upstream gradient is
-                                              * pre_a [M,256] pre_wT[256,256]^T + sum of the dy slabs (dy_partials may be 0)
+  const float* w; int n2; float alpha; const float* relu_mask; float* out;
+  const float* pre_a; const float* pre_w;    /* optional leading product: the upstream gradient is
+                                              * pre_a [M,256] pre_w[256,256] + sum of the dy slabs (dy_partials may be 0)
                                               * + dy_residual - the input gradient of the projection that read the
-                                              * normalised rows (pre_wT = that weight, transposed) */
+                                              * normalised rows (pre_w = that nn.Linear weight) */
 } petr_ln_bwd_proj_args;
 int petr_ln_bwd_proj(const petr_ln_bwd_proj_args* a, void* stream);
 

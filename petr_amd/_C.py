@@ -97,11 +97,11 @@ class AttnOutLnArgs(C.Structure):
     _fields_ = _fields(
         ('a', C.c_void_p), ('o_part', C.c_void_p), ('ml_part', C.c_void_p), ('n_split', C.c_int),
         ('B', C.c_int), ('H', C.c_int), ('Q', C.c_int), ('attn_scale', C.c_float), ('lse', C.c_void_p),
-        ('w', C.c_void_p), ('bias', C.c_void_p), ('residual', C.c_void_p), ('drop', Dropout),
+        ('wT', C.c_void_p), ('bias', C.c_void_p), ('residual', C.c_void_p), ('drop', Dropout),
         ('gamma', C.c_void_p), ('beta', C.c_void_p), ('eps', C.c_float),
         ('z', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('y', C.c_void_p),
         ('y2', C.c_void_p), ('add2', C.c_void_p), ('add2_rows', C.c_int), ('M', C.c_int),
-        ('w2', C.c_void_p), ('bias2', C.c_void_p), ('out2', C.c_void_p))
+        ('w2T', C.c_void_p), ('bias2', C.c_void_p), ('out2', C.c_void_p))
 
 
 class LnProjArgs(C.Structure):
@@ -110,7 +110,7 @@ class LnProjArgs(C.Structure):
         ('drop', Dropout), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('eps', C.c_float),
         ('z', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('y', C.c_void_p),
         ('y2', C.c_void_p), ('add2', C.c_void_p), ('add2_rows', C.c_int), ('M', C.c_int),
-        ('w2', C.c_void_p), ('bias2', C.c_void_p), ('out2', C.c_void_p), ('n2', C.c_int), ('n2_pos', C.c_int))
+        ('w2T', C.c_void_p), ('bias2', C.c_void_p), ('out2', C.c_void_p), ('n2', C.c_int), ('n2_pos', C.c_int))
 
 
 class LnBwdProjArgs(C.Structure):
@@ -118,8 +118,8 @@ class LnBwdProjArgs(C.Structure):
         ('z', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('gamma', C.c_void_p),
         ('dy', C.c_void_p), ('dy_partials', C.c_int), ('dy_partial_stride', C.c_long), ('dy_residual', C.c_void_p),
         ('dz', C.c_void_p), ('dz_drop', C.c_void_p), ('drop', Dropout), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p),
-        ('M', C.c_int), ('wT', C.c_void_p), ('n2', C.c_int), ('alpha', C.c_float), ('relu_mask', C.c_void_p), ('out', C.c_void_p),
-        ('pre_a', C.c_void_p), ('pre_wT', C.c_void_p))
+        ('M', C.c_int), ('w', C.c_void_p), ('n2', C.c_int), ('alpha', C.c_float), ('relu_mask', C.c_void_p), ('out', C.c_void_p),
+        ('pre_a', C.c_void_p), ('pre_w', C.c_void_p))
 
 
 class FfnFwdArgs(C.Structure):

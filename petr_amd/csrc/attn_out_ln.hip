@@ -9,16 +9,16 @@
 //   prologue   the 16 x 256 attention rows are merged from the split partials (or read), normalised, written back as the
 //              attention output the backward needs, and kept in LDS;
 //   product    wave w computes columns 32 w .. + 31 on v_mfma_f32_16x16x4_f32 (exact fp32): per 16-deep K group a lane
-//              takes one float4 of the A row block from LDS and one float4 of W per column tile straight from L2 (lane
-//              (n, q) holds k = 16 g + 4 q .. + 3; step j of the group multiplies element j of both - the k order inside
-//              a group only has to agree between the operands); the W loads of the next groups are in flight under the
-//              MFMAs of the current one;
+//              takes one float4 of the A row block from LDS and four float2 of the TRANSPOSED weight straight from L2
+//              (WStreamT below: lane (n, q) holds k = 16 g + 4 q .. + 3 of columns 2 n, 2 n + 1; step j multiplies element j
+//              of both); half of K is in flight under the MFMAs of the other half, and the next product's first half
+//              follows without a gap;
 //   epilogue   bias, dropout, residual; row sums of the 16 rows across the 16 lanes of a row group (xor shuffles) and
 //              the eight waves (LDS), two passes (mean, then centred squares) like layernorm_fwd_kernel;
 //   optional   a second 256 x 256 projection of the normalised rows (+ the query_pos addend): the NEXT attention's query
 //              projection (petr_transformer.py:341-362: q = (x + query_pos) Wq^T + bq) - the rows go back to LDS, the same
 //              product runs again.  One more link of the chain in the same launch.
-// 57 workgroups at 900 rows: 2 x 128 dependent 32-cycle MFMAs per wave (3.4 us) are the floor of the product.
+// 57 workgroups at 900 rows: 128 32-cycle MFMAs per wave and product, two waves per SIMD (3.4 us) are the floor of a product.
 #include "common.h"
 
 namespace {
@@ -26,54 +26,7 @@ namespace {
 constexpr int AO_C = 256, AO_ROWS = 16, AO_PITCH = AO_C + 4;
 constexpr float AO_LN2 = 0.6931471805599453f;
 
-// The W rows of one wave's two 16-column tiles, streamed from L2 in 32-deep K groups: lane (n = lane & 15, q = lane >> 4) holds
-// k = 32 g + 8 q .. + 7 of row n as two float4 - the four q of a row cover one full 128-byte line per group (16-deep groups
-// with one float4 per lane touched every line twice, half a line at a time).  Step j of a group multiplies element j of the
-// A and the W fragment: the k order inside a group only has to agree between the operands.  Four groups (half of K) in flight.
-struct WStream {
-  float4 f[4][2][2];
-  __device__ __forceinline__ void first(const float* wa, const float* wb) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f[g][0][0] = *reinterpret_cast<const float4*>(wa + 32 * g);
-      f[g][0][1] = *reinterpret_cast<const float4*>(wa + 32 * g + 4);
-      f[g][1][0] = *reinterpret_cast<const float4*>(wb + 32 * g);
-      f[g][1][1] = *reinterpret_cast<const float4*>(wb + 32 * g + 4);
-    }
-  }
-  // acc += A (16 x 256, LDS rows at arow = As + (lane & 15) * pitch + 8 (lane >> 4)) x W[tile rows][:]^T
-  __device__ __forceinline__ void run(const float* arow, const float* wa, const float* wb, f32x4& acc0, f32x4& acc1) {
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const float4 a0 = *reinterpret_cast<const float4*>(arow + 32 * g), a1 = *reinterpret_cast<const float4*>(arow + 32 * g + 4);
-      const float4 p0 = f[g & 3][0][0], p1 = f[g & 3][0][1], q0 = f[g & 3][1][0], q1 = f[g & 3][1][1];
-      if (g + 4 < 8) {
-        f[g & 3][0][0] = *reinterpret_cast<const float4*>(wa + 32 * (g + 4));
-        f[g & 3][0][1] = *reinterpret_cast<const float4*>(wa + 32 * (g + 4) + 4);
-        f[g & 3][1][0] = *reinterpret_cast<const float4*>(wb + 32 * (g + 4));
-        f[g & 3][1][1] = *reinterpret_cast<const float4*>(wb + 32 * (g + 4) + 4);
-      }
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, p0.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, q0.x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, p0.y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, q0.y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, p0.z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, q0.z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, p0.w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, q0.w, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, p1.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, q1.x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, p1.y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, q1.y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, p1.z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, q1.z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, p1.w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, q1.w, acc1, 0, 0, 0);
-    }
-  }
-};
-
-// The same product with the weight read k-major (wT [K][N]: row k holds the N outputs' weights of input k): lane
+// The weight is read k-major (wT [K][N]: row k holds the N outputs' weights of input k): lane
 // (n = lane & 15, kq = lane >> 4) takes ONE float2 wT[k][col0 + 2 n, + 1] per k - the 16 lanes of a k share one 128-byte line, an
 // instruction touches 4 full lines.  (With W [N][K] every lane of an instruction sits in a line of its own: 64 tag lookups per
 // 1 KB, and the 16-row kernels ran at the L1's lookup rate - 14 bytes / clock / CU measured - not at the matrix cores'.)  The
@@ -160,7 +113,8 @@ __global__ __launch_bounds__(512) void attn_out_ln_kernel(const AoParams p) {
   __shared__ __attribute__((aligned(16))) float Ps[AO_ROWS * AO_PITCH];     // add2 in, y2 out
   __shared__ float red[2][8][AO_ROWS];
   const petr_attn_out_ln_args& a = p.a;
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int m0 = blockIdx.x * AO_ROWS;
   const int tr = t >> 5, tc = 8 * (t & 31);                 // this thread's piece of a row-block image
   const int tm = min(m0 + tr, a.M - 1);
@@ -175,12 +129,12 @@ __global__ __launch_bounds__(512) void attn_out_ln_kernel(const AoParams p) {
     radd[0] = src[0]; radd[1] = src[1];
   }
 
-  // W fragments of the first eight K groups: requested before the prologue so that their latency runs under the merge
+  // W fragments of the first half of K: requested before the prologue so that their latency runs under the merge
   const int nl = lane & 15, q4 = lane >> 4;
-  const float* w0 = a.w + (long)(32 * wave + nl) * AO_C + 8 * q4;        // column tile 0 of this wave; tile 1: + 16 rows of W
-  const float* w1 = w0 + 16 * AO_C;
-  WStream ws;
-  ws.first(w0, w1);
+  const float* w0 = a.wT + 32 * wave;                      // this wave's 32 columns of wT [256][256]
+  const uint32_t lo = WStreamT<1>::lane_off(lane, AO_C);
+  WStreamT<1> ws;
+  ws.first(w0, AO_C, lo);
 
   // ---- prologue: the A row block (thread: row t >> 5, head (t >> 2) & 7, 8 channels 8 (t & 3) .. + 7) ----
   {
@@ -246,16 +200,16 @@ __global__ __launch_bounds__(512) void attn_out_ln_kernel(const AoParams p) {
 
   // ---- product: wave = 16 rows x 32 columns, K = 256 in 16 groups of 16 ----
   __syncthreads();
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const float* arow = As + nl * AO_PITCH + 8 * q4;
-  ws.run(arow, w0, w1, acc0, acc1);
-  // second projection (optional): its first W groups are requested now, their latency runs under the epilogue
-  const float* v0 = a.w2 ? a.w2 + (long)(32 * wave + nl) * AO_C + 8 * q4 : w0;
-  const float* v1 = v0 + 16 * AO_C;
-  if (a.w2) ws.first(v0, v1);
+  f32x4 acc[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+  const float* arow = As + nl * AO_PITCH + 4 * q4;
+  // second projection (optional): the first half of its weight follows the first product's in the stream, its latency runs
+  // under the epilogue
+  const float* v0 = a.w2T ? a.w2T + 32 * wave : nullptr;
+  ws.run(arow, AO_PITCH, w0, AO_C, lo, v0, AO_C, lo, acc);
+  const f32x4 acc0 = acc[0][0], acc1 = acc[0][1];
 
-  // ---- epilogue: lane holds rows 4 q4 + i (i = 0..3), columns 32 wave + nl (acc0) and + 16 (acc1) ----
-  const int c0 = 32 * wave + nl, c1 = c0 + 16;
+  // ---- epilogue: lane holds rows 4 q4 + i (i = 0..3), columns 32 wave + 2 nl (acc0) and + 1 (acc1) ----
+  const int c0 = 32 * wave + 2 * nl, c1 = c0 + 1;
   const float bia0 = a.bias ? a.bias[c0] : 0.f, bia1 = a.bias ? a.bias[c1] : 0.f;
   float z0[4], z1[4], part[4];
 #pragma unroll
@@ -336,16 +290,15 @@ __global__ __launch_bounds__(512) void attn_out_ln_kernel(const AoParams p) {
     }
   }
   // ---- second projection: out2 = (y2, or y) W2^T + bias2 - the next attention's query projection of the same rows ----
-  if (!a.w2) return;
-  acc0 = acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-  ws.run(arow, v0, v1, acc0, acc1);
+  if (!a.w2T) return;
+  acc[0][0] = acc[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ws.run(arow, AO_PITCH, v0, AO_C, lo, nullptr, AO_C, lo, acc);
   const float bb0 = a.bias2 ? a.bias2[c0] : 0.f, bb1 = a.bias2 ? a.bias2[c1] : 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + 4 * q4 + i;
     if (m >= a.M) continue;
-    a.out2[(long)m * AO_C + c0] = acc0[i] + bb0;
-    a.out2[(long)m * AO_C + c1] = acc1[i] + bb1;
+    *reinterpret_cast<float2*>(a.out2 + (long)m * AO_C + c0) = make_float2(acc[0][0][i] + bb0, acc[0][1][i] + bb1);
   }
 }
 
@@ -362,111 +315,112 @@ struct LpParams {
   DropDev drop;
 };
 
+// half-wave sum: the 32 threads that share a row of a 16 x 256 row image (thread = row t >> 5, columns 8 (t & 31) .. + 7)
+__device__ __forceinline__ float row32_sum(float x) {
+  x += __shfl_xor(x, 1, 64);
+  x += __shfl_xor(x, 2, 64);
+  x += __shfl_xor(x, 4, 64);
+  x += __shfl_xor(x, 8, 64);
+  x += __shfl_xor(x, 16, 64);
+  return x;
+}
+
 __global__ __launch_bounds__(512) void ln_proj_kernel(const LpParams p) {
   __shared__ __attribute__((aligned(16))) float As[AO_ROWS * AO_PITCH];
-  __shared__ float red[2][8][AO_ROWS];
   const petr_ln_proj_args& a = p.a;
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int m0 = blockIdx.x * AO_ROWS, jb = blockIdx.y;
   const int nl = lane & 15, q4 = lane >> 4;
-  const float* w0 = a.w2 + ((long)256 * jb + 32 * wave + nl) * AO_C + 8 * q4;
-  const float* w1 = w0 + 16 * AO_C;
-  WStream ws;
-  ws.first(w0, w1);
-  const int c0 = 32 * wave + nl, c1 = c0 + 16;
-  const float bia0 = a.bias ? a.bias[c0] : 0.f, bia1 = a.bias ? a.bias[c1] : 0.f;
-  float z0[4], z1[4], part[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int mc = min(m0 + 4 * q4 + i, a.M - 1);
-    float u0 = 0.f, u1 = 0.f;
-    for (int sp = 0; sp < a.n_partials; ++sp) {
-      const float* x = a.x + (long)sp * a.partial_stride + (long)mc * AO_C;
-      u0 += x[c0];
-      u1 += x[c1];
-    }
-    u0 += bia0; u1 += bia1;
-    if (p.drop.thr) {
-      const uint32_t rk = drop_row_key(p.drop, (uint32_t)mc);
-      u0 = drop_keep(rk, (uint32_t)c0, p.drop.thr) ? u0 * p.drop.scale : 0.f;
-      u1 = drop_keep(rk, (uint32_t)c1, p.drop.thr) ? u1 * p.drop.scale : 0.f;
-    }
-    if (a.residual) {
-      u0 += a.residual[(long)mc * AO_C + c0];
-      u1 += a.residual[(long)mc * AO_C + c1];
-    }
-    z0[i] = u0; z1[i] = u1;
-    part[i] = u0 + u1;
-  }
-  auto row_reduce = [&](float (&v)[4], int slot) -> void {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float x = v[i];
-      x += __shfl_xor(x, 1, 64);
-      x += __shfl_xor(x, 2, 64);
-      x += __shfl_xor(x, 4, 64);
-      x += __shfl_xor(x, 8, 64);
-      if (nl == 0) red[slot][wave][4 * q4 + i] = x;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float x = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) x += red[slot][w][4 * q4 + i];
-      v[i] = x;
-    }
-  };
-  row_reduce(part, 0);
-  float mean[4], sq[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    mean[i] = part[i] * (1.f / AO_C);
-    const float d0 = z0[i] - mean[i], d1 = z1[i] - mean[i];
-    sq[i] = d0 * d0 + d1 * d1;
-  }
-  row_reduce(sq, 1);
-  const float g0 = a.gamma[c0], g1 = a.gamma[c1], be0 = a.beta[c0], be1 = a.beta[c1];
-  const bool writer = jb == 0;
-  const bool with_pos = jb < a.n2_pos;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + 4 * q4 + i;
-    const int mc = min(m, a.M - 1);
-    const float rstd = 1.f / sqrtf(sq[i] * (1.f / AO_C) + a.eps);
-    const float y0 = (z0[i] - mean[i]) * rstd * g0 + be0, y1 = (z1[i] - mean[i]) * rstd * g1 + be1;
-    float u0 = y0, u1 = y1;
-    if (a.add2) {
-      const long o2 = (long)(a.add2_rows > 0 ? mc % a.add2_rows : mc) * AO_C;
-      u0 = y0 + a.add2[o2 + c0];
-      u1 = y1 + a.add2[o2 + c1];
-    }
-    if (writer && m < a.M) {
-      const long o = (long)m * AO_C;
-      if (a.z) { a.z[o + c0] = z0[i]; a.z[o + c1] = z1[i]; }
-      a.y[o + c0] = y0; a.y[o + c1] = y1;
-      if (a.y2) { a.y2[o + c0] = u0; a.y2[o + c1] = u1; }
-      if (wave == 0 && nl == 0) {
-        if (a.mean) a.mean[m] = mean[i];
-        if (a.rstd) a.rstd[m] = rstd;
-      }
-    }
-    As[(4 * q4 + i) * AO_PITCH + c0] = with_pos ? u0 : y0;
-    As[(4 * q4 + i) * AO_PITCH + c1] = with_pos ? u1 : y1;
-  }
-  __syncthreads();
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const float* arow = As + nl * AO_PITCH + 8 * q4;
-  ws.run(arow, w0, w1, acc0, acc1);
-  const int n0 = 256 * jb + c0, n1 = n0 + 16;
-  const float bb0 = a.bias2 ? a.bias2[n0] : 0.f, bb1 = a.bias2 ? a.bias2[n1] : 0.f;
   const long ld2 = 256L * a.n2;
+  const float* w0 = a.w2T + 256 * jb + 32 * wave;            // this wave's 32 columns of w2T [256][256 n2]
+  const uint32_t lo = WStreamT<1>::lane_off(lane, ld2);
+  WStreamT<1> ws;
+  ws.first(w0, ld2, lo);
+  // ---- the normalisation in the ROW-IMAGE layout: thread = (row t >> 5, 8 consecutive columns) - every global access is a
+  // 16-byte one, a row's statistics are sums over one half wave (no LDS, no barrier) ----
+  const int tr = t >> 5, tc = 8 * (t & 31);
+  const int m = m0 + tr, mc = min(m, a.M - 1);
+  float v[8];
+  {
+    const float4* x = reinterpret_cast<const float4*>(a.x + (long)mc * AO_C + tc);
+    float4 s0 = x[0], s1 = x[1];
+    for (int sp = 1; sp < a.n_partials; ++sp) {
+      const float4* xs = reinterpret_cast<const float4*>(a.x + (long)sp * a.partial_stride + (long)mc * AO_C + tc);
+      const float4 u0 = xs[0], u1 = xs[1];
+      s0.x += u0.x; s0.y += u0.y; s0.z += u0.z; s0.w += u0.w;
+      s1.x += u1.x; s1.y += u1.y; s1.z += u1.z; s1.w += u1.w;
+    }
+    v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w; v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
+  }
+  auto ld8 = [&](const float* ptr, float (&o)[8]) {
+    const float4 u0 = reinterpret_cast<const float4*>(ptr)[0], u1 = reinterpret_cast<const float4*>(ptr)[1];
+    o[0] = u0.x; o[1] = u0.y; o[2] = u0.z; o[3] = u0.w; o[4] = u1.x; o[5] = u1.y; o[6] = u1.z; o[7] = u1.w;
+  };
+  auto st8 = [&](float* ptr, const float (&o)[8]) {
+    reinterpret_cast<float4*>(ptr)[0] = make_float4(o[0], o[1], o[2], o[3]);
+    reinterpret_cast<float4*>(ptr)[1] = make_float4(o[4], o[5], o[6], o[7]);
+  };
+  float gam[8], bet[8], tmp[8];
+  ld8(a.gamma + tc, gam);
+  ld8(a.beta + tc, bet);
+  if (a.bias) {
+    ld8(a.bias + tc, tmp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += tmp[j];
+  }
+  if (p.drop.thr) {
+    const uint32_t rk = drop_row_key(p.drop, (uint32_t)mc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t hsh = drop_pair_hash(rk, (uint32_t)(tc + 2 * j) >> 1);
+      v[2 * j] = (uint16_t)hsh >= (uint16_t)p.drop.thr ? v[2 * j] * p.drop.scale : 0.f;
+      v[2 * j + 1] = (uint16_t)(hsh >> 16) >= (uint16_t)p.drop.thr ? v[2 * j + 1] * p.drop.scale : 0.f;
+    }
+  }
+  if (a.residual) {
+    ld8(a.residual + (long)mc * AO_C + tc, tmp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += tmp[j];
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sum += v[j];
+  const float mean = row32_sum(sum) * (1.f / AO_C);
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sq += (v[j] - mean) * (v[j] - mean);
+  const float rstd = 1.f / sqrtf(row32_sum(sq) * (1.f / AO_C) + a.eps);
+  float y[8], y2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) y2[j] = y[j] = (v[j] - mean) * rstd * gam[j] + bet[j];
+  if (a.add2) {
+    ld8(a.add2 + (long)(a.add2_rows > 0 ? mc % a.add2_rows : mc) * AO_C + tc, tmp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y2[j] = y[j] + tmp[j];
+  }
+  if (jb == 0 && m < a.M) {
+    const long o = (long)m * AO_C + tc;
+    if (a.z) st8(a.z + o, v);
+    st8(a.y + o, y);
+    if (a.y2) st8(a.y2 + o, y2);
+    if ((t & 31) == 0) {
+      if (a.mean) a.mean[m] = mean;
+      if (a.rstd) a.rstd[m] = rstd;
+    }
+  }
+  st8(As + tr * AO_PITCH + tc, jb < a.n2_pos ? y2 : y);
+  __syncthreads();
+  f32x4 acc[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+  const float* arow = As + nl * AO_PITCH + 4 * q4;
+  ws.run(arow, AO_PITCH, w0, ld2, lo, nullptr, ld2, lo, acc);
+  const int n0 = 256 * jb + 32 * wave + 2 * nl;
+  const float bb0 = a.bias2 ? a.bias2[n0] : 0.f, bb1 = a.bias2 ? a.bias2[n0 + 1] : 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + 4 * q4 + i;
-    if (m >= a.M) continue;
-    a.out2[(long)m * ld2 + n0] = acc0[i] + bb0;
-    a.out2[(long)m * ld2 + n1] = acc1[i] + bb1;
+    const int mo = m0 + 4 * q4 + i;
+    if (mo >= a.M) continue;
+    *reinterpret_cast<float2*>(a.out2 + (long)mo * ld2 + n0) = make_float2(acc[0][0][i] + bb0, acc[0][1][i] + bb1);
   }
 }
 
@@ -485,130 +439,131 @@ struct LbParams {
 
 __global__ __launch_bounds__(512) void ln_bwd_proj_kernel(const LbParams p) {
   __shared__ __attribute__((aligned(16))) float As[AO_ROWS * AO_PITCH];
-  __shared__ float red[2][8][AO_ROWS];
+  __shared__ __attribute__((aligned(16))) float Cs[2][AO_ROWS * AO_PITCH];   // dy xhat and dy of the block: column sums for dgamma / dbeta
   const petr_ln_bwd_proj_args& a = p.a;
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int m0 = blockIdx.x * AO_ROWS, jb = blockIdx.y;
   const int nl = lane & 15, q4 = lane >> 4;
-  const float* w0 = a.wT + ((long)256 * jb + 32 * wave + nl) * AO_C + 8 * q4;
-  const float* w1 = w0 + 16 * AO_C;
-  WStream ws;
-  ws.first(w0, w1);
-  const int c0 = 32 * wave + nl, c1 = c0 + 16;
-  // optional leading product: dy = pre_a pre_wT^T (+ dy_residual) - the input gradient of the projection that consumed the
-  // normalised rows (the cross-attention's query projection), computed here instead of by a launch of its own; its
-  // accumulators fall in exactly the (row, column) layout the LayerNorm backward below works in
-  f32x4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f};
-  if (a.pre_a) {
-    {
-      const int r = t >> 5, cc = 8 * (t & 31);
-      const float4* src = reinterpret_cast<const float4*>(a.pre_a + (long)min(m0 + r, a.M - 1) * AO_C + cc);
-      float4* ls = reinterpret_cast<float4*>(As + r * AO_PITCH + cc);
-      ls[0] = src[0]; ls[1] = src[1];
-    }
-    const float* u0 = a.pre_wT + (long)(32 * wave + nl) * AO_C + 8 * q4;
-    const float* u1 = u0 + 16 * AO_C;
-    WStream us;
-    us.first(u0, u1);
-    __syncthreads();
-    us.run(As + nl * AO_PITCH + 8 * q4, u0, u1, pre0, pre1);
-    __syncthreads();                       // As is rewritten below
-  }
-  const float gm0 = a.gamma[c0], gm1 = a.gamma[c1];
-  float xh0[4], xh1[4], g0[4], g1[4], s1[4], s2[4], rs[4];
-  float cg0 = 0.f, cg1 = 0.f, cb0 = 0.f, cb1 = 0.f;         // column sums over this lane's four rows
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + 4 * q4 + i;
-    const int mc = min(m, a.M - 1);
-    const long o = (long)mc * AO_C;
-    float d0 = pre0[i], d1 = pre1[i];
-    for (int sp = 0; sp < a.dy_partials; ++sp) {
-      const float* x = a.dy + (long)sp * a.dy_partial_stride + o;
-      d0 += x[c0];
-      d1 += x[c1];
-    }
-    if (a.dy_residual) { d0 += a.dy_residual[o + c0]; d1 += a.dy_residual[o + c1]; }
-    if (m >= a.M) d0 = d1 = 0.f;                              // padding rows add nothing to the column sums
-    const float mean = a.mean[mc], rstd = a.rstd[mc];
-    rs[i] = rstd;
-    xh0[i] = (a.z[o + c0] - mean) * rstd;
-    xh1[i] = (a.z[o + c1] - mean) * rstd;
-    g0[i] = d0 * gm0; g1[i] = d1 * gm1;
-    s1[i] = g0[i] + g1[i];
-    s2[i] = g0[i] * xh0[i] + g1[i] * xh1[i];
-    cg0 += d0 * xh0[i]; cg1 += d1 * xh1[i];
-    cb0 += d0; cb1 += d1;
-  }
-  auto row_reduce = [&](float (&v)[4], int slot) -> void {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float x = v[i];
-      x += __shfl_xor(x, 1, 64);
-      x += __shfl_xor(x, 2, 64);
-      x += __shfl_xor(x, 4, 64);
-      x += __shfl_xor(x, 8, 64);
-      if (nl == 0) red[slot][wave][4 * q4 + i] = x;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float x = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) x += red[slot][w][4 * q4 + i];
-      v[i] = x;
-    }
+  const long ld2 = 256L * a.n2;
+  const float* w0 = a.w + 256 * jb + 32 * wave;              // this wave's 32 columns of W [256][256 n2]: dx = dz W
+  const uint32_t lo = WStreamT<1>::lane_off(lane, ld2), lop = WStreamT<1>::lane_off(lane, AO_C);
+  WStreamT<1> ws;
+  const int tr = t >> 5, tc = 8 * (t & 31);                  // row-image layout: thread = (row, 8 consecutive columns)
+  const int m = m0 + tr, mc = min(m, a.M - 1);
+  auto ld8 = [&](const float* ptr, float (&o)[8]) {
+    const float4 u0 = reinterpret_cast<const float4*>(ptr)[0], u1 = reinterpret_cast<const float4*>(ptr)[1];
+    o[0] = u0.x; o[1] = u0.y; o[2] = u0.z; o[3] = u0.w; o[4] = u1.x; o[5] = u1.y; o[6] = u1.z; o[7] = u1.w;
   };
-  row_reduce(s1, 0);
-  row_reduce(s2, 1);
-  const bool writer = jb == 0;
-  if (writer && (a.dgamma || a.dbeta)) {      // the 16 rows' column sums: across the four row groups of the wave, then atomics
-    cg0 += __shfl_xor(cg0, 16, 64); cg0 += __shfl_xor(cg0, 32, 64);
-    cg1 += __shfl_xor(cg1, 16, 64); cg1 += __shfl_xor(cg1, 32, 64);
-    cb0 += __shfl_xor(cb0, 16, 64); cb0 += __shfl_xor(cb0, 32, 64);
-    cb1 += __shfl_xor(cb1, 16, 64); cb1 += __shfl_xor(cb1, 32, 64);
-    if (q4 == 0) {
-      if (a.dgamma) { atomicAdd(a.dgamma + c0, cg0); atomicAdd(a.dgamma + c1, cg1); }
-      if (a.dbeta) { atomicAdd(a.dbeta + c0, cb0); atomicAdd(a.dbeta + c1, cb1); }
+  auto st8 = [&](float* ptr, const float (&o)[8]) {
+    reinterpret_cast<float4*>(ptr)[0] = make_float4(o[0], o[1], o[2], o[3]);
+    reinterpret_cast<float4*>(ptr)[1] = make_float4(o[4], o[5], o[6], o[7]);
+  };
+  float d[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d[j] = 0.f;
+  // optional leading product: dy = pre_a pre_w (+ dy_residual) - the input gradient of the projection that consumed the
+  // normalised rows (the cross-attention's query projection), computed here instead of by a launch of its own; its
+  // accumulators go through LDS into the row-image layout the LayerNorm backward below works in
+  if (a.pre_a) {
+    const float* u0 = a.pre_w + 32 * wave;                   // pre_w [256][256]: d(input) = pre_a pre_w
+    ws.first(u0, AO_C, lop);
+    {
+      float tmp[8];
+      ld8(a.pre_a + (long)mc * AO_C + tc, tmp);
+      st8(As + tr * AO_PITCH + tc, tmp);
+    }
+    __syncthreads();
+    f32x4 pre[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+    ws.run(As + nl * AO_PITCH + 4 * q4, AO_PITCH, u0, AO_C, lop, w0, ld2, lo, pre);     // the main weight follows in the stream
+    __syncthreads();                       // every wave is past its reads of As
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float2*>(As + (4 * q4 + i) * AO_PITCH + 32 * wave + 2 * nl) = make_float2(pre[0][0][i], pre[0][1][i]);
+    __syncthreads();
+    ld8(As + tr * AO_PITCH + tc, d);
+    // (As is rewritten below by the thread that just read the same elements)
+  } else {
+    ws.first(w0, ld2, lo);
+  }
+  float tmp[8];
+  for (int sp = 0; sp < a.dy_partials; ++sp) {
+    ld8(a.dy + (long)sp * a.dy_partial_stride + (long)mc * AO_C + tc, tmp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] += tmp[j];
+  }
+  if (a.dy_residual) {
+    ld8(a.dy_residual + (long)mc * AO_C + tc, tmp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] += tmp[j];
+  }
+  if (m >= a.M) {                                             // padding rows add nothing to the column sums
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = 0.f;
+  }
+  const float mean = a.mean[mc], rstd = a.rstd[mc];
+  float xh[8], gm[8], g[8];
+  ld8(a.z + (long)mc * AO_C + tc, xh);
+  ld8(a.gamma + tc, gm);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    xh[j] = (xh[j] - mean) * rstd;
+    g[j] = d[j] * gm[j];
+    s1 += g[j];
+    s2 += g[j] * xh[j];
+  }
+  const float m1 = row32_sum(s1) * (1.f / AO_C), m2 = row32_sum(s2) * (1.f / AO_C);
+  float dz[8], e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = dz[j] = rstd * (g[j] - m1 - xh[j] * m2);
+  if (p.drop.thr) {                         // gradient of the dropped branch of z = drop(f) + residual
+    const uint32_t rk = drop_row_key(p.drop, (uint32_t)mc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t hsh = drop_pair_hash(rk, (uint32_t)(tc + 2 * j) >> 1);
+      e[2 * j] = (uint16_t)hsh >= (uint16_t)p.drop.thr ? dz[2 * j] * p.drop.scale : 0.f;
+      e[2 * j + 1] = (uint16_t)(hsh >> 16) >= (uint16_t)p.drop.thr ? dz[2 * j + 1] * p.drop.scale : 0.f;
     }
   }
+  const bool writer = jb == 0;
+  if (writer && m < a.M) {
+    const long o = (long)m * AO_C + tc;
+    st8(a.dz + o, dz);
+    if (a.dz_drop) st8(a.dz_drop + o, e);
+  }
+  st8(As + tr * AO_PITCH + tc, e);
+  const bool col_sums = writer && (a.dgamma || a.dbeta);
+  if (col_sums) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + 4 * q4 + i;
-    const int mc = min(m, a.M - 1);
-    const float m1 = s1[i] * (1.f / AO_C), m2 = s2[i] * (1.f / AO_C);
-    const float d0 = rs[i] * (g0[i] - m1 - xh0[i] * m2), d1 = rs[i] * (g1[i] - m1 - xh1[i] * m2);
-    float e0 = d0, e1 = d1;
-    if (p.drop.thr) {                         // gradient of the dropped branch of z = drop(f) + residual
-      const uint32_t rk = drop_row_key(p.drop, (uint32_t)mc);
-      e0 = drop_keep(rk, (uint32_t)c0, p.drop.thr) ? d0 * p.drop.scale : 0.f;
-      e1 = drop_keep(rk, (uint32_t)c1, p.drop.thr) ? d1 * p.drop.scale : 0.f;
-    }
-    if (writer && m < a.M) {
-      const long o = (long)m * AO_C;
-      a.dz[o + c0] = d0; a.dz[o + c1] = d1;
-      if (a.dz_drop) { a.dz_drop[o + c0] = e0; a.dz_drop[o + c1] = e1; }
-    }
-    As[(4 * q4 + i) * AO_PITCH + c0] = e0;
-    As[(4 * q4 + i) * AO_PITCH + c1] = e1;
+    for (int j = 0; j < 8; ++j) tmp[j] = d[j] * xh[j];
+    st8(Cs[0] + tr * AO_PITCH + tc, tmp);
+    st8(Cs[1] + tr * AO_PITCH + tc, d);
   }
   __syncthreads();
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const float* arow = As + nl * AO_PITCH + 8 * q4;
-  ws.run(arow, w0, w1, acc0, acc1);
-  const int n0 = 256 * jb + c0, n1 = n0 + 16;
-  const long ld2 = 256L * a.n2;
+  if (col_sums) {                           // thread = (quantity t >> 8, column t & 255): the 16 rows' sum, one float atomic
+    const float* cs = Cs[t >> 8] + (t & 255);
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < AO_ROWS; ++r) acc += cs[r * AO_PITCH];
+    float* dst = (t >> 8) ? a.dbeta : a.dgamma;
+    if (dst) atomicAdd(dst + (t & 255), acc);
+  }
+  f32x4 acc[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+  const float* arow = As + nl * AO_PITCH + 4 * q4;
+  ws.run(arow, AO_PITCH, w0, ld2, lo, nullptr, ld2, lo, acc);
+  const int n0 = 256 * jb + 32 * wave + 2 * nl;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + 4 * q4 + i;
-    if (m >= a.M) continue;
-    float v0 = acc0[i] * a.alpha, v1 = acc1[i] * a.alpha;
+    const int mo = m0 + 4 * q4 + i;
+    if (mo >= a.M) continue;
+    float v0 = acc[0][0][i] * a.alpha, v1 = acc[0][1][i] * a.alpha;
     if (a.relu_mask) {
-      v0 = a.relu_mask[(long)m * ld2 + n0] > 0.f ? v0 : 0.f;
-      v1 = a.relu_mask[(long)m * ld2 + n1] > 0.f ? v1 : 0.f;
+      const float2 rm = *reinterpret_cast<const float2*>(a.relu_mask + (long)mo * ld2 + n0);
+      v0 = rm.x > 0.f ? v0 : 0.f;
+      v1 = rm.y > 0.f ? v1 : 0.f;
     }
-    a.out[(long)m * ld2 + n0] = v0;
-    a.out[(long)m * ld2 + n1] = v1;
+    *reinterpret_cast<float2*>(a.out + (long)mo * ld2 + n0) = make_float2(v0, v1);
   }
 }
 
@@ -738,13 +693,17 @@ extern "C" int petr_ffn_fwd(const petr_ffn_fwd_args* ap, void* stream) {
 }
 
 extern "C" int petr_ln_bwd_proj(const petr_ln_bwd_proj_args* ap, void* stream) {
-  PETR_CHECK(ap && ap->z && ap->mean && ap->rstd && ap->gamma && ap->dz && ap->wT && ap->out && ap->M > 0 && ap->n2 > 0 &&
-                 ((ap->dy && ap->dy_partials > 0) || (ap->pre_a && ap->pre_wT && ap->dy_partials == 0)),
+  PETR_CHECK(ap && ap->z && ap->mean && ap->rstd && ap->gamma && ap->dz && ap->w && ap->out && ap->M > 0 && ap->n2 > 0 &&
+                 ((ap->dy && ap->dy_partials > 0) || (ap->pre_a && ap->pre_w && ap->dy_partials == 0)),
              PETR_ERR_INVALID, "ln_bwd_proj: bad arguments");
-  PETR_CHECK(!ap->pre_a || (ap->pre_wT && aligned16(ap->pre_a) && aligned16(ap->pre_wT)), PETR_ERR_INVALID,
-             "ln_bwd_proj: pre_a needs pre_wT, both 16-byte aligned");
+  PETR_CHECK(!ap->pre_a || (ap->pre_w && aligned16(ap->pre_a) && aligned16(ap->pre_w)), PETR_ERR_INVALID,
+             "ln_bwd_proj: pre_a needs pre_w, both 16-byte aligned");
   const petr_ln_bwd_proj_args& a = *ap;
-  PETR_CHECK(aligned16(a.wT), PETR_ERR_INVALID, "ln_bwd_proj: wT must be 16-byte aligned");
+  PETR_CHECK(aligned16(a.w) && aligned16(a.out) && (!a.relu_mask || aligned16(a.relu_mask)), PETR_ERR_INVALID,
+             "ln_bwd_proj: w / out / relu_mask must be 16-byte aligned");
+  PETR_CHECK(aligned16(a.z) && aligned16(a.gamma) && aligned16(a.dz) && (!a.dy || (aligned16(a.dy) && !(a.dy_partial_stride & 3))) &&
+                 (!a.dy_residual || aligned16(a.dy_residual)) && (!a.dz_drop || aligned16(a.dz_drop)),
+             PETR_ERR_INVALID, "ln_bwd_proj: every [.., 256] operand must be 16-byte aligned");
   PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "ln_bwd_proj: dropout p=%g outside [0,1)", (double)a.drop.p);
   PETR_CHECK(!(a.drop.p > 0.f) || a.dz_drop, PETR_ERR_INVALID, "ln_bwd_proj: dropout needs dz_drop");
   LbParams p;
@@ -757,10 +716,14 @@ extern "C" int petr_ln_bwd_proj(const petr_ln_bwd_proj_args* ap, void* stream) {
 }
 
 extern "C" int petr_ln_proj(const petr_ln_proj_args* ap, void* stream) {
-  PETR_CHECK(ap && ap->x && ap->gamma && ap->beta && ap->y && ap->w2 && ap->out2 && ap->M > 0 && ap->n_partials > 0 && ap->n2 > 0,
+  PETR_CHECK(ap && ap->x && ap->gamma && ap->beta && ap->y && ap->w2T && ap->out2 && ap->M > 0 && ap->n_partials > 0 && ap->n2 > 0,
              PETR_ERR_INVALID, "ln_proj: bad arguments");
   const petr_ln_proj_args& a = *ap;
-  PETR_CHECK(aligned16(a.w2), PETR_ERR_INVALID, "ln_proj: w2 must be 16-byte aligned");
+  PETR_CHECK(aligned16(a.w2T) && aligned16(a.out2), PETR_ERR_INVALID, "ln_proj: w2T / out2 must be 16-byte aligned");
+  PETR_CHECK(aligned16(a.x) && !(a.partial_stride & 3) && aligned16(a.gamma) && aligned16(a.beta) && aligned16(a.y) &&
+                 (!a.bias || aligned16(a.bias)) && (!a.residual || aligned16(a.residual)) && (!a.z || aligned16(a.z)) &&
+                 (!a.y2 || aligned16(a.y2)) && (!a.add2 || aligned16(a.add2)),
+             PETR_ERR_INVALID, "ln_proj: every [.., 256] operand must be 16-byte aligned");
   PETR_CHECK(!a.y2 || a.add2, PETR_ERR_INVALID, "ln_proj: y2 without add2");
   PETR_CHECK(a.n2_pos >= 0 && a.n2_pos <= a.n2 && (a.n2_pos == 0 || a.add2), PETR_ERR_INVALID, "ln_proj: n2_pos needs add2");
   PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "ln_proj: dropout p=%g outside [0,1)", (double)a.drop.p);
@@ -773,16 +736,17 @@ extern "C" int petr_ln_proj(const petr_ln_proj_args* ap, void* stream) {
 }
 
 extern "C" int petr_attn_out_ln(const petr_attn_out_ln_args* ap, void* stream) {
-  PETR_CHECK(ap && ap->a && ap->w && ap->gamma && ap->beta && ap->y && ap->M > 0, PETR_ERR_INVALID, "attn_out_ln: null pointer");
+  PETR_CHECK(ap && ap->a && ap->wT && ap->gamma && ap->beta && ap->y && ap->M > 0, PETR_ERR_INVALID, "attn_out_ln: null pointer");
   const petr_attn_out_ln_args& a = *ap;
-  PETR_CHECK(aligned16(a.a) && aligned16(a.w), PETR_ERR_INVALID, "attn_out_ln: a / w must be 16-byte aligned");
+  PETR_CHECK(aligned16(a.a) && aligned16(a.wT), PETR_ERR_INVALID, "attn_out_ln: a / wT must be 16-byte aligned");
   if (a.n_split > 1) {
     PETR_CHECK(a.o_part && a.ml_part && a.B > 0 && a.H == 8 && a.Q > 0 && a.M == a.B * a.Q && aligned16(a.o_part) &&
                    (((uintptr_t)a.ml_part) & 7) == 0,
                PETR_ERR_INVALID, "attn_out_ln: merging needs o_part / ml_part, H == 8 and M == B * Q");
   }
   PETR_CHECK(!a.y2 || a.add2, PETR_ERR_INVALID, "attn_out_ln: y2 without add2");
-  PETR_CHECK(!a.w2 || (a.out2 && aligned16(a.w2)), PETR_ERR_INVALID, "attn_out_ln: w2 needs out2 (and 16-byte alignment)");
+  PETR_CHECK(!a.w2T || (a.out2 && aligned16(a.w2T) && aligned16(a.out2)), PETR_ERR_INVALID,
+             "attn_out_ln: w2T needs out2 (both 16-byte aligned)");
   PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "attn_out_ln: dropout p=%g outside [0,1)", (double)a.drop.p);
   AoParams p;
   p.a = a;

@@ -513,18 +513,18 @@ static int ln_fwd(const float* x, int np, long pstride, const float* bias, const
 }
 
 // merge of the attention partials + out-projection + dropout + residual + LayerNorm (+ query_pos add) in one launch
-static int attn_out_ln(float* ao, const float* ws, int n_split, const Dims& d, float attn_scale, float* lse, const float* w,
+static int attn_out_ln(float* ao, const float* ws, int n_split, const Dims& d, float attn_scale, float* lse, const float* wT,
                        const float* bias, const float* res, const petr_dropout* drop, const float* g, const float* b, float* z,
                        float* mean, float* rstd, float* y, float* y2, const float* add2, int add2_rows, void* s,
-                       const float* w2 = nullptr, const float* bias2 = nullptr, float* out2 = nullptr) {
+                       const float* w2T = nullptr, const float* bias2 = nullptr, float* out2 = nullptr) {
   petr_attn_out_ln_args a;
   memset(&a, 0, sizeof a);
   a.a = ao; a.n_split = n_split; a.B = d.B; a.H = d.NH; a.Q = d.Q; a.attn_scale = attn_scale; a.lse = lse;
   if (n_split > 1) { a.o_part = ws; a.ml_part = ws + (long)n_split * d.B * d.NH * d.Q * 32; }
-  a.w = w; a.bias = bias; a.residual = res;
+  a.wT = wT; a.bias = bias; a.residual = res;
   if (drop) a.drop = *drop;
   a.gamma = g; a.beta = b; a.eps = 1e-5f; a.z = z; a.mean = mean; a.rstd = rstd; a.y = y; a.y2 = y2; a.add2 = add2;
-  a.add2_rows = add2_rows; a.M = (int)d.BQ; a.w2 = w2; a.bias2 = bias2; a.out2 = out2;
+  a.add2_rows = add2_rows; a.M = (int)d.BQ; a.w2T = w2T; a.bias2 = bias2; a.out2 = out2;
   return petr_attn_out_ln(&a, s);
 }
 
@@ -541,18 +541,18 @@ static int ln_bwd(const float* z, const float* mean, const float* rstd, const fl
   return petr_layernorm_bwd(&a, s);
 }
 
-// LayerNorm backward + the input gradient of the branch's linear layer (through its transposed weight) in one launch
+// LayerNorm backward + the input gradient of the branch's linear layer (dx = dz W: the weight as stored) in one launch
 static int ln_bwd_proj(const float* z, const float* mean, const float* rstd, const float* g, const float* dy, int dy_partials,
                        long dy_pstride, const float* dy_res, float* dz, float* dz_drop, const petr_dropout* drop, float* dg,
-                       float* db, long M, const float* wT, int n2, float alpha, const float* relu_mask, float* out, void* s,
-                       const float* pre_a = nullptr, const float* pre_wT = nullptr) {
+                       float* db, long M, const float* w, int n2, float alpha, const float* relu_mask, float* out, void* s,
+                       const float* pre_a = nullptr, const float* pre_w = nullptr) {
   petr_ln_bwd_proj_args a;
   memset(&a, 0, sizeof a);
   a.z = z; a.mean = mean; a.rstd = rstd; a.gamma = g; a.dy = dy; a.dy_partials = dy_partials; a.dy_partial_stride = dy_pstride;
   a.dy_residual = dy_res; a.dz = dz; a.dz_drop = dz_drop;
   if (drop && dz_drop) a.drop = *drop;
-  a.dgamma = dg; a.dbeta = db; a.M = (int)M; a.wT = wT; a.n2 = n2; a.alpha = alpha; a.relu_mask = relu_mask; a.out = out;
-  a.pre_a = pre_a; a.pre_wT = pre_wT;
+  a.dgamma = dg; a.dbeta = db; a.M = (int)M; a.w = w; a.n2 = n2; a.alpha = alpha; a.relu_mask = relu_mask; a.out = out;
+  a.pre_a = pre_a; a.pre_w = pre_w;
   return petr_ln_bwd_proj(&a, s);
 }
 
@@ -696,6 +696,13 @@ static int launch_weight_transposes(const float* Pm, float* Wm, const PL& P, con
   PETR_LAUNCH_CHECK("transpose_batch");
   return PETR_OK;
 }
+static bool env_on(const char* name) { const char* v = getenv(name); return !v || atoi(v) != 0; }    // default on
+// does the forward leave the transposed weight copies in the workspace?  (head_fwd makes them, head_bwd asks)
+template <class D>
+static bool fwd_transposes(const petr_head_config*, const D& d, int C) {
+  static const bool fuse_env = env_on("PETR_FUSE_OUT_LN"), ffn_env = env_on("PETR_FFN_FUSED");
+  return C == 256 && ((fuse_env && d.NH == 8) || ffn_env);
+}
 // dx[M,K] = dy[M,N] @ w[N,K] through wT[K][N]: both operands K-contiguous, like a forward
 static petr_gemm_args lin_dgrad_t(const float* dy, const float* wT, float* dx, long M, int N, int K) {
   petr_gemm_args g = gemm0();
@@ -709,7 +716,6 @@ static petr_gemm_args lin_dgrad_t(const float* dy, const float* wT, float* dx, l
 // bf16 mode stores the two 4C-wide position-embedding hiddens (relu outputs, the largest activations of the step) and their
 // gradients as bf16 in the front half of their fp32 buffers: every contraction that touches them rounds to bf16 on load
 // anyway, so only the bytes change.  Needs 16-byte K-contiguous rows on the bf16 side (C % 8 == 0 always holds).
-static bool env_on(const char* name) { const char* v = getenv(name); return !v || atoi(v) != 0; }    // default on
 static bool hidden_bf16(const petr_head_io* io) {
   static const bool on = env_on("PETR_HID16");       // PETR_HID16=0: fp32 storage (the same-box A/B switch)
   return io->attn_bf16 != 0 && on;
@@ -892,7 +898,9 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   // both FFN contractions in one launch (fp32 FFN; PETR_FFN_FUSED=0: two contractions): it reads the weights k-major
   static const bool ffn_fused_env = env_on("PETR_FFN_FUSED");
   const bool ffn_fused = ffn_fused_env && !ffn16 && W.ffn_fsplit > 0;
-  if (ffn_fused) RUN(launch_weight_transposes(Pm, Wm, P, W, d.NL, C, d.F, true, false, (hipStream_t)s));
+  // the 16- / 32-row kernels (petr_attn_out_ln, petr_ln_proj, petr_ffn_fwd) stream their weights k-major: transposed copies of
+  // the decoder weights, made here once per forward (the backward's input-gradient contractions read them too)
+  if (fwd_transposes(cfg, d, C)) RUN(launch_weight_transposes(Pm, Wm, P, W, d.NL, C, d.F, true, true, (hipStream_t)s));
   // ---- side 2: input_proj (petr_head.py:390) + sine 3D (positional_encoding.py:58-100) + adapt_pos3d hidden ----
   {
     petr_gemm_args g = gemm0();   // NCHW view [C_in][HW] read as an M-contiguous operand -> token-major memory
@@ -1052,10 +1060,10 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
       RUN(mha_f(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
                 Wm + lw.ao_s, Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, sched, s, training ? &dr_sp : nullptr,
                 use_bits ? bits_ptr(l, 1) : nullptr, ns_self, 1));
-      RUN(attn_out_ln(Wm + lw.ao_s, mws, ns_self, d, training ? hidden_drop_scale(dr_sp) : 1.f, Wm + lw.lse_s, Pm + lp.sa_out_w,
+      RUN(attn_out_ln(Wm + lw.ao_s, mws, ns_self, d, training ? hidden_drop_scale(dr_sp) : 1.f, Wm + lw.lse_s, Wm + W.wt[l].sa_out,
                       Pm + lp.sa_out_b, x_in, training ? &dr_so : nullptr, Pm + lp.n_g[0], Pm + lp.n_b[0], Wm + lw.z0,
                       Wm + lw.mean0, Wm + lw.rstd0, Wm + lw.x1, Wm + lw.xe1, E, d.Q, s,
-                      Pm + lp.ca_in_w, Pm + lp.ca_in_b, Wm + lw.qc));      // + the cross-attention's query projection
+                      Wm + W.wt[l].ca_q, Pm + lp.ca_in_b, Wm + lw.qc));    // + the cross-attention's query projection
     } else {
     RUN(mha_f(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
               Wm + lw.ao_s, Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, sched, s, training ? &dr_sp : nullptr,
@@ -1093,7 +1101,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
               Wm + W.v_all + (long)l * d.L * C, Wm + lw.ao_c, Wm + lw.lse_c, kpm, d, (int)d.L, mws, W.mha_ws_bytes, sched, s,
               training ? &dr_cp : nullptr, use_bits ? bits_ptr(l, 0) : nullptr, fuse_out ? ns_cross : 0, fuse_out ? 1 : 0));
     if (fuse_out) {
-      RUN(attn_out_ln(Wm + lw.ao_c, mws, ns_cross, d, training ? hidden_drop_scale(dr_cp) : 1.f, Wm + lw.lse_c, Pm + lp.ca_out_w,
+      RUN(attn_out_ln(Wm + lw.ao_c, mws, ns_cross, d, training ? hidden_drop_scale(dr_cp) : 1.f, Wm + lw.lse_c, Wm + W.wt[l].ca_out,
                       Pm + lp.ca_out_b, Wm + lw.x1, training ? &dr_co : nullptr, Pm + lp.n_g[1], Pm + lp.n_b[1], Wm + lw.z1,
                       Wm + lw.mean1, Wm + lw.rstd1, Wm + lw.x2, nullptr, nullptr, 0, s));
     } else {
@@ -1141,7 +1149,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
       q.gamma = Pm + lp.n_g[2]; q.beta = Pm + lp.n_b[2]; q.eps = 1e-5f;
       q.z = slabs ? Wm + lw.z2 : nullptr; q.mean = Wm + lw.mean2; q.rstd = Wm + lw.rstd2; q.y = xs_l;
       q.y2 = xe_next; q.add2 = E; q.add2_rows = d.Q; q.M = (int)d.BQ;
-      q.w2 = Pm + P.lay[l + 1].sa_in_w; q.bias2 = Pm + P.lay[l + 1].sa_in_b; q.out2 = Wm + W.lay[l + 1].qkv; q.n2 = 3; q.n2_pos = 2;
+      q.w2T = Wm + W.wt[l + 1].sa_in; q.bias2 = Pm + P.lay[l + 1].sa_in_b; q.out2 = Wm + W.lay[l + 1].qkv; q.n2 = 3; q.n2_pos = 2;
       RUN(petr_ln_proj(&q, s));
     } else if (!slabs) {
       RUN(ln_fwd(Wm + lw.z2, 1, 0, nullptr, nullptr, Pm + lp.n_g[2], Pm + lp.n_b[2], xs_l, nullptr, Wm + lw.mean2,
@@ -1249,9 +1257,9 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   static const bool defer_env = env_on("PETR_WGRAD_DEFER");
   static const bool dgrad_t = env_on("PETR_DGRAD_T");        // PETR_DGRAD_T=0: input gradients read W itself (K-major operand)
   hipEvent_t ev_tr = nullptr;
-  // LayerNorm backward + the following input gradient in one launch (needs the transposed weights; PETR_FUSE_LN_BWD=0: separate)
+  // LayerNorm backward + the following input gradient in one launch (PETR_FUSE_LN_BWD=0: separate)
   static const bool fuse_bwd_env = env_on("PETR_FUSE_LN_BWD");
-  const bool fuse_bwd = fuse_bwd_env && dgrad_t && C == 256;
+  const bool fuse_bwd = fuse_bwd_env && C == 256;
   int wg_rr = 0, n_pend = 0;
   bool defer = false;
   petr_gemm_args pend[24];
@@ -1277,8 +1285,6 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   const int wflag = tok16 ? PETR_GEMM_B_BF16 : 0;
   static const bool ffn16_env = env_on("PETR_FFN16");
   const bool ffn16 = tok16 && ffn16_env;
-  static const bool ffn_fused_env = env_on("PETR_FFN_FUSED");
-  const bool ffn_fused = ffn_fused_env && !ffn16 && W.ffn_fsplit > 0;   // the forward's condition (head_fwd)
   static const bool drop_bits_env = env_on("PETR_DROP_BITS");          // the forward generated them (same workspace)
   const bool use_bits = io->dropout_p > 0.f && drop_bits_env;
   const uint32_t* bits0 = reinterpret_cast<const uint32_t*>(Wm + W.bits);
@@ -1322,8 +1328,9 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // transposed decoder weights for the layer stages' input gradients: side stream 1, beside the branch backward
       if (dgrad_t) {
         ln.fork(1);
-        // the FFN pair is already there when the forward ran petr_ffn_fwd (same parameters, same workspace)
-        RUN(launch_weight_transposes(Pm, Wm, P, W, d.NL, C, d.F, !ffn_fused, true, (hipStream_t)ln.side(1)));
+        // nothing to do when the forward made them (same parameters, same workspace)
+        const bool have = fwd_transposes(cfg, d, C);
+        RUN(launch_weight_transposes(Pm, Wm, P, W, d.NL, C, d.F, !have, !have, (hipStream_t)ln.side(1)));
         if (ln.ctx) {
           ev_tr = ln.next();
           (void)hipEventRecord(ev_tr, (hipStream_t)ln.side(1));
@@ -1452,7 +1459,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       static const bool fuse_ffn2 = getenv("PETR_FUSE_LN_BWD") && atoi(getenv("PETR_FUSE_LN_BWD")) == 2;
       if (fuse_bwd && fuse_ffn2 && d.F % 256 == 0) {
         RUN(ln_bwd_proj(Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, Pm + lp.n_g[2], G, 1, 0, nullptr, d_z2,
-                        training ? d_f2 : nullptr, training ? &dr[5] : nullptr, Gp + lp.n_g[2], Gp + lp.n_b[2], d.BQ, Wm + wt.f2,
+                        training ? d_f2 : nullptr, training ? &dr[5] : nullptr, Gp + lp.n_g[2], Gp + lp.n_b[2], d.BQ, Pm + lp.f2_w,
                         d.F / 256, training ? hidden_drop_scale(dr[4]) : 1.f, Wm + lw.hff, d_h, s));
         RUN(wgrad(lin_wgrad(d_f2, C, Wm + lw.hff, d.F, Gp + lp.f2_w, Gp + lp.f2_b, d.BQ, C, d.F)));
       } else {
@@ -1481,7 +1488,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       float* d_ao = Wm + lg.d_ao;
       if (fuse_bwd) {
         RUN(ln_bwd_proj(Wm + lw.z1, Wm + lw.mean1, Wm + lw.rstd1, Pm + lp.n_g[1], d_x2, sk, d.BQ * C, sk > 1 ? d_z2 : nullptr, d_z1,
-                        training ? d_f1 : nullptr, training ? &dr[3] : nullptr, Gp + lp.n_g[1], Gp + lp.n_b[1], d.BQ, Wm + wt.ca_out,
+                        training ? d_f1 : nullptr, training ? &dr[3] : nullptr, Gp + lp.n_g[1], Gp + lp.n_b[1], d.BQ, Pm + lp.ca_out_w,
                         1, 1.f, nullptr, d_ao, s));
         RUN(wgrad(lin_wgrad(d_f1, C, Wm + lw.ao_c, C, Gp + lp.ca_out_w, Gp + lp.ca_out_b, d.BQ, C, C)));
       } else {
@@ -1559,8 +1566,8 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       if (fuse_bwd) {
         // d(x1) = d_qc Wq (the query projection's input gradient, formed in the kernel) + d_z1 (identity path of LN1)
         RUN(ln_bwd_proj(Wm + lw.z0, Wm + lw.mean0, Wm + lw.rstd0, Pm + lp.n_g[0], nullptr, 0, 0, d_z1, d_z0,
-                        training ? d_f0 : nullptr, training ? &dr[1] : nullptr, Gp + lp.n_g[0], Gp + lp.n_b[0], d.BQ, Wm + wt.sa_out,
-                        1, 1.f, nullptr, d_ao_s, s, d_qc, Wm + wt.ca_q));
+                        training ? d_f0 : nullptr, training ? &dr[1] : nullptr, Gp + lp.n_g[0], Gp + lp.n_b[0], d.BQ, Pm + lp.sa_out_w,
+                        1, 1.f, nullptr, d_ao_s, s, d_qc, Pm + lp.ca_in_w));
         RUN(wgrad(lin_wgrad(d_f0, C, Wm + lw.ao_s, C, Gp + lp.sa_out_w, Gp + lp.sa_out_b, d.BQ, C, C)));
       } else {
       RUN(ln_bwd(Wm + lw.z0, Wm + lw.mean0, Wm + lw.rstd0, Pm + lp.n_g[0], d_x1, nullptr, d_z0, Gp + lp.n_g[0],

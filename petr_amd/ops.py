@@ -121,7 +121,7 @@ def attn_out_ln(a, w, bias, residual, gamma, beta, partials=None, n_split=1, BHQ
                 add2_rows=0, eps=1e-5, w2=None, bias2=None):
     """petr_attn_out_ln: [merge of the attention partials ->] a W^T + bias -> dropout -> + residual -> LayerNorm (-> + add2).
     ``a``: [M, 256] attention output (n_split <= 1) or an uninitialised [M, 256] buffer that receives the merged output.
-    Returns (y, y2 or None, z, mean, rstd, lse or None)."""
+    w, w2: nn.Linear layout [out, in] (transposed here: the kernel reads them k-major).  Returns (y, y2 or None, z, mean, rstd, lse or None)."""
     L = _C.lib()
     M = a.shape[0]
     y, z = torch.empty_like(a), torch.empty_like(a)
@@ -131,9 +131,11 @@ def attn_out_ln(a, w, bias, residual, gamma, beta, partials=None, n_split=1, BHQ
     lse = torch.empty(B * H * Q, device=a.device) if n_split > 1 else None
     o_part = partials if n_split > 1 else None
     ml_part = partials[n_split * B * H * Q * 32:] if n_split > 1 else None
-    args = _C.AttnOutLnArgs(_ptr(a), _ptr(o_part), _ptr(ml_part), n_split, B, H, Q, float(attn_scale), _ptr(lse), _ptr(w), _ptr(bias),
+    wT = w.t().contiguous()                                   # the kernel streams the weights k-major
+    w2T = w2.t().contiguous() if w2 is not None else None
+    args = _C.AttnOutLnArgs(_ptr(a), _ptr(o_part), _ptr(ml_part), n_split, B, H, Q, float(attn_scale), _ptr(lse), _ptr(wT), _ptr(bias),
                             _ptr(residual), _C.dropout(drop), _ptr(gamma), _ptr(beta), float(eps), _ptr(z), _ptr(mean), _ptr(rstd),
-                            _ptr(y), _ptr(y2), _ptr(add2), add2_rows, M, _ptr(w2), _ptr(bias2), None)
+                            _ptr(y), _ptr(y2), _ptr(add2), add2_rows, M, _ptr(w2T), _ptr(bias2), None)
     out2 = torch.empty_like(a) if w2 is not None else None
     args.out2 = _ptr(out2)
     _C.check(L.petr_attn_out_ln(C.byref(args), _stream()), 'petr_attn_out_ln')
@@ -155,8 +157,9 @@ def ln_proj(x, gamma, beta, w2, bias2=None, bias=None, residual=None, drop=None,
     y2 = torch.empty_like(y) if add2 is not None else None
     mean, rstd = torch.empty(M, device=x.device), torch.empty(M, device=x.device)
     out2 = torch.empty((M, 256 * n2), device=x.device)
+    w2T = w2.t().contiguous()                                 # [256, 256 n2]: the kernel streams the weight k-major
     a = _C.LnProjArgs(_ptr(_f32(x)), P, M * Cc, _ptr(bias), _ptr(residual), _C.dropout(drop), _ptr(gamma), _ptr(beta), float(eps),
-                      _ptr(z), _ptr(mean), _ptr(rstd), _ptr(y), _ptr(y2), _ptr(add2), add2_rows, M, _ptr(w2), _ptr(bias2), _ptr(out2),
+                      _ptr(z), _ptr(mean), _ptr(rstd), _ptr(y), _ptr(y2), _ptr(add2), add2_rows, M, _ptr(w2T), _ptr(bias2), _ptr(out2),
                       n2, n2_pos)
     _C.check(L.petr_ln_proj(C.byref(a), _stream()), 'petr_ln_proj')
     return y, y2, z, mean, rstd, out2
@@ -172,17 +175,17 @@ def ln_bwd_proj(z, mean, rstd, gamma, dy, w, dy_residual=None, drop=None, alpha=
         P, M, Cc = dy.shape
     else:
         P, (M, Cc) = 1, dy.shape
-    wT = w.t().contiguous()
-    pre_wT = pre_w.t().contiguous() if pre_w is not None else None
-    n2 = wT.shape[0] // 256
+    w = w.contiguous()                   # dx = dz W: the nn.Linear weight is already k-major for this product
+    pre_w = pre_w.contiguous() if pre_w is not None else None
+    n2 = w.shape[1] // 256
     dz = torch.empty((M, Cc), device=z.device)
     dzd = torch.empty_like(dz) if drop is not None else None
     dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
     out = torch.empty((M, 256 * n2), device=z.device)
     dyc = _f32(dy).contiguous() if dy is not None else None
     a = _C.LnBwdProjArgs(_ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dyc), P, M * Cc, _ptr(dy_residual),
-                         _ptr(dz), _ptr(dzd), _C.dropout(drop), _ptr(dg), _ptr(db), M, _ptr(wT), n2, float(alpha), _ptr(relu_mask),
-                         _ptr(out), _ptr(pre_a), _ptr(pre_wT))
+                         _ptr(dz), _ptr(dzd), _C.dropout(drop), _ptr(dg), _ptr(db), M, _ptr(w), n2, float(alpha), _ptr(relu_mask),
+                         _ptr(out), _ptr(pre_a), _ptr(pre_w))
     _C.check(L.petr_ln_bwd_proj(C.byref(a), _stream()), 'petr_ln_bwd_proj')
     return dz, dzd, dg, db, out
 

@@ -370,6 +370,19 @@ typedef struct {
 } petr_ffn_fwd_args;
 int petr_ffn_fwd(const petr_ffn_fwd_args* a, void* stream);
 
+/* The FFN's input gradient in one launch (the backward of petr_ffn_fwd's two products):
+ *     d_hidden = alpha * (dy w2) where hidden > 0, else 0      [M, F]   (written: the first layer's weight gradient reads it)
+ *     part[s]  = d_hidden[:, slice s] w1[slice s, :]           [M, 256], summed by the consumer (petr_ln_bwd_proj's dy slabs)
+ *   dy [M, 256] = gradient of the FFN output (after the output dropout's mask), hidden [M, F] = the forward's stored hidden
+ *   (post ReLU and dropout: zero exactly where no gradient flows), alpha = the hidden dropout's 1/(1-p) (0 or 1: none).
+ *   w1 [F, 256], w2 [256, F]: the nn.Linear weights as stored (both products are k-major in them). */
+typedef struct {
+  const float* dy; const float* w2; const float* hidden; float alpha; const float* w1;
+  float* d_hidden; float* part; long part_stride;
+  int M, F, n_split;
+} petr_ffn_bwd_args;
+int petr_ffn_bwd(const petr_ffn_bwd_args* a, void* stream);
+
 /* y[i] = bf16(x[i]) (round to nearest even), n elements, both 16-byte aligned: produces the bf16 K/V operands
  * from the fp32 projections (the tensor .to(bfloat16) an autocast reference run would do) */
 int petr_cast_bf16(const float* x, uint16_t* y, long n, void* stream);

@@ -129,6 +129,13 @@ class FfnFwdArgs(C.Structure):
         ('M', C.c_int), ('F', C.c_int), ('n_split', C.c_int))
 
 
+class FfnBwdArgs(C.Structure):
+    _fields_ = _fields(
+        ('dy', C.c_void_p), ('w2', C.c_void_p), ('hidden', C.c_void_p), ('alpha', C.c_float), ('w1', C.c_void_p),
+        ('d_hidden', C.c_void_p), ('part', C.c_void_p), ('part_stride', C.c_long),
+        ('M', C.c_int), ('F', C.c_int), ('n_split', C.c_int))
+
+
 class MhaBwdArgs(C.Structure):
     _fields_ = _fields(
         ('q', C.c_void_p), ('q_bs', C.c_long), ('q_hs', C.c_long), ('q_rs', C.c_long),
@@ -297,7 +304,7 @@ EXPORTS = [
     'petr_posemb3d_fwd', 'petr_posemb3d_bwd', 'petr_gemm', 'petr_colsum_workspace_bytes', 'petr_colsum',
     'petr_layernorm_fwd', 'petr_layernorm_bwd_workspace_bytes', 'petr_layernorm_bwd',
     'petr_mha_fwd_workspace_bytes', 'petr_mha_choose_split', 'petr_mha_fwd', 'petr_mha_fwd_bf16_workspace_bytes',
-    'petr_mha_fwd_bf16', 'petr_mha_fwd_bf16_choose_split', 'petr_attn_out_ln', 'petr_ln_proj', 'petr_ln_bwd_proj', 'petr_ffn_fwd', 'petr_cast_bf16', 'petr_add_rows_bf16', 'petr_mha_bwd_workspace_bytes',
+    'petr_mha_fwd_bf16', 'petr_mha_fwd_bf16_choose_split', 'petr_attn_out_ln', 'petr_ln_proj', 'petr_ln_bwd_proj', 'petr_ffn_fwd', 'petr_ffn_bwd', 'petr_cast_bf16', 'petr_add_rows_bf16', 'petr_mha_bwd_workspace_bytes',
     'petr_mha_bwd', 'petr_mha_bwd_bf16_workspace_bytes', 'petr_mha_bwd_bf16', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows', 'petr_gate_fwd', 'petr_gate_bwd', 'petr_prof_begin', 'petr_prof_end',
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',

@@ -582,10 +582,13 @@ struct FfParams {
   petr_ffn_fwd_args a;
   DropDev drop;
   int nrb;          // row blocks
+  const float* mask;   // backward (petr_ffn_bwd): the forward's hidden [M, F]; the first product's result is zeroed where it is <= 0
+  float alpha;         //   and scaled by the hidden dropout's 1 / (1 - p) elsewhere, instead of bias / ReLU / dropout
 };
 
 constexpr int FF_ROWS = 32;
 
+template <bool BWD>
 __global__ __launch_bounds__(512) void ffn_fwd_kernel(const FfParams p) {
   __shared__ __attribute__((aligned(16))) float As[FF_ROWS * AO_PITCH];     // the x rows
   __shared__ __attribute__((aligned(16))) float Hs[FF_ROWS * AO_PITCH];     // one block of 256 hidden units
@@ -633,6 +636,14 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const FfParams p) {
 #pragma unroll
     for (int rg = 0; rg < 2; ++rg) acc[rg][0] = acc[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* w2b = w2 + (long)256 * b * AO_C;
+    float2 msk[2][4];
+    if (BWD) {          // the forward's hidden at this lane's accumulator elements, requested ahead of the product
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          msk[rg][i] = *reinterpret_cast<const float2*>(p.mask + (long)min(m0 + 16 * rg + 4 * q4 + i, a.M - 1) * a.F + h0 + 256 * b + c0);
+    }
     ws.run(arow, AO_PITCH, w1 + 256 * b, a.F, lo1, w2b, AO_C, lo2, acc);
     const float2 bc = bia;
     if (b + 1 < nb && a.b1) bia = *reinterpret_cast<const float2*>(a.b1 + h0 + 256 * (b + 1) + c0);
@@ -642,8 +653,15 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const FfParams p) {
     for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float u0 = fmaxf(acc[rg][0][i] + bc.x, 0.f), u1 = fmaxf(acc[rg][1][i] + bc.y, 0.f);
-        if (p.drop.thr) {
+        float u0, u1;
+        if (BWD) {
+          u0 = msk[rg][i].x > 0.f ? acc[rg][0][i] * p.alpha : 0.f;
+          u1 = msk[rg][i].y > 0.f ? acc[rg][1][i] * p.alpha : 0.f;
+        } else {
+          u0 = fmaxf(acc[rg][0][i] + bc.x, 0.f);
+          u1 = fmaxf(acc[rg][1][i] + bc.y, 0.f);
+        }
+        if (!BWD && p.drop.thr) {
           const uint32_t hsh = drop_pair_hash(rk[rg][i], (uint32_t)f0 >> 1);
           u0 = (uint16_t)hsh >= (uint16_t)p.drop.thr ? u0 * p.drop.scale : 0.f;
           u1 = (uint16_t)(hsh >> 16) >= (uint16_t)p.drop.thr ? u1 * p.drop.scale : 0.f;
@@ -687,8 +705,36 @@ extern "C" int petr_ffn_fwd(const petr_ffn_fwd_args* ap, void* stream) {
   p.nrb = (int)cdiv(a.M, FF_ROWS);
   const int rep = 8 / a.n_split;
   const long grid = cdiv(p.nrb, rep) * 8;
-  hipLaunchKernelGGL(ffn_fwd_kernel, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
+  p.mask = nullptr; p.alpha = 1.f;
+  hipLaunchKernelGGL(ffn_fwd_kernel<false>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
   PETR_LAUNCH_CHECK("ffn_fwd");
+  return PETR_OK;
+}
+
+// the FFN's input gradient: the same two chained products with the weights as stored (dh = dy W2 is k-major in W2 [256, F],
+// dx = dh W1 in W1 [F, 256]) and the ReLU / dropout mask in place of bias, ReLU and dropout
+extern "C" int petr_ffn_bwd(const petr_ffn_bwd_args* ap, void* stream) {
+  PETR_CHECK(ap && ap->dy && ap->w2 && ap->hidden && ap->w1 && ap->d_hidden && ap->part && ap->M > 0 && ap->F > 0, PETR_ERR_INVALID,
+             "ffn_bwd: bad arguments");
+  const petr_ffn_bwd_args& b = *ap;
+  PETR_CHECK(b.n_split == 1 || b.n_split == 2 || b.n_split == 4 || b.n_split == 8, PETR_ERR_UNSUPPORTED,
+             "ffn_bwd: n_split=%d not in {1, 2, 4, 8}", b.n_split);
+  PETR_CHECK(b.F % (256 * b.n_split) == 0, PETR_ERR_UNSUPPORTED, "ffn_bwd: F=%d must be a multiple of 256 * n_split", b.F);
+  PETR_CHECK(aligned16(b.dy) && aligned16(b.w2) && aligned16(b.w1) && aligned16(b.hidden) && aligned16(b.d_hidden) && aligned16(b.part) &&
+                 !(b.part_stride & 3),
+             PETR_ERR_INVALID, "ffn_bwd: every operand must be 16-byte aligned");
+  PETR_CHECK(b.n_split == 1 || b.part_stride >= (long)b.M * AO_C, PETR_ERR_INVALID, "ffn_bwd: part_stride too small");
+  FfParams p;
+  memset(&p.a, 0, sizeof p.a);
+  p.a.x = b.dy; p.a.w1t = b.w2; p.a.b1 = nullptr; p.a.w2t = b.w1; p.a.hidden = b.d_hidden; p.a.part = b.part;
+  p.a.part_stride = b.part_stride; p.a.M = b.M; p.a.F = b.F; p.a.n_split = b.n_split;
+  p.drop = DropDev{0u, 0u, 0u, 1.f};
+  p.nrb = (int)cdiv(b.M, FF_ROWS);
+  p.mask = b.hidden; p.alpha = b.alpha == 0.f ? 1.f : b.alpha;
+  const int rep = 8 / b.n_split;
+  const long grid = cdiv(p.nrb, rep) * 8;
+  hipLaunchKernelGGL(ffn_fwd_kernel<true>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
+  PETR_LAUNCH_CHECK("ffn_bwd");
   return PETR_OK;
 }
 

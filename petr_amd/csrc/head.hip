@@ -414,7 +414,7 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
     WOff::LayerG& g = W.lg[l];
     g.d_z2 = wb.add("g_d_z2", d.BQ * C);
     g.d_h = wb.add("g_d_h", d.BQ * d.F);
-    g.d_x2 = wb.add("g_d_x2", (long)W.ffn_split * d.BQ * C);
+    g.d_x2 = wb.add("g_d_x2", (long)(W.ffn_fsplit > W.ffn_split ? W.ffn_fsplit : W.ffn_split) * d.BQ * C);
     g.d_z1 = wb.add("g_d_z1", d.BQ * C);
     g.d_ao = wb.add("g_d_ao", d.BQ * C);
     g.d_x1 = wb.add("g_d_x1", d.BQ * C);
@@ -1453,10 +1453,25 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       const WOff::LayerT& wt = W.wt[l];
       petr_gemm_args g;
       // stored hidden = relu(.) * keep/(1-p): (hidden > 0) is relu-mask AND keep; the 1/(1-p) rides on alpha
-      // (the fused form also exists for this site - LayerNorm backward + the FFN2 input gradient with its ReLU mask, 8 column
-      // blocks - but measured 64-77 us against 10 + 40 for the two kernels: eight re-derivations of the rows and a scalar
-      // mask epilogue; PETR_FUSE_LN_BWD=2 selects it)
-      static const bool fuse_ffn2 = getenv("PETR_FUSE_LN_BWD") && atoi(getenv("PETR_FUSE_LN_BWD")) == 2;
+      // PETR_FUSE_LN_BWD: 3 (default) both FFN input gradients in one launch (petr_ffn_bwd: d_h stays on chip between them);
+      // 2: LayerNorm backward + the FFN2 input gradient with its ReLU mask in petr_ln_bwd_proj (8 column blocks); 1: separate
+      static const int fuse_lvl = getenv("PETR_FUSE_LN_BWD") ? atoi(getenv("PETR_FUSE_LN_BWD")) : 3;
+      const bool ffn_bwd_fused = fuse_bwd && fuse_lvl >= 3 && W.ffn_fsplit > 0 && !ffn16;   // bf16 mode: level 2 measured level with it
+      const bool fuse_ffn2 = fuse_lvl >= 2;
+      float* d_x2 = Wm + lg.d_x2;
+      const int sk = ffn_bwd_fused ? W.ffn_fsplit : W.ffn_split;
+      if (ffn_bwd_fused) {
+        RUN(ln_bwd(Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, Pm + lp.n_g[2], G, nullptr, d_z2, Gp + lp.n_g[2], Gp + lp.n_b[2],
+                   d.BQ, C, 0, 0, s, 1, 0, nullptr, training ? d_f2 : nullptr, &dr[5]));
+        RUN(wgrad(lin_wgrad(d_f2, C, Wm + lw.hff, d.F, Gp + lp.f2_w, Gp + lp.f2_b, d.BQ, C, d.F)));
+        petr_ffn_bwd_args fb;
+        memset(&fb, 0, sizeof fb);
+        fb.dy = d_f2; fb.w2 = Pm + lp.f2_w; fb.hidden = Wm + lw.hff; fb.alpha = training ? hidden_drop_scale(dr[4]) : 1.f;
+        fb.w1 = Pm + lp.f1_w; fb.d_hidden = d_h; fb.part = d_x2; fb.part_stride = d.BQ * C;
+        fb.M = (int)d.BQ; fb.F = (int)d.F; fb.n_split = sk;
+        RUN(petr_ffn_bwd(&fb, s));
+        RUN(wgrad(lin_wgrad(d_h, d.F, Wm + lw.x2, C, Gp + lp.f1_w, Gp + lp.f1_b, d.BQ, d.F, C)));
+      } else {
       if (fuse_bwd && fuse_ffn2 && d.F % 256 == 0) {
         RUN(ln_bwd_proj(Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, Pm + lp.n_g[2], G, 1, 0, nullptr, d_z2,
                         training ? d_f2 : nullptr, training ? &dr[5] : nullptr, Gp + lp.n_g[2], Gp + lp.n_b[2], d.BQ, Pm + lp.f2_w,
@@ -1475,25 +1490,25 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       RUN(wgrad(lin_wgrad(d_h, d.F, Wm + lw.x2, C, Gp + lp.f1_w, Gp + lp.f1_b, d.BQ, d.F, C)));
       // d_x2 = d_h @ W1 + d_z2 (identity path): K = F is long and there are only BQ/64 x 4 output tiles, so the
       // contraction is split over K into slabs that the LayerNorm backward sums in its prologue
-      float* d_x2 = Wm + lg.d_x2;
-      const int sk = W.ffn_split;
       g = dgrad_t ? lin_dgrad_t(d_h, Wm + wt.f1, d_x2, d.BQ, d.F, C) : lin_dgrad(d_h, Pm + lp.f1_w, d_x2, d.BQ, d.F, C);
       if (ffn16) { g = lin_dgrad(d_h, Wp(lp.f1_w), d_x2, d.BQ, d.F, C); g.flags = PETR_GEMM_BF16 | wflag; }
       if (sk > 1) { g.split_k = sk; g.c_split_stride = d.BQ * C; }
       else { g.r = d_z2; g.ldr = C; }
       RUN(petr_gemm(&g, s));
+      }
+      const float* id2 = (ffn_bwd_fused || sk > 1) ? d_z2 : nullptr;    // LN2's identity path: not inside the slabs
       // LN1 / cross-attention
       float* d_z1 = Wm + lg.d_z1;
       float* d_f1 = training ? Wm + lg.d_zd[1] : d_z1;          // gradient of the cross-attention out-projection's output
       float* d_ao = Wm + lg.d_ao;
       if (fuse_bwd) {
-        RUN(ln_bwd_proj(Wm + lw.z1, Wm + lw.mean1, Wm + lw.rstd1, Pm + lp.n_g[1], d_x2, sk, d.BQ * C, sk > 1 ? d_z2 : nullptr, d_z1,
+        RUN(ln_bwd_proj(Wm + lw.z1, Wm + lw.mean1, Wm + lw.rstd1, Pm + lp.n_g[1], d_x2, sk, d.BQ * C, id2, d_z1,
                         training ? d_f1 : nullptr, training ? &dr[3] : nullptr, Gp + lp.n_g[1], Gp + lp.n_b[1], d.BQ, Pm + lp.ca_out_w,
                         1, 1.f, nullptr, d_ao, s));
         RUN(wgrad(lin_wgrad(d_f1, C, Wm + lw.ao_c, C, Gp + lp.ca_out_w, Gp + lp.ca_out_b, d.BQ, C, C)));
       } else {
       RUN(ln_bwd(Wm + lw.z1, Wm + lw.mean1, Wm + lw.rstd1, Pm + lp.n_g[1], d_x2, nullptr, d_z1, Gp + lp.n_g[1],
-                 Gp + lp.n_b[1], d.BQ, C, 0, 0, s, sk, d.BQ * C, sk > 1 ? d_z2 : nullptr, training ? d_f1 : nullptr, &dr[3]));
+                 Gp + lp.n_b[1], d.BQ, C, 0, 0, s, sk, d.BQ * C, id2, training ? d_f1 : nullptr, &dr[3]));
       RUN(wgrad(lin_wgrad(d_f1, C, Wm + lw.ao_c, C, Gp + lp.ca_out_w, Gp + lp.ca_out_b, d.BQ, C, C)));
       g = dgrad_t ? lin_dgrad_t(d_f1, Wm + wt.ca_out, d_ao, d.BQ, C, C) : lin_dgrad(d_f1, Pm + lp.ca_out_w, d_ao, d.BQ, C, C);
       RUN(petr_gemm(&g, s));

@@ -204,6 +204,18 @@ def ffn_fwd(x, w1, b1, w2, n_split=4, drop=None, store_hidden=True, transposed=N
     return hidden, part
 
 
+def ffn_bwd(dy, w1, w2, hidden, alpha=1.0, n_split=4):
+    """petr_ffn_bwd: d_hidden = alpha * (dy @ w2) masked by hidden > 0, and the per-slice partial sums of d_hidden @ w1.
+    dy [M,256], w1 [F,256], w2 [256,F], hidden [M,F].  Returns (d_hidden [M,F], part [n_split, M, 256])."""
+    L = _C.lib()
+    M, F = dy.shape[0], w1.shape[0]
+    dh = torch.empty((M, F), device=dy.device)
+    part = torch.empty((n_split, M, 256), device=dy.device)
+    a = _C.FfnBwdArgs(_ptr(_f32(dy)), _ptr(w2), _ptr(hidden), float(alpha), _ptr(w1), _ptr(dh), _ptr(part), M * 256, M, F, n_split)
+    _C.check(L.petr_ffn_bwd(C.byref(a), _stream()), 'petr_ffn_bwd')
+    return dh, part
+
+
 def dropout_bits(drop, BH, Q, L, device='cuda'):
     """The attention-dropout mask of ``dropout_mask(drop, BH * Q, L)`` packed for the attention kernels:
     (query-major words for ``mha_fwd*``, key-major words for ``mha_bwd*``), both int32 [petr_dropout_bits_words]."""

@@ -849,6 +849,24 @@ def test_ffn_fwd_equals_the_two_contractions(ops, M, F, n_split, training):
     assert torch.equal(part, part2)
 
 
+@pytest.mark.parametrize('M,F,n_split,alpha', [(900, 2048, 8, 1.0 / (1 - 6554 / 65536)), (1800, 2048, 4, 1.0), (37, 512, 2, 1.25)])
+def test_ffn_bwd_equals_the_two_input_gradients(ops, M, F, n_split, alpha):
+    """petr_ffn_bwd against float64: d_hidden = alpha (dy W2) where the forward's hidden is positive, slabs = d_hidden W1 per slice."""
+    g = torch.Generator().manual_seed(M + F + n_split)
+    C = 256
+    dy = dev(torch.randn(M, C, generator=g))
+    w1, w2 = dev(torch.randn(F, C, generator=g) * 0.06), dev(torch.randn(C, F, generator=g) * 0.03)
+    hidden = dev(torch.relu(torch.randn(M, F, generator=g)))            # zeros where the ReLU / the dropout blocked the unit
+    dh, part = ops.ffn_bwd(dy, w1, w2, hidden, alpha=alpha, n_split=n_split)
+    dh_ref = (dy.double() @ w2.double()) * alpha * (hidden > 0)
+    assert relerr(dh, dh_ref) < 2e-6
+    assert torch.equal(dh == 0, dh_ref == 0)
+    hb = F // n_split
+    for s_ in range(n_split):
+        ref = dh[:, s_ * hb:(s_ + 1) * hb].double() @ w1[s_ * hb:(s_ + 1) * hb].double()
+        assert relerr(part[s_], ref) < 2e-6, s_
+
+
 @pytest.mark.parametrize('M,P,F,training', [(900, 1, 256, True), (900, 4, 256, False), (900, 1, 2048, True), (37, 2, 512, True)])
 def test_ln_bwd_proj_equals_layernorm_bwd_then_input_gradient(ops, M, P, F, training):
     """petr_ln_bwd_proj against the two launches it replaces: layernorm_bwd (slab sum + identity path, dropped copy, dgamma /

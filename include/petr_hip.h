@@ -347,9 +347,11 @@ typedef struct {
   int M;
   const float* w; int n2; float alpha; const float* relu_mask; float* out;
   const float* pre_a; const float* pre_w;    /* optional leading product: the upstream gradient is
-                                              * pre_a [M,256] pre_w[256,256] + sum of the dy slabs (dy_partials may be 0)
-                                              * + dy_residual - the input gradient of the projection that read the
+                                              * pre_a [M, 256 pre_n] pre_w[256 pre_n, 256] + sum of the dy slabs (dy_partials
+                                              * may be 0) + dy_residual - the input gradient of the projection that read the
                                               * normalised rows (pre_w = that nn.Linear weight) */
+  int pre_n;                                 /* its depth in blocks of 256 (0 = 1; at most 3: a self-attention in_proj).  With
+                                              * a leading product n2 may be 0: LayerNorm backward only (w, out unused) */
 } petr_ln_bwd_proj_args;
 int petr_ln_bwd_proj(const petr_ln_bwd_proj_args* a, void* stream);
 

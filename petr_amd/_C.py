@@ -119,7 +119,7 @@ class LnBwdProjArgs(C.Structure):
         ('dy', C.c_void_p), ('dy_partials', C.c_int), ('dy_partial_stride', C.c_long), ('dy_residual', C.c_void_p),
         ('dz', C.c_void_p), ('dz_drop', C.c_void_p), ('drop', Dropout), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p),
         ('M', C.c_int), ('w', C.c_void_p), ('n2', C.c_int), ('alpha', C.c_float), ('relu_mask', C.c_void_p), ('out', C.c_void_p),
-        ('pre_a', C.c_void_p), ('pre_w', C.c_void_p))
+        ('pre_a', C.c_void_p), ('pre_w', C.c_void_p), ('pre_n', C.c_int))
 
 
 class FfnFwdArgs(C.Structure):

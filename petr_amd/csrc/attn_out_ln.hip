@@ -446,7 +446,7 @@ __global__ __launch_bounds__(512) void ln_bwd_proj_kernel(const LbParams p) {
   const int m0 = blockIdx.x * AO_ROWS, jb = blockIdx.y;
   const int nl = lane & 15, q4 = lane >> 4;
   const long ld2 = 256L * a.n2;
-  const float* w0 = a.w + 256 * jb + 32 * wave;              // this wave's 32 columns of W [256][256 n2]: dx = dz W
+  const float* w0 = a.w ? a.w + 256 * jb + 32 * wave : nullptr;   // this wave's 32 columns of W [256][256 n2]: dx = dz W
   const uint32_t lo = WStreamT<1>::lane_off(lane, ld2), lop = WStreamT<1>::lane_off(lane, AO_C);
   WStreamT<1> ws;
   const int tr = t >> 5, tc = 8 * (t & 31);                  // row-image layout: thread = (row, 8 consecutive columns)
@@ -466,24 +466,33 @@ __global__ __launch_bounds__(512) void ln_bwd_proj_kernel(const LbParams p) {
   // normalised rows (the cross-attention's query projection), computed here instead of by a launch of its own; its
   // accumulators go through LDS into the row-image layout the LayerNorm backward below works in
   if (a.pre_a) {
-    const float* u0 = a.pre_w + 32 * wave;                   // pre_w [256][256]: d(input) = pre_a pre_w
+    // pre_w [256 pre_n][256]: d(input) = pre_a pre_w, K = 256 pre_n in blocks of 256 - the (at most three) operand blocks sit in
+    // As and the two column-sum images, which are not needed before the products are over
+    const int pre_n = a.pre_n > 0 ? a.pre_n : 1;
+    const float* u0 = a.pre_w + 32 * wave;
     ws.first(u0, AO_C, lop);
-    {
-      float tmp[8];
-      ld8(a.pre_a + (long)mc * AO_C + tc, tmp);
-      st8(As + tr * AO_PITCH + tc, tmp);
+    for (int kb = 0; kb < pre_n; ++kb) {
+      float blk[8];
+      ld8(a.pre_a + (long)mc * AO_C * pre_n + 256 * kb + tc, blk);
+      st8((kb == 0 ? As : Cs[kb - 1]) + tr * AO_PITCH + tc, blk);
     }
     __syncthreads();
     f32x4 pre[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
-    ws.run(As + nl * AO_PITCH + 4 * q4, AO_PITCH, u0, AO_C, lop, w0, ld2, lo, pre);     // the main weight follows in the stream
-    __syncthreads();                       // every wave is past its reads of As
+    for (int kb = 0; kb < pre_n; ++kb) {
+      const float* blk = (kb == 0 ? As : Cs[kb - 1]) + nl * AO_PITCH + 4 * q4;
+      const bool last = kb + 1 == pre_n;
+      // the next block's weight - or the trailing product's - follows in the stream
+      const float* wn = last ? (a.n2 > 0 ? w0 : nullptr) : u0 + (long)256 * (kb + 1) * AO_C;
+      ws.run(blk, AO_PITCH, u0 + (long)256 * kb * AO_C, AO_C, lop, wn, last ? ld2 : (long)AO_C, last ? lo : lop, pre);
+    }
+    __syncthreads();                       // every wave is past its reads of the operand blocks
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       *reinterpret_cast<float2*>(As + (4 * q4 + i) * AO_PITCH + 32 * wave + 2 * nl) = make_float2(pre[0][0][i], pre[0][1][i]);
     __syncthreads();
     ld8(As + tr * AO_PITCH + tc, d);
     // (As is rewritten below by the thread that just read the same elements)
-  } else {
+  } else if (a.n2 > 0) {
     ws.first(w0, ld2, lo);
   }
   float tmp[8];
@@ -549,6 +558,7 @@ __global__ __launch_bounds__(512) void ln_bwd_proj_kernel(const LbParams p) {
     float* dst = (t >> 8) ? a.dbeta : a.dgamma;
     if (dst) atomicAdd(dst + (t & 255), acc);
   }
+  if (a.n2 <= 0) return;                    // LayerNorm backward (behind the leading product) only
   f32x4 acc[1][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
   const float* arow = As + nl * AO_PITCH + 4 * q4;
   ws.run(arow, AO_PITCH, w0, ld2, lo, nullptr, ld2, lo, acc);
@@ -739,13 +749,15 @@ extern "C" int petr_ffn_bwd(const petr_ffn_bwd_args* ap, void* stream) {
 }
 
 extern "C" int petr_ln_bwd_proj(const petr_ln_bwd_proj_args* ap, void* stream) {
-  PETR_CHECK(ap && ap->z && ap->mean && ap->rstd && ap->gamma && ap->dz && ap->w && ap->out && ap->M > 0 && ap->n2 > 0 &&
+  PETR_CHECK(ap && ap->z && ap->mean && ap->rstd && ap->gamma && ap->dz && ap->M > 0 &&
+                 ((ap->n2 > 0 && ap->w && ap->out) || (ap->n2 == 0 && ap->pre_a)) &&
                  ((ap->dy && ap->dy_partials > 0) || (ap->pre_a && ap->pre_w && ap->dy_partials == 0)),
              PETR_ERR_INVALID, "ln_bwd_proj: bad arguments");
+  PETR_CHECK(ap->pre_n >= 0 && ap->pre_n <= 3, PETR_ERR_UNSUPPORTED, "ln_bwd_proj: pre_n=%d outside 0..3", ap->pre_n);
   PETR_CHECK(!ap->pre_a || (ap->pre_w && aligned16(ap->pre_a) && aligned16(ap->pre_w)), PETR_ERR_INVALID,
              "ln_bwd_proj: pre_a needs pre_w, both 16-byte aligned");
   const petr_ln_bwd_proj_args& a = *ap;
-  PETR_CHECK(aligned16(a.w) && aligned16(a.out) && (!a.relu_mask || aligned16(a.relu_mask)), PETR_ERR_INVALID,
+  PETR_CHECK((!a.w || aligned16(a.w)) && (!a.out || aligned16(a.out)) && (!a.relu_mask || aligned16(a.relu_mask)), PETR_ERR_INVALID,
              "ln_bwd_proj: w / out / relu_mask must be 16-byte aligned");
   PETR_CHECK(aligned16(a.z) && aligned16(a.gamma) && aligned16(a.dz) && (!a.dy || (aligned16(a.dy) && !(a.dy_partial_stride & 3))) &&
                  (!a.dy_residual || aligned16(a.dy_residual)) && (!a.dz_drop || aligned16(a.dz_drop)),
@@ -756,7 +768,7 @@ extern "C" int petr_ln_bwd_proj(const petr_ln_bwd_proj_args* ap, void* stream) {
   p.a = a;
   p.drop = make_drop(a.drop);
   if (a.alpha == 0.f) p.a.alpha = 1.f;
-  hipLaunchKernelGGL(ln_bwd_proj_kernel, dim3((unsigned)cdiv(a.M, AO_ROWS), (unsigned)a.n2), dim3(512), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(ln_bwd_proj_kernel, dim3((unsigned)cdiv(a.M, AO_ROWS), (unsigned)(a.n2 > 0 ? a.n2 : 1)), dim3(512), 0, (hipStream_t)stream, p);
   PETR_LAUNCH_CHECK("ln_bwd_proj");
   return PETR_OK;
 }

@@ -545,14 +545,14 @@ static int ln_bwd(const float* z, const float* mean, const float* rstd, const fl
 static int ln_bwd_proj(const float* z, const float* mean, const float* rstd, const float* g, const float* dy, int dy_partials,
                        long dy_pstride, const float* dy_res, float* dz, float* dz_drop, const petr_dropout* drop, float* dg,
                        float* db, long M, const float* w, int n2, float alpha, const float* relu_mask, float* out, void* s,
-                       const float* pre_a = nullptr, const float* pre_w = nullptr) {
+                       const float* pre_a = nullptr, const float* pre_w = nullptr, int pre_n = 0) {
   petr_ln_bwd_proj_args a;
   memset(&a, 0, sizeof a);
   a.z = z; a.mean = mean; a.rstd = rstd; a.gamma = g; a.dy = dy; a.dy_partials = dy_partials; a.dy_partial_stride = dy_pstride;
   a.dy_residual = dy_res; a.dz = dz; a.dz_drop = dz_drop;
   if (drop && dz_drop) a.drop = *drop;
   a.dgamma = dg; a.dbeta = db; a.M = (int)M; a.w = w; a.n2 = n2; a.alpha = alpha; a.relu_mask = relu_mask; a.out = out;
-  a.pre_a = pre_a; a.pre_w = pre_w;
+  a.pre_a = pre_a; a.pre_w = pre_w; a.pre_n = pre_n;
   return petr_ln_bwd_proj(&a, s);
 }
 
@@ -1458,11 +1458,21 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       static const int fuse_lvl = getenv("PETR_FUSE_LN_BWD") ? atoi(getenv("PETR_FUSE_LN_BWD")) : 3;
       const bool ffn_bwd_fused = fuse_bwd && fuse_lvl >= 3 && W.ffn_fsplit > 0 && !ffn16;   // bf16 mode: level 2 measured level with it
       const bool fuse_ffn2 = fuse_lvl >= 2;
+      static const bool fuse_in_env = env_on("PETR_FUSE_IN_DGRAD");
+      const bool fuse_in = ffn_bwd_fused && fuse_in_env && C == 256;       // see the end of the stage: must match layer l+1's choice
       float* d_x2 = Wm + lg.d_x2;
       const int sk = ffn_bwd_fused ? W.ffn_fsplit : W.ffn_split;
       if (ffn_bwd_fused) {
+        if (fuse_in && l + 1 < d.NL) {
+          // the input gradient of layer l+1's self-attention in-projection (K = 3C) is formed here, in front of the LayerNorm
+          // backward that consumes it: d(x3_l) = d_qkv(l+1) W_in(l+1) + d_z0(l+1) (identity) + the branches' gradient
+          RUN(ln_bwd_proj(Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, Pm + lp.n_g[2], Wm + W.lg[l + 1].d_z0, 1, 0, G, d_z2,
+                          training ? d_f2 : nullptr, training ? &dr[5] : nullptr, Gp + lp.n_g[2], Gp + lp.n_b[2], d.BQ, nullptr, 0, 1.f,
+                          nullptr, nullptr, s, Wm + W.d_qkv + (long)(l + 1) * d.BQ * 3 * C, Pm + P.lay[l + 1].sa_in_w, 3));
+        } else {
         RUN(ln_bwd(Wm + lw.z2, Wm + lw.mean2, Wm + lw.rstd2, Pm + lp.n_g[2], G, nullptr, d_z2, Gp + lp.n_g[2], Gp + lp.n_b[2],
                    d.BQ, C, 0, 0, s, 1, 0, nullptr, training ? d_f2 : nullptr, &dr[5]));
+        }
         RUN(wgrad(lin_wgrad(d_f2, C, Wm + lw.hff, d.F, Gp + lp.f2_w, Gp + lp.f2_b, d.BQ, C, d.F)));
         petr_ffn_bwd_args fb;
         memset(&fb, 0, sizeof fb);
@@ -1606,7 +1616,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       }
       RUN(wgrad(lin_wgrad(d_qkv + 2 * C, 3 * C, x_in, C, Gp + lp.sa_in_w + (long)2 * C * C, Gp + lp.sa_in_b + 2 * C, d.BQ, C,
                           C)));
-      if (l > 0) {
+      if (l > 0 && !fuse_in) {       // (fuse_in: layer l-1's first kernel forms it)
         // d(x_in) = d_z0 (identity) + d_qkv @ W_in, added to the post-norm gradient of level l-1
         float* dst = Wm + W.d_xs + (long)(l - 1) * d.BQ * C;
         g = dgrad_t ? lin_dgrad_t(d_qkv, Wm + wt.sa_in, dst, d.BQ, 3 * C, C) : lin_dgrad(d_qkv, Pm + lp.sa_in_w, dst, d.BQ, 3 * C, C);

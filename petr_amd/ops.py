@@ -175,17 +175,18 @@ def ln_bwd_proj(z, mean, rstd, gamma, dy, w, dy_residual=None, drop=None, alpha=
         P, M, Cc = dy.shape
     else:
         P, (M, Cc) = 1, dy.shape
-    w = w.contiguous()                   # dx = dz W: the nn.Linear weight is already k-major for this product
+    w = w.contiguous() if w is not None else None       # dx = dz W: the nn.Linear weight is already k-major for this product
     pre_w = pre_w.contiguous() if pre_w is not None else None
-    n2 = w.shape[1] // 256
+    n2 = w.shape[1] // 256 if w is not None else 0      # w None: LayerNorm backward behind the leading product only
+    pre_n = pre_a.shape[1] // 256 if pre_a is not None else 0
     dz = torch.empty((M, Cc), device=z.device)
     dzd = torch.empty_like(dz) if drop is not None else None
     dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
-    out = torch.empty((M, 256 * n2), device=z.device)
+    out = torch.empty((M, 256 * n2), device=z.device) if n2 else None
     dyc = _f32(dy).contiguous() if dy is not None else None
     a = _C.LnBwdProjArgs(_ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dyc), P, M * Cc, _ptr(dy_residual),
                          _ptr(dz), _ptr(dzd), _C.dropout(drop), _ptr(dg), _ptr(db), M, _ptr(w), n2, float(alpha), _ptr(relu_mask),
-                         _ptr(out), _ptr(pre_a), _ptr(pre_w))
+                         _ptr(out), _ptr(pre_a), _ptr(pre_w), pre_n)
     _C.check(L.petr_ln_bwd_proj(C.byref(a), _stream()), 'petr_ln_bwd_proj')
     return dz, dzd, dg, db, out
 

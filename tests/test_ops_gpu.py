@@ -849,6 +849,28 @@ def test_ffn_fwd_equals_the_two_contractions(ops, M, F, n_split, training):
     assert torch.equal(part, part2)
 
 
+@pytest.mark.parametrize('M,training', [(900, True), (37, False)])
+def test_ln_bwd_proj_leading_in_projection_gradient_only(ops, M, training):
+    """petr_ln_bwd_proj with a K = 768 leading product and no trailing one: the upstream gradient of the LayerNorm backward is
+    d_qkv W_in (a self-attention in-projection's input gradient) + one dy slab (the identity path) + dy_residual."""
+    g = torch.Generator().manual_seed(M)
+    C = 256
+    x = dev(torch.randn(M, C, generator=g))
+    gamma, beta = dev(torch.rand(C, generator=g) + 0.5), dev(torch.randn(C, generator=g))
+    _, z, mean, rstd = ops.layernorm(x, gamma, beta, save_stats=True)
+    d_qkv = dev(torch.randn(M, 3 * C, generator=g))
+    w_in = dev(torch.randn(3 * C, C, generator=g) * 0.06)
+    d_id, d_br = dev(torch.randn(M, C, generator=g)), dev(torch.randn(M, C, generator=g))
+    drop = (3, 4, 0.1) if training else None
+    dy_sum = (d_qkv.double() @ w_in.double() + d_id.double() + d_br.double()).float()
+    ref = ops.layernorm_bwd(z, mean, rstd, gamma, dy_sum, drop=drop)
+    dz, dzd, dg, db, out = ops.ln_bwd_proj(z, mean, rstd, gamma, d_id, None, dy_residual=d_br, drop=drop, pre_a=d_qkv, pre_w=w_in)
+    assert out is None
+    assert relerr(dz, ref[0]) < 1e-5 and relerr(dg, ref[1]) < 1e-5 and relerr(db, ref[2]) < 1e-5
+    if training:
+        assert relerr(dzd, ref[3]) < 1e-5
+
+
 @pytest.mark.parametrize('M,F,n_split,alpha', [(900, 2048, 8, 1.0 / (1 - 6554 / 65536)), (1800, 2048, 4, 1.0), (37, 512, 2, 1.25)])
 def test_ffn_bwd_equals_the_two_input_gradients(ops, M, F, n_split, alpha):
     """petr_ffn_bwd against float64: d_hidden = alpha (dy W2) where the forward's hidden is positive, slabs = d_hidden W1 per slice."""

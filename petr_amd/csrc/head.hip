@@ -1456,7 +1456,8 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // PETR_FUSE_LN_BWD: 3 (default) both FFN input gradients in one launch (petr_ffn_bwd: d_h stays on chip between them);
       // 2: LayerNorm backward + the FFN2 input gradient with its ReLU mask in petr_ln_bwd_proj (8 column blocks); 1: separate
       static const int fuse_lvl = getenv("PETR_FUSE_LN_BWD") ? atoi(getenv("PETR_FUSE_LN_BWD")) : 3;
-      const bool ffn_bwd_fused = fuse_bwd && fuse_lvl >= 3 && W.ffn_fsplit > 0 && !ffn16;   // bf16 mode: level 2 measured level with it
+      static const bool ffn_bwd16_env = env_on("PETR_FFN_BWD_FUSED_BF16");
+      const bool ffn_bwd_fused = fuse_bwd && fuse_lvl >= 3 && W.ffn_fsplit > 0 && (!ffn16 || ffn_bwd16_env);
       const bool fuse_ffn2 = fuse_lvl >= 2;
       static const bool fuse_in_env = env_on("PETR_FUSE_IN_DGRAD");
       const bool fuse_in = ffn_bwd_fused && fuse_in_env && C == 256;       // see the end of the stage: must match layer l+1's choice

@@ -861,7 +861,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   uint16_t* mem16 = reinterpret_cast<uint16_t*>(Wm + W.mem);          // tok16: bf16 images in the front half of the
   uint16_t* mempos16 = reinterpret_cast<uint16_t*>(Wm + W.mempos);    // fp32 buffers, same element indexing
   if (tok16) RUN(petr_cast_bf16(Pm, p16, P.total, s));
-  static const bool ffn16_env = env_on("PETR_FFN16");
+  static const bool ffn16_env = getenv("PETR_FFN16") && atoi(getenv("PETR_FFN16")) != 0;   // opt-in: the fused fp32 FFN kernels measured faster
   const bool ffn16 = tok16 && ffn16_env;
   // bf16 mode: the 1x1 convolutions over NCHW maps take the K-major variant of the bf16 contraction where it applies
   auto bf16_km = [&](const petr_gemm_args& q) {
@@ -1113,8 +1113,9 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
                training ? &dr_co : nullptr));
     }
     // FFN (mmcv FFN): x + W2 relu(W1 x + b1) + b2 ; second contraction split over K
-    // bf16 mode: both FFN contractions on the bf16 matrix cores with the bf16 weight copy, as autocast runs them
-    // (900 x 2048 x 256 alone: 21.8 -> 11.8 us; PETR_FFN16=0: fp32)
+    // one launch for both contractions (petr_ffn_fwd, fp32).  PETR_FFN16=1 (bf16 mode only): two contractions on the bf16 matrix
+    // cores with the bf16 weight copy instead, as autocast runs them (11.8 us each alone, but the pair, its launch gap and the
+    // bf16 input gradients measured 1.4-1.7 % of a step slower than the fused fp32 kernels)
     float* xs_l = Wm + W.xs + (long)l * d.BQ * C;
     const int n_slabs = ffn_fused ? W.ffn_fsplit : W.ffn_split;
     const bool slabs = ffn_fused || !(W.ffn_split == 1 && !training);   // false: the second contraction wrote z2 itself
@@ -1283,7 +1284,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   const uint16_t* p16 = reinterpret_cast<const uint16_t*>(Wm + W.p16);        // made by the forward (same parameters)
   auto Wp = [&](long off) -> const float* { return tok16 ? reinterpret_cast<const float*>(p16 + off) : Pm + off; };
   const int wflag = tok16 ? PETR_GEMM_B_BF16 : 0;
-  static const bool ffn16_env = env_on("PETR_FFN16");
+  static const bool ffn16_env = getenv("PETR_FFN16") && atoi(getenv("PETR_FFN16")) != 0;   // opt-in: the fused fp32 FFN kernels measured faster
   const bool ffn16 = tok16 && ffn16_env;
   static const bool drop_bits_env = env_on("PETR_DROP_BITS");          // the forward generated them (same workspace)
   const bool use_bits = io->dropout_p > 0.f && drop_bits_env;

@@ -10,6 +10,8 @@ timeout -k 10 400 python3 bench.py > gpurun_out/final_bench_c5.json 2> gpurun_ou
 cp $(find /tmp/final_stats -name '*kernel_stats.csv' | head -1) gpurun_out/final_kernel_stats.csv
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d /tmp/final_stats16 -o p --output-format csv -- python3 $R/bench.py --workload p4_1600 --dtype bf16 --steps 20 --warmup 5 --timed-only > /tmp/final_stats16.log 2>&1) || exit 4
 cp $(find /tmp/final_stats16 -name '*kernel_stats.csv' | head -1) gpurun_out/final_kernel_stats_p4_1600_bf16.csv
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d /tmp/final_stats32 -o p --output-format csv -- python3 $R/bench.py --workload c5 --steps 40 --warmup 10 --timed-only > /tmp/final_stats32.log 2>&1) || exit 5
+cp $(find /tmp/final_stats32 -name '*kernel_stats.csv' | head -1) gpurun_out/final_kernel_stats_c5_timed_only.csv
 python3 -c "
 import json
 d=json.load(open('gpurun_out/final_bench_c5.json'))

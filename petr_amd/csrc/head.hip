@@ -1543,7 +1543,8 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // v2-800 bf16 5.78 -> 5.86, p4-1600 bf16 6.04 -> 6.06, c5 fp32 4.94 -> 5.01: the second fork per layer costs more than
       // the overlap it removes, so the stage keeps its single flush at the end.
       static const bool midflush = getenv("PETR_WGRAD_MIDFLUSH") && atoi(getenv("PETR_WGRAD_MIDFLUSH")) != 0;
-      if (defer && midflush) RUN(flush_wgrads());
+      static const bool flush_b = getenv("PETR_WGRAD_FLUSH_EARLY") && atoi(getenv("PETR_WGRAD_FLUSH_EARLY")) == 2;
+      if (defer && (midflush || flush_b)) RUN(flush_wgrads());
       // K / V projection backward of THIS layer (token-sized: the largest contractions of the backward) leaves the
       // critical path: dW_l and d_src (+)= dKV_l W_l go to the side streams right behind the attention backward that
       // produced dK_l / dV_l and run beside the 900-row chain of the remaining layers; the final stage only joins.
@@ -1603,6 +1604,12 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       g = dgrad_t ? lin_dgrad_t(d_f0, Wm + wt.sa_out, d_ao_s, d.BQ, C, C) : lin_dgrad(d_f0, Pm + lp.sa_out_w, d_ao_s, d.BQ, C, C);
       RUN(petr_gemm(&g, s));
       }
+      // The stage's weight gradients start HERE (one fork per stage): beside the self-attention backward (256 workgroups) and
+      // the next stage's first 57-workgroup kernel, where three quarters of the chip idle - not beside the next FFN backward,
+      // which fills it (PETR_WGRAD_FLUSH_EARLY=0: at the end of the stage).  The in-projection's weight gradients queued below
+      // leave with the next stage's fork, or at the end of the call.
+      static const int flush_early = getenv("PETR_WGRAD_FLUSH_EARLY") ? atoi(getenv("PETR_WGRAD_FLUSH_EARLY")) : 1;
+      if (defer && flush_early == 1) RUN(flush_wgrads());
       float* d_qkv = Wm + W.d_qkv + (long)l * d.BQ * 3 * C;
       RUN(mha_b(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
                 Wm + lw.ao_s, d_ao_s, Wm + lw.lse_s, nullptr, d_qkv, d_qkv + C, d_qkv + 2 * C, d, d.Q, mws, W.mha_ws_bytes, s,
@@ -1744,7 +1751,11 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         RUN(petr_axpy(Gp + P.ref, Wm + W.d_ref_tmp, 1.f, (long)d.Q * 3, s));
       }
     }
-    RUN(flush_wgrads());     // the stage's queued weight gradients: one fork, alternating side streams
+    // the stage's queued weight gradients: one fork, alternating side streams (a decoder-layer stage that forked early keeps
+    // its last few for the next stage's fork unless the call ends here)
+    static const bool flush_early_ = env_on("PETR_WGRAD_FLUSH_EARLY");
+    const bool layer_stage = stage >= 1 && stage <= d.NL;
+    if (!(defer && flush_early_ && layer_stage && stage + 1 < stage_end && stage + 1 <= d.NL)) RUN(flush_wgrads());
   }
   // The caller's stream is made to wait for the side streams only when the LAST stage has been enqueued.  After an
   // earlier stage range the weight gradients of those stages may still be running on the side streams: whoever

@@ -1364,6 +1364,9 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       for (int i = 0; i < 6; ++i) a.pc_range[i] = cfg->pc_range[i];
       a.time_div = cfg->with_time ? io->time_div : 0.f; a.eps = 1e-5f;
       float* d_raw = Wm + W.s0_raw;   // [R, code]
+      // the cls branch below runs on side stream 0 BESIDE the reg branch: its fork is recorded here, in front of the reg
+      // branch's kernels (recorded behind them it made the cls branch wait for the whole reg branch: 65 us of the c5 step)
+      ln.fork(0);
       RUN(petr_bbox_epilogue_bwd(&a, gr->d_bbox, d_raw, Wm + W.d_ref_tmp, s));
       float* d_r2 = Wm + W.s0_r2;
       petr_gemm_args g;
@@ -1407,8 +1410,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       RUN(petr_gemm(&g, s));
       // ---- cls branch: independent of the reg branch until the post-norm, so it runs beside it on side stream 0 and
       // leaves its input gradient in a buffer of its own (summed by the post-norm backward's prologue) ----
-      void* sc = ln.side(0);
-      ln.fork(0);
+      void* sc = ln.side(0);          // (forked before the reg branch was enqueued, see above)
       RUN(wgrad(gw(lin_wgrad(gr->d_cls, d.ncls, Wm + W.c2n, C, Gp + P.cls_w[2], Gp + P.cls_b[2], RG, d.ncls, C), d.ncls, C)));
       float* d_c2n = Wm + W.s0_c2n;
       g = gd(lin_dgrad(gr->d_cls, Pm + P.cls_w[2], d_c2n, RG, d.ncls, C), d.ncls, C, C);
@@ -1636,6 +1638,43 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
     } else {
       // ================= final stage =================
       const int V = d.B * d.N;
+      // query_pos gradient: sum over layers and batch of the d(q-proj inputs) slabs the layer stages produced on the side
+      // streams, then the query_embedding MLP + pos2posemb3d backward.  It depends on the LAYER stages only, so it runs early in
+      // this stage (behind the K / V input gradients, by when the layer stages' last weight gradients have drained): ordered
+      // behind the side streams as they stand NOW - joined at the end of the stage it waited for this stage's token-sized
+      // weight gradients as well and then ran alone, 100 us of the c5 step (PETR_QE_EARLY=0: that order).
+      static const bool qe_early = env_on("PETR_QE_EARLY");
+      hipEvent_t ev_q[2] = {nullptr, nullptr};
+      if (qe_early) {
+        RUN(flush_wgrads());
+        if (ln.ctx)
+          for (int i = 0; i < 2 && i < ln.ctx->n_side; ++i) {
+            ev_q[i] = ln.next();
+            (void)hipEventRecord(ev_q[i], ln.ctx->side[i]);
+          }
+      }
+      auto query_embedding_bwd = [&](bool early) -> int {
+        petr_gemm_args g;
+        if (early) {
+          for (int i = 0; i < 2; ++i)
+            if (ev_q[i]) (void)hipStreamWaitEvent(ln.main, ev_q[i], 0);
+        } else {
+          ln.join(0);
+          ln.join(1);
+        }
+        RUN(petr_reduce_batch(Wm + W.d_e_slab, 2 * d.NL * d.B, d.Q, C, Wm + W.d_e, 0, s));
+        // query_embedding MLP + pos2posemb3d (petr_head.py:422-423)
+        RUN(wgrad(lin_wgrad(Wm + W.d_e, C, Wm + W.qe_h, C, Gp + P.qe_w2, Gp + P.qe_b2, d.Q, C, C)));
+        g = lin_dgrad(Wm + W.d_e, Pm + P.qe_w2, Wm + W.d_qe_h, d.Q, C, C);
+        g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.qe_h; g.ldr = C;
+        RUN(petr_gemm(&g, s));
+        RUN(wgrad(lin_wgrad(Wm + W.d_qe_h, C, Wm + W.posemb, C * 3 / 2, Gp + P.qe_w1, Gp + P.qe_b1, d.Q, C, C * 3 / 2)));
+        g = lin_dgrad(Wm + W.d_qe_h, Pm + P.qe_w1, Wm + W.d_posemb, d.Q, C, C * 3 / 2);
+        RUN(petr_gemm(&g, s));
+        RUN(petr_posemb3d_bwd(Pm + P.ref, io->dim_t, Wm + W.d_posemb, Wm + W.d_ref_tmp, d.Q, C / 2, s));
+        RUN(petr_axpy(Gp + P.ref, Wm + W.d_ref_tmp, 1.f, (long)d.Q * 3, s));
+        return PETR_OK;
+      };
       // (opt-in schedule) the K/V projection backward of every layer ran on the side streams behind its layer: wait for it
       if (kv_overlap) {
         ln.join(0);
@@ -1664,6 +1703,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g = L16(g);
         RUN(petr_gemm(&g, s));
       }
+      if (qe_early) RUN(query_embedding_bwd(true));
       // d_mem = dV-path + d(mem+pos) ; d_pos = d(mem+pos)
       RUN(petr_axpy(Wm + W.d_mem, Wm + W.d_mempos, 1.f, d.BL * C, s));
       const float* d_pos = Wm + W.d_mempos;
@@ -1732,24 +1772,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
           RUN(petr_gemm(&g, s));
         }
       }
-      // query_pos gradient: sum over layers and batch of the d(q-proj inputs) slabs the layer stages produced on the
-      // side streams
-      {
-        petr_gemm_args g;
-        ln.join(0);
-        ln.join(1);
-        RUN(petr_reduce_batch(Wm + W.d_e_slab, 2 * d.NL * d.B, d.Q, C, Wm + W.d_e, 0, s));
-        // query_embedding MLP + pos2posemb3d (petr_head.py:422-423)
-        RUN(wgrad(lin_wgrad(Wm + W.d_e, C, Wm + W.qe_h, C, Gp + P.qe_w2, Gp + P.qe_b2, d.Q, C, C)));
-        g = lin_dgrad(Wm + W.d_e, Pm + P.qe_w2, Wm + W.d_qe_h, d.Q, C, C);
-        g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.qe_h; g.ldr = C;
-        RUN(petr_gemm(&g, s));
-        RUN(wgrad(lin_wgrad(Wm + W.d_qe_h, C, Wm + W.posemb, C * 3 / 2, Gp + P.qe_w1, Gp + P.qe_b1, d.Q, C, C * 3 / 2)));
-        g = lin_dgrad(Wm + W.d_qe_h, Pm + P.qe_w1, Wm + W.d_posemb, d.Q, C, C * 3 / 2);
-        RUN(petr_gemm(&g, s));
-        RUN(petr_posemb3d_bwd(Pm + P.ref, io->dim_t, Wm + W.d_posemb, Wm + W.d_ref_tmp, d.Q, C / 2, s));
-        RUN(petr_axpy(Gp + P.ref, Wm + W.d_ref_tmp, 1.f, (long)d.Q * 3, s));
-      }
+      if (!qe_early) RUN(query_embedding_bwd(false));
     }
     // the stage's queued weight gradients: one fork, alternating side streams (a decoder-layer stage that forked early keeps
     // its last few for the next stage's fork unless the call ends here)

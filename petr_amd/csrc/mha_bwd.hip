@@ -320,7 +320,7 @@ extern "C" int petr_mha_bwd(const petr_mha_bwd_args* ap, void* stream) {
   const petr_mha_bwd_args& a = p.a;
   p.nkb = (int)cdiv(a.L, 128);
   p.q_splits = choose_q_splits(a.B, a.H, a.Q, a.L);
-  if (const char* e = getenv("PETR_MHA_BWD_QSPLITS")) {   // tuning override
+  if (const char* e = getenv(a.L <= a.Q ? "PETR_MHA_BWD_QSPLITS_SELF" : "PETR_MHA_BWD_QSPLITS")) {   // tuning overrides
     const int v = atoi(e);
     if (v >= 1 && v <= (int)cdiv(a.Q, 32)) p.q_splits = v;
   }

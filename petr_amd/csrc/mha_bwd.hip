@@ -296,7 +296,10 @@ int choose_q_splits(int B, int H, int Q, int L) {
   for (int s = 1; s <= qtiles && s <= 16; ++s) {
     const int per = (int)cdiv(qtiles, s);
     if ((long)(s - 1) * per >= qtiles) continue;
-    const double cost = (double)cdiv(base * s, 256) * per + 1.0 * s;
+    // rounds of 256 workgroups x (query tiles per workgroup + its epilogue: with s > 1 every workgroup ends with 32 KB of dK / dV
+    // float atomics, ~2.5 tiles' worth).  Fits the same-box step times at c5 (s = 3 < 5 < 7 < 4 < 2 < 1) and for the
+    // self-attention (4 < 5 ~ 6 ~ 8 < 3 < 10 < 2); the earlier `rounds * per + s` picked 5 at c5.
+    const double cost = (double)cdiv(base * s, 256) * (per + (s > 1 ? 2.5 : 1.0));
     if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
   }
   return best;

@@ -279,11 +279,72 @@ __global__ __launch_bounds__(256) void sine3d_rows_kernel(Sine3dParams p) {
   }
 }
 
+// The same tables written PLANE-wise: one workgroup per (pair k, view) evaluates sin / cos of the W column, the H row and the
+// one view argument of its pair - one sincosf per thread - and streams its six channel planes [H][W] out as 16-byte stores
+// (a plane of the NCHW output is contiguous; sine3d_rows_kernel writes a W-float segment per channel and row: 48 us for the
+// 37 MB of the 6 x 40 x 100 shape).  Needs W % 4 == 0 and W + H + 1 <= 256; same expressions on the same arguments, same bits.
+__global__ __launch_bounds__(256) void sine3d_planes_kernel(Sine3dParams p) {
+  __shared__ __attribute__((aligned(16))) float xs[256], xc[256];
+  __shared__ float ys[256], yc[256], nsc[2];
+  const int half = p.F >> 1;
+  const int k = blockIdx.x, bn = blockIdx.y;
+  const int n = bn % p.N;
+  const int t = threadIdx.x;
+  auto emb = [&](int cum, int tot) {
+    float e = (float)cum;
+    if (p.normalize) e = (e + p.offset) / ((float)tot + p.eps) * p.scale;
+    return e;
+  };
+  {
+    float e = 0.f;
+    float *sn = nullptr, *cs = nullptr;
+    if (t < p.W) { e = emb(t + 1, p.W); sn = xs + t; cs = xc + t; }
+    else if (t < p.W + p.H) { e = emb(t - p.W + 1, p.H); sn = ys + (t - p.W); cs = yc + (t - p.W); }
+    else if (t == p.W + p.H) { e = emb(n + 1, p.N); sn = nsc; cs = nsc + 1; }
+    if (sn) {
+      const float d0 = p.dim_t[2 * k], d1 = p.dim_t[2 * k + 1];
+      if (d0 == d1) {
+        sincosf(e / d0, sn, cs);
+      } else {
+        *sn = sinf(e / d0);
+        *cs = cosf(e / d1);
+      }
+    }
+  }
+  __syncthreads();
+  const int HW = p.H * p.W, n4 = HW >> 2;
+  float* ob = p.out + (size_t)bn * 3 * p.F * HW;
+  // channel (axis, sc, k) = axis * F + sc * half + k (see sine3d_kernel)
+  float4* pl[6];
+#pragma unroll
+  for (int as = 0; as < 6; ++as) pl[as] = reinterpret_cast<float4*>(ob + (size_t)((as >> 1) * p.F + (as & 1) * half + k) * HW);
+  const float4 cn0 = make_float4(nsc[0], nsc[0], nsc[0], nsc[0]), cn1 = make_float4(nsc[1], nsc[1], nsc[1], nsc[1]);
+  const int dh = 1024 / p.W, dw = 1024 - dh * p.W;         // one step of the loop advances 1024 pixels
+  int h = (4 * t) / p.W, w = 4 * t - h * p.W;
+  for (int i4 = t; i4 < n4; i4 += 256) {
+    const float y0 = ys[h], y1 = yc[h];
+    pl[0][i4] = cn0;
+    pl[1][i4] = cn1;
+    pl[2][i4] = make_float4(y0, y0, y0, y0);
+    pl[3][i4] = make_float4(y1, y1, y1, y1);
+    pl[4][i4] = *reinterpret_cast<const float4*>(xs + w);
+    pl[5][i4] = *reinterpret_cast<const float4*>(xc + w);
+    h += dh; w += dw;
+    if (w >= p.W) { w -= p.W; ++h; }
+  }
+}
+
 extern "C" int petr_sine3d_fwd(const petr_sine3d_args* a, void* stream) {
   PETR_CHECK(a && a->dim_t && a->out, PETR_ERR_INVALID, "sine3d: null pointer");
   PETR_CHECK(a->F > 0 && (a->F & 1) == 0, PETR_ERR_INVALID, "sine3d: num_feats must be even");
   Sine3dParams p{a->mask, a->dim_t, a->out, a->B, a->N, a->H, a->W, a->F, a->normalize, a->scale, a->eps, a->offset};
   const size_t rows_lds = ((size_t)a->F * (a->W + 1) + 2 * (size_t)a->F) * sizeof(float);
+  static const bool planes_on = !(getenv("PETR_SINE3D_PLANES") && atoi(getenv("PETR_SINE3D_PLANES")) == 0);
+  if (!a->mask && planes_on && a->W % 4 == 0 && a->W + a->H + 1 <= 256 && aligned16(a->out)) {
+    hipLaunchKernelGGL(sine3d_planes_kernel, dim3(a->F / 2, a->B * a->N), dim3(256), 0, (hipStream_t)stream, p);
+    PETR_LAUNCH_CHECK("sine3d_planes");
+    return PETR_OK;
+  }
   if (!a->mask && rows_lds <= 64 * 1024) {        // no padding anywhere: the per-row kernel
     hipLaunchKernelGGL(sine3d_rows_kernel, dim3(a->H, a->B * a->N, 4), dim3(256), rows_lds, (hipStream_t)stream, p);
     PETR_LAUNCH_CHECK("sine3d_rows");

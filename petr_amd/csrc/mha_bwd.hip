@@ -300,7 +300,7 @@ int choose_q_splits(int B, int H, int Q, int L) {
     // float atomics, ~2.5 tiles' worth).  Fits the same-box step times at c5 (s = 3 < 5 < 7 < 4 < 2 < 1) and for the
     // self-attention (4 < 5 ~ 6 ~ 8 < 3 < 10 < 2); the earlier `rounds * per + s` picked 5 at c5.
     const double cost = (double)cdiv(base * s, 256) * (per + (s > 1 ? 2.5 : 1.0));
-    if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    if (cost <= best_cost + 1e-9) { best_cost = cost; best = s; }     // ties: the finer split (batch 2 at c5: 3 beats 2 by 1.4 %)
   }
   return best;
 }

@@ -23,6 +23,9 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <array>
+#include <map>
+#include <mutex>
 
 namespace {
 
@@ -31,7 +34,9 @@ constexpr int P33 = 33;
 
 struct MhaBwdParams {
   petr_mha_bwd_args a;
-  int nkb, q_splits, qtiles_per_split;
+  int nkb, q_splits;
+  int qt_cut[17];      // query-tile range of split s: [qt_cut[s], qt_cut[s+1]) - the splits may be UNEVEN (plan_q_splits)
+  int ordered;         // workgroup order inside an XCD: split-major (all first splits, then all second ...), see the kernel
   int vec;             // q/do/k/v 16-byte loads legal
   DropDev drop;        // the forward's probability dropout (thr == 0: off)
   const uint32_t* drop_bits;   // key-major packed mask (petr_dropout_bits) or null: re-hash
@@ -53,9 +58,20 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
 
   const petr_mha_bwd_args& a = p.a;
   const int total = p.nkb * a.B * a.H * p.q_splits;
-  const int w = xcd_remap(blockIdx.x, total);
-  const int qs = w % p.q_splits;
-  const int rest = w / p.q_splits;
+  int qs, rest;
+  if (p.ordered) {
+    // workgroup ids are dealt round-robin to the 8 XCDs and dispatched in order inside each: XCD x takes the (key block, head)
+    // pairs [x R/8, (x+1) R/8) and runs ALL their first (largest) splits before any second one - longest-first list
+    // scheduling of the uneven splits over the XCD's workgroup slots (R = pairs, a multiple of 8)
+    const int rx = (total / p.q_splits) >> 3;
+    const int x = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    qs = sq / rx;
+    rest = x * rx + (sq - qs * rx);
+  } else {
+    const int w = xcd_remap(blockIdx.x, total);
+    qs = w % p.q_splits;
+    rest = w / p.q_splits;
+  }
   const int kb = rest % p.nkb;
   const int bh = rest / p.nkb;
   const int b = bh / a.H, hd = bh - b * a.H;
@@ -104,8 +120,8 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
   for (int r = 0; r < 16; ++r) dKt[r] = dVt[r] = 0.f;
 
   const int qtiles = (a.Q + 31) / 32;
-  const int qt_begin = qs * p.qtiles_per_split;
-  const int qt_end = min(qtiles, qt_begin + p.qtiles_per_split);
+  const int qt_begin = p.qt_cut[qs];
+  const int qt_end = min(qtiles, p.qt_cut[qs + 1]);
   const float inv_scale = 1.f / a.scale;
   const float sc2 = a.scale * LOG2E;
 
@@ -305,6 +321,96 @@ int choose_q_splits(int B, int H, int Q, int L) {
   return best;
 }
 
+// Uneven query splits for long key ranges.  With R (key block, head) pairs and S even splits the R S equal workgroups fill
+// the chip's workgroup slots (2 per CU) in ceil(R S / 512) rounds, the last one mostly empty (c5: 264 pairs x 3 = 792 = 1.55
+// rounds, paid as 2).  Splits of DIFFERENT sizes, dispatched largest first, pack the slots like longest-first list scheduling:
+// c5 (19, 8, 2) tiles instead of (10, 10, 9) -> 21.5 instead of 25 tile-times per slot in the model below, p4-1408 (23, 6)
+// instead of one split -> 76.5 instead of 90.  Model: per XCD (R / 8 pairs, 64 slots) every workgroup costs its query tiles +
+// 2.5 (split: dK / dV atomic epilogue) or + 1.0 (unsplit); searched over all non-increasing compositions into <= 4 parts and
+// the even splits up to 16, memoised per shape.  Short key ranges (the self-attention) keep choose_q_splits' even split: their
+// workgroups are latency-bound in ways this model does not carry (it would take 8 splits where 4 measures best).
+struct QPlan { int n; int cut[17]; };
+static double simulate_slots(int rx, const int* sizes, int n, int slots) {
+  // greedy list scheduling of n groups of rx equal workgroups, in order, onto `slots` machines
+  double t[64];
+  for (int i = 0; i < slots; ++i) t[i] = 0.0;
+  const double e = n > 1 ? 2.5 : 1.0;
+  for (int g = 0; g < n; ++g)
+    for (int r = 0; r < rx; ++r) {
+      int m = 0;
+      for (int i = 1; i < slots; ++i)
+        if (t[i] < t[m]) m = i;
+      t[m] += sizes[g] + e;
+    }
+  double mx = 0.0;
+  for (int i = 0; i < slots; ++i) mx = t[i] > mx ? t[i] : mx;
+  return mx;
+}
+static void search_parts(int rx, int left, int k, int mx, int* cur, int depth, double* best, QPlan* plan) {
+  if (k == 1) {
+    if (left > mx || left < 1) return;
+    cur[depth] = left;
+    const double c = simulate_slots(rx, cur, depth + 1, 64);
+    if (c < *best - 1e-9) {
+      *best = c;
+      plan->n = depth + 1;
+      plan->cut[0] = 0;
+      for (int i = 0; i <= depth; ++i) plan->cut[i + 1] = plan->cut[i] + cur[i];
+    }
+    return;
+  }
+  for (int a = left - (k - 1) < mx ? left - (k - 1) : mx; a >= 1; --a) {
+    cur[depth] = a;
+    search_parts(rx, left - a, k - 1, a, cur, depth + 1, best, plan);
+  }
+}
+static QPlan plan_q_splits(int B, int H, int Q, int L) {
+  static std::mutex mu;
+  static std::map<std::array<int, 4>, QPlan> memo;
+  std::lock_guard<std::mutex> lock(mu);
+  const std::array<int, 4> key = {B, H, Q, L};
+  auto it = memo.find(key);
+  if (it != memo.end()) return it->second;
+  const int qtiles = (int)cdiv(Q, 32);
+  const long R = cdiv(L, 128) * (long)B * H;
+  QPlan plan;
+  auto even = [&](int sp) {
+    plan.n = sp;
+    const int per = (int)cdiv(qtiles, sp);
+    for (int i = 0; i <= sp; ++i) plan.cut[i] = i * per < qtiles ? i * per : qtiles;
+  };
+  // Where the model is trusted (standalone kernel times, scripts/bwd32_plan_sweep.sh): the big splits fit ONE round of slots
+  // (c5: 33 pairs per XCD, (19, 8, 2) 161 us against 169 even) or the unsplit schedule leaves a nearly empty last round
+  // (p4-1408: 132 = 2.06 rounds, (23, 6) 502 us against 582).  In between (v2-800: 94 = 1.47 rounds) every plan measured
+  // within +-4 % of unsplit - the chip-wide float-atomic rate, which the slot model does not carry, eats the packing gain -
+  // and the even heuristic stays.
+  const double rounds = (double)(R / 8) / 64.0;
+  const bool trusted = rounds <= 1.0 || (rounds - (long)rounds > 0.0 && rounds - (long)rounds < 0.15);
+  if (L <= 2048 || (R & 7) || R / 8 > 4096 || !trusted) {
+    even(choose_q_splits(B, H, Q, L));
+  } else {
+    const int rx = (int)(R / 8);
+    double best = 1e30;
+    int cur[16];
+    for (int k = 1; k <= 4 && k <= qtiles; ++k) search_parts(rx, qtiles, k, qtiles, cur, 0, &best, &plan);
+    for (int sp = 5; sp <= 16 && sp <= qtiles; ++sp) {
+      const int per = (int)cdiv(qtiles, sp);
+      if ((long)(sp - 1) * per >= qtiles) continue;
+      int sizes[16];
+      for (int i = 0; i < sp; ++i) sizes[i] = (i + 1) * per <= qtiles ? per : qtiles - i * per;
+      const double c = simulate_slots(rx, sizes, sp, 64);
+      if (c < best - 1e-9) { best = c; even(sp); }
+    }
+  }
+  memo[key] = plan;
+  if (getenv("PETR_MHA_BWD_PLAN_PRINT")) {            // diagnostics: the plan of every new shape, once
+    fprintf(stderr, "mha_bwd plan B=%d H=%d Q=%d L=%d: %d split(s), query tiles", B, H, Q, L, plan.n);
+    for (int i = 0; i < plan.n; ++i) fprintf(stderr, " %d", plan.cut[i + 1] - plan.cut[i]);
+    fprintf(stderr, "\n");
+  }
+  return plan;
+}
+
 }  // namespace
 
 extern "C" size_t petr_mha_bwd_workspace_bytes(int B, int H, int Q, int L) {
@@ -322,12 +428,40 @@ extern "C" int petr_mha_bwd(const petr_mha_bwd_args* ap, void* stream) {
   p.a = *ap;
   const petr_mha_bwd_args& a = p.a;
   p.nkb = (int)cdiv(a.L, 128);
-  p.q_splits = choose_q_splits(a.B, a.H, a.Q, a.L);
-  if (const char* e = getenv(a.L <= a.Q ? "PETR_MHA_BWD_QSPLITS_SELF" : "PETR_MHA_BWD_QSPLITS")) {   // tuning overrides
-    const int v = atoi(e);
-    if (v >= 1 && v <= (int)cdiv(a.Q, 32)) p.q_splits = v;
+  {
+    const int qtiles = (int)cdiv(a.Q, 32);
+    static const bool uneven_on = !(getenv("PETR_MHA_BWD_UNEVEN") && atoi(getenv("PETR_MHA_BWD_UNEVEN")) == 0);
+    QPlan plan;
+    int forced = 0;
+    if (const char* e = getenv(a.L <= a.Q ? "PETR_MHA_BWD_QSPLITS_SELF" : "PETR_MHA_BWD_QSPLITS")) {   // tuning overrides: even splits
+      const int v = atoi(e);
+      if (v >= 1 && v <= qtiles) forced = v;
+    }
+    const char* explicit_plan = a.L > a.Q ? getenv("PETR_MHA_BWD_PLAN") : nullptr;     // tuning: "23,6" = tiles per split
+    if (explicit_plan) {
+      plan.n = 0; plan.cut[0] = 0;
+      for (const char* c = explicit_plan; *c && plan.n < 16;) {
+        const int v = atoi(c);
+        if (v < 1) break;
+        plan.cut[plan.n + 1] = plan.cut[plan.n] + v;
+        ++plan.n;
+        while (*c && *c != ',') ++c;
+        if (*c == ',') ++c;
+      }
+      PETR_CHECK(plan.n >= 1 && plan.cut[plan.n] == qtiles, PETR_ERR_INVALID, "mha_bwd: PETR_MHA_BWD_PLAN must sum to %d query tiles", qtiles);
+    } else if (!forced && uneven_on) {
+      plan = plan_q_splits(a.B, a.H, a.Q, a.L);
+    } else {
+      plan.n = forced ? forced : choose_q_splits(a.B, a.H, a.Q, a.L);
+      const int per = (int)cdiv(qtiles, plan.n);
+      if ((long)(plan.n - 1) * per >= qtiles) plan.n = (int)cdiv(qtiles, per);      // an override that would leave an empty split
+      for (int i = 0; i <= plan.n; ++i) plan.cut[i] = i * per < qtiles ? i * per : qtiles;
+    }
+    p.q_splits = plan.n;
+    for (int i = 0; i <= 16; ++i) p.qt_cut[i] = i <= plan.n ? plan.cut[i] : qtiles;
+    const long R = (long)p.nkb * a.B * a.H;
+    p.ordered = !(R & 7) && uneven_on;
   }
-  p.qtiles_per_split = (int)cdiv(cdiv(a.Q, 32), p.q_splits);
   p.vec = aligned16(a.q) && aligned16(a.d_o) && !(a.q_bs & 3) && !(a.q_hs & 3) && !(a.q_rs & 3) && !(a.do_bs & 3) &&
           !(a.do_hs & 3) && !(a.do_rs & 3);
   hipStream_t s = (hipStream_t)stream;

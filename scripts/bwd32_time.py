@@ -16,7 +16,10 @@ def t(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 g = torch.Generator().manual_seed(0)
-for name, Q, L in (('self', 900, 900), ('c5', 900, 4224), ('p4_1408', 900, 16896), ('v2_800', 900, 12000), ('p4_1600', 900, 24000)):
+SHAPES = (('self', 900, 900), ('c5', 900, 4224), ('p4_1408', 900, 16896), ('v2_800', 900, 12000), ('p4_1600', 900, 24000))
+ONLY = os.environ.get('SHAPE')          # SHAPE=c5: that shape alone (PMC passes)
+for name, Q, L in SHAPES:
+    if ONLY and name != ONLY: continue
     mk = lambda n: torch.randn(1, n, 256, generator=g).cuda().view(1, n, 8, 32).permute(0, 2, 1, 3)
     q, do, k, v = mk(Q), mk(Q), mk(L), mk(L)
     drop = (1234, 3, p) if p > 0 else None

@@ -330,11 +330,11 @@ int choose_q_splits(int B, int H, int Q, int L) {
 // the even splits up to 16, memoised per shape.  Short key ranges (the self-attention) keep choose_q_splits' even split: their
 // workgroups are latency-bound in ways this model does not carry (it would take 8 splits where 4 measures best).
 struct QPlan { int n; int cut[17]; };
-static double simulate_slots(int rx, const int* sizes, int n, int slots) {
+static double simulate_slots(int rx, const int* sizes, int n, int slots, double e_split = 2.5) {
   // greedy list scheduling of n groups of rx equal workgroups, in order, onto `slots` machines
   double t[64];
   for (int i = 0; i < slots; ++i) t[i] = 0.0;
-  const double e = n > 1 ? 2.5 : 1.0;
+  const double e = n > 1 ? e_split : 1.0;
   for (int g = 0; g < n; ++g)
     for (int r = 0; r < rx; ++r) {
       int m = 0;
@@ -386,7 +386,20 @@ static QPlan plan_q_splits(int B, int H, int Q, int L) {
   // and the even heuristic stays.
   const double rounds = (double)(R / 8) / 64.0;
   const bool trusted = rounds <= 1.0 || (rounds - (long)rounds > 0.0 && rounds - (long)rounds < 0.15);
-  if (L <= 2048 || (R & 7) || R / 8 > 4096 || !trusted) {
+  if (L > 2048 && !(R & 7) && R / 8 <= 4096 && !trusted) {
+    // in between: EVEN splits only, chosen by the same slot model with the split epilogue priced at 4.5 tiles (v2-800: two
+    // even splits, 361 us against 376 unsplit alone, step 7.15 -> 7.04 ms; p4-1600: unsplit)
+    const int rx = (int)(R / 8);
+    double best = 1e30;
+    for (int sp = 1; sp <= 8 && sp <= qtiles; ++sp) {
+      const int per = (int)cdiv(qtiles, sp);
+      if ((long)(sp - 1) * per >= qtiles) continue;
+      int sizes[8];
+      for (int i = 0; i < sp; ++i) sizes[i] = (i + 1) * per <= qtiles ? per : qtiles - i * per;
+      const double c = simulate_slots(rx, sizes, sp, 64, 4.5);
+      if (c < best - 1e-9) { best = c; even(sp); }
+    }
+  } else if (L <= 2048 || (R & 7) || R / 8 > 4096) {
     even(choose_q_splits(B, H, Q, L));
   } else {
     const int rx = (int)(R / 8);

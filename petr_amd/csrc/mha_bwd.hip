@@ -385,7 +385,8 @@ static QPlan plan_q_splits(int B, int H, int Q, int L) {
   // within +-4 % of unsplit - the chip-wide float-atomic rate, which the slot model does not carry, eats the packing gain -
   // and the even heuristic stays.
   const double rounds = (double)(R / 8) / 64.0;
-  const bool trusted = rounds <= 1.0 || (rounds - (long)rounds > 0.0 && rounds - (long)rounds < 0.15);
+  const bool trusted = (rounds <= 1.0 || (rounds - (long)rounds > 0.0 && rounds - (long)rounds < 0.15)) &&
+                       qtiles <= 64;      // (the composition search is cubic in the tile count: 1 800 plans at 29 tiles)
   if (L > 2048 && !(R & 7) && R / 8 <= 4096 && !trusted) {
     // in between: EVEN splits only, chosen by the same slot model with the split epilogue priced at 4.5 tiles (v2-800: two
     // even splits, 361 us against 376 unsplit alone, step 7.15 -> 7.04 ms; p4-1600: unsplit)

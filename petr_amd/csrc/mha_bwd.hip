@@ -32,6 +32,22 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int P33 = 33;
 
+// Diagnostic build only (-DPETR_DIAG_BWD_STAMPS, scripts/bwd32_stamps.sh): s_memtime stamps at the phase boundaries of
+// the tile loop, summed over the tiles of a wave and added (wave 0, lane 0 of every workgroup) to 16 counters at the
+// front of the otherwise unused workspace.  No stamp exists in the product build.
+#ifdef PETR_DIAG_BWD_STAMPS
+#define STAMP(i)                                                  \
+  do {                                                            \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    const uint64_t now__ = __builtin_amdgcn_s_memtime();          \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    st_acc[i] += now__ - st_last;                                 \
+    st_last = now__;                                              \
+  } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 struct MhaBwdParams {
   petr_mha_bwd_args a;
   int nkb, q_splits;
@@ -83,6 +99,10 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
   const bool key_ok = key < a.L;
   const int key_ld = key_ok ? key : a.L - 1;
 
+#ifdef PETR_DIAG_BWD_STAMPS
+  uint64_t st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t st_last = __builtin_amdgcn_s_memtime();
+#endif
   const float* qp = a.q + (long)b * a.q_bs + (long)hd * a.q_hs;
   const float* gp = a.d_o + (long)b * a.do_bs + (long)hd * a.do_hs;
   const float* kp = a.k + (long)b * a.k_bs + (long)hd * a.k_hs;
@@ -197,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
     if (qt_begin + 1 < qt_end) gload(qt_begin + 1);
   }
   __syncthreads();
+  STAMP(0);      // prologue: K / V rows, first tile staged
   for (int qt = qt_begin; qt < qt_end; ++qt) {
     f32x16 S, dP;
 #pragma unroll
@@ -210,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
       S = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[c * P33 + 16 * h + s], kf[s], S, 0, 0, 0);
       dP = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[c * P33 + 16 * h + s], vf[s], dP, 0, 0, 0);
     }
+    STAMP(1);    // S / dP products issued
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       S[r] = __builtin_amdgcn_exp2f(S[r] * sc2);   // p
@@ -234,7 +256,9 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) dSs[wave][mfma32_row(r, h) * P33 + c] = dP[r];
+    STAMP(2);    // exp / ds, dV / dK products, ds to LDS
     __syncthreads();   // every wave is done with this tile's Q / dO / lse / delta images
+    STAMP(3);    // barrier 1
     if (qt + 1 < qt_end) {
       stage(qt + 1);
       if (qt + 2 < qt_end) gload(qt + 2);
@@ -249,7 +273,9 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
                                                  dQp, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][mfma32_row(r, h) * 32 + c] = dQp[r];
+    STAMP(4);    // next tile staged, dQ product, partial tile to LDS
     __syncthreads();
+    STAMP(5);    // barrier 2
     {
       float* dq = a.dq + (long)b * a.dq_bs + (long)hd * a.dq_hs + (long)qt * 32 * a.dq_rs;   // wave-uniform tile base
 #pragma unroll
@@ -259,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
         if (qt * 32 + (idx >> 5) < a.Q) atomicAdd(dq + dq_off[j], v * a.scale);
       }
     }
+    STAMP(6);    // partial tiles summed, dQ atomics issued
   }
 
   // ---- dK / dV: transpose each wave's 32x32 accumulators through LDS, then row-major adds ----
@@ -302,6 +329,15 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
       }
     }
   }
+#ifdef PETR_DIAG_BWD_STAMPS
+  STAMP(7);      // dK / dV epilogue issued (not drained)
+  if (t == 0) {
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(a.ws);
+    for (int i = 0; i < 8; ++i) atomicAdd(out + i, (unsigned long long)st_acc[i]);
+    atomicAdd(out + 8, (unsigned long long)(qt_end > qt_begin ? qt_end - qt_begin : 0));
+    atomicAdd(out + 9, 1ull);
+  }
+#endif
 }
 
 int choose_q_splits(int B, int H, int Q, int L) {

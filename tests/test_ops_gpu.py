@@ -229,7 +229,11 @@ def test_mha_fwd_strided_views_and_all_masked(ops):
     assert torch.isnan(o[1]).all() and torch.isnan(want[1]).all()
 
 
-@pytest.mark.parametrize('B,H,Q,L,masked', [(1, 8, 900, 4224, False), (1, 2, 70, 333, True), (2, 8, 900, 900, False)])
+# Shapes: c5 / self-attention / ragged, plus one per branch of the query-split planner of the atomic form and the
+# (batch 2, p4-1408, v2-800, p4-1600) key counts the executor runs: every BASELINE config's backward is compared with fp64.
+@pytest.mark.parametrize('B,H,Q,L,masked', [(1, 8, 900, 4224, False), (1, 2, 70, 333, True), (2, 8, 900, 900, False),
+                                            (2, 8, 900, 4224, False), (1, 8, 900, 12000, False), (1, 8, 900, 16896, True),
+                                            (1, 8, 900, 24000, False), (1, 8, 300, 4224, False)])
 def test_mha_bwd(ops, B, H, Q, L, masked):
     g = torch.Generator().manual_seed(Q * 3 + L)
     q, k, v = (torch.randn(B, H, n, 32, generator=g).double().requires_grad_(True) for n in (Q, L, L))
@@ -334,7 +338,8 @@ def test_layernorm_dropout_fwd_bwd(ops):
     assert relerr(dgm, gd.grad) < 1e-5 and relerr(dbt, bd.grad) < 1e-5
 
 
-@pytest.mark.parametrize('B,H,Q,L,split,masked', [(1, 8, 900, 1000, 0, False), (2, 2, 70, 333, 3, True), (1, 8, 130, 4224, 8, False)])
+@pytest.mark.parametrize('B,H,Q,L,split,masked', [(1, 8, 900, 1000, 0, False), (2, 2, 70, 333, 3, True), (1, 8, 130, 4224, 8, False),
+                                                   (1, 8, 900, 12000, 0, False), (1, 4, 900, 16896, 0, True)])
 def test_mha_dropout_fwd_bwd(ops, B, H, Q, L, split, masked):
     g = torch.Generator().manual_seed(Q * 7 + L)
     q, k, v = (torch.randn(B, H, n, 32, generator=g).double().requires_grad_(True) for n in (Q, L, L))
@@ -356,6 +361,11 @@ def test_mha_dropout_fwd_bwd(ops, B, H, Q, L, split, masked):
     assert relerr(o, want) < 2e-6
     assert relerr(lse, torch.logsumexp(s, -1)) < 2e-6                     # the LSE is the undropped softmax's
     dq, dk, dv = ops.mha_bwd(qf, kf, vf, o, dev(do), lse, dev(kpm) if masked else None, drop=drop)
+    assert relerr(dq, q.grad) < 1e-5 and relerr(dk, k.grad) < 1e-5 and relerr(dv, v.grad) < 1e-5
+    # ... and with the packed keep bits the forward leaves (what the executor's backward reads)
+    bits = torch.zeros_like(ops.dropout_bits(drop, B * H, Q, L)[1])
+    ops.mha_fwd(qf, kf, vf, dev(kpm) if masked else None, n_split=split, drop=drop, drop_bits=bits)
+    dq, dk, dv = ops.mha_bwd(qf, kf, vf, o, dev(do), lse, dev(kpm) if masked else None, drop=drop, drop_bits=bits)
     assert relerr(dq, q.grad) < 1e-5 and relerr(dk, k.grad) < 1e-5 and relerr(dv, v.grad) < 1e-5
     # p = 0 is the dropout-free kernel
     o0, _ = ops.mha_fwd(qf, kf, vf, dev(kpm) if masked else None, n_split=split, drop=(2024, 2, 0.0))
@@ -623,7 +633,8 @@ BF16_BWD_TOL = 2e-2      # max-norm relative error of dq / dk / dv against fp64 
 @pytest.mark.parametrize('B,H,Q,L,masked,drop,kt', [
     (1, 8, 900, 4224, False, None, 1), (1, 8, 900, 4224, False, (3, 2, 0.1), 1), (1, 2, 70, 333, True, None, 1),
     (2, 3, 31, 65, False, (5, 1, 0.3), 1), (1, 1, 1, 1, False, None, 1), (1, 4, 129, 1000, True, (8, 4, 0.1), 1),
-    (1, 8, 900, 4224, False, (3, 2, 0.1), 2), (1, 2, 200, 700, True, None, 2), (1, 8, 900, 12000, False, None, 1)])
+    (1, 8, 900, 4224, False, (3, 2, 0.1), 2), (1, 2, 200, 700, True, None, 2), (1, 8, 900, 12000, False, None, 1),
+    (1, 8, 900, 24000, False, None, 1), (1, 8, 900, 24000, False, (3, 2, 0.1), 1), (1, 8, 900, 16896, True, (9, 1, 0.1), 1)])
 def test_mha_bwd_bf16(ops, B, H, Q, L, masked, drop, kt, monkeypatch):
     """petr_mha_bwd_bf16 (gradient of petr_mha_fwd_bf16) vs fp64 autograd through softmax attention on the same
     bf16-rounded K / V (and the same exported dropout mask); kt = key tiles per wave: both shapes of the kernel."""

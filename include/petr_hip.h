@@ -493,6 +493,29 @@ int petr_reduce_partials(const float* x, int n_partials, long stride, const floa
 int petr_reduce_batch(const float* x, int B, long rows, int C, float* out, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Grouped weight gradients: up to PETR_WGRAD_MAX independent contractions in ONE launch,
+ *     dw_i[M_i, N_i] += sum_{k < K_i} dy_i[k, m] * x_i[k, n] ,   db_i[m] += sum_k dy_i[k, m]   (db optional)
+ * the parameter gradients autograd forms for the nn.Linear / nn.MultiheadAttention weights of one decoder layer
+ * (petr_transformer.py:158-224: self-attention in/out projections, cross-attention query / out projections, mmcv FFN
+ * layers 0 and 1) - ten small-output, 900-row contractions per layer that petr_gemm would run as ten launches of
+ * K-split workgroups with float atomics.  dy_i [K_i, >= M_i] and x_i [K_i, >= N_i] are row-major activations (leading
+ * dimensions lda / ldb, multiples of 4, 16-byte aligned), M_i and N_i multiples of 64; dw_i row-major with leading
+ * dimension ldc.  Each 64 x 64 output tile is owned by ONE workgroup that walks the whole K range (ksplit == 1: plain
+ * read-add-store, bit-reproducible) or by ksplit workgroups that add their K slices with float atomics (token-sized K).
+ * fp32 on v_mfma_f32_32x32x2_f32.  Returns PETR_ERR_UNSUPPORTED (nothing launched) if an item breaks the layout rules:
+ * callers fall back to petr_gemm for that item. */
+#define PETR_WGRAD_MAX 16
+typedef struct {
+  const float* dy; long lda;
+  const float* x; long ldb;
+  float* dw; long ldc;
+  float* db;
+  int M, N, K;
+  int ksplit;
+} petr_wgrad_item;
+int petr_wgrad_grouped(const petr_wgrad_item* items, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Training loss on the device: PETRHead.loss / loss_single / get_targets /
  * _get_target_single (models/dense_heads/petr_head.py:470-728) with HungarianAssigner3D.assign
  * (core/bbox/assigners/hungarian_assigner_3d.py:61-143; the reference goes device -> CPU scipy ->

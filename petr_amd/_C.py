@@ -136,6 +136,11 @@ class FfnBwdArgs(C.Structure):
         ('M', C.c_int), ('F', C.c_int), ('n_split', C.c_int))
 
 
+class WgradItem(C.Structure):        # petr_wgrad_item
+    _fields_ = _fields(('dy', C.c_void_p), ('lda', C.c_long), ('x', C.c_void_p), ('ldb', C.c_long), ('dw', C.c_void_p),
+                       ('ldc', C.c_long), ('db', C.c_void_p), ('M', C.c_int), ('N', C.c_int), ('K', C.c_int), ('ksplit', C.c_int))
+
+
 class MhaBwdArgs(C.Structure):
     _fields_ = _fields(
         ('q', C.c_void_p), ('q_bs', C.c_long), ('q_hs', C.c_long), ('q_rs', C.c_long),
@@ -273,6 +278,7 @@ def lib():
     L.petr_gate_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.petr_gate_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
     L.petr_fill.argtypes = [C.c_void_p, C.c_float, C.c_long, C.c_void_p]
+    L.petr_wgrad_grouped.argtypes = [C.POINTER(WgradItem), C.c_int, C.c_void_p]
     L.petr_fpn_upsample_add.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
     L.petr_axpy.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_long, C.c_void_p]
     L.petr_reduce_partials.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
@@ -309,7 +315,7 @@ EXPORTS = [
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
     'petr_ctx_create', 'petr_ctx_destroy', 'petr_ctx_join_into', 'petr_dropout_mask', 'petr_dropout_bits_words', 'petr_dropout_bits', 'petr_loss_workspace_bytes', 'petr_loss_fwd_bwd',
-    'petr_decode_boxes', 'petr_decode_topk', 'petr_fpn_upsample_add',
+    'petr_decode_boxes', 'petr_decode_topk', 'petr_fpn_upsample_add', 'petr_wgrad_grouped',
 ]
 
 

@@ -1,5 +1,6 @@
 // Library-level entry points: version, thread-local error text, device capabilities.
 #include "common.h"
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -23,6 +24,22 @@ extern "C" int petr_device_caps(int* num_cu, char* arch, int arch_len) {
   if (num_cu) *num_cu = prop.multiProcessorCount;
   if (arch && arch_len > 0) snprintf(arch, (size_t)arch_len, "%s", prop.gcnArchName);
   return PETR_OK;
+}
+
+// CU count per device: a hardware constant, cached after the first query of each device (relaxed atomics: racing first
+// calls store the same value)
+int petr_num_cus() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (dev >= 0 && dev < 64) {
+    const int v = cache[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+  }
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+  if (dev >= 0 && dev < 64 && n > 0) cache[dev].store(n, std::memory_order_relaxed);
+  return n;
 }
 
 // ---------------------------------------------------------------------------------------------

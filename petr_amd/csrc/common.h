@@ -14,6 +14,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void petr_set_error(const char* fmt, ...);
+// CU count of the current device (hardware constant, read once per device; <= 0 on error)
+int petr_num_cus();
 
 // opt-in event timing of tagged launches (api.cpp); no-ops unless petr_prof_begin() was called
 enum { PETR_PROF_MHA_FWD = 1, PETR_PROF_MHA_BWD = 2, PETR_PROF_GEMM = 3, PETR_PROF_COORDS3D = 4 };

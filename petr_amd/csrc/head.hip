@@ -1266,8 +1266,37 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   petr_gemm_args pend[24];
   auto flush_wgrads = [&]() -> int {
     if (!n_pend) return PETR_OK;
+#ifdef PETR_DIAG_SKIP_WGRAD      // diagnostic build only: the main chain's time without any weight-gradient work beside it
+    n_pend = 0;
+    return PETR_OK;
+#endif
     ln.fork_first(2);
-    for (int i = 0; i < n_pend; ++i) RUN(petr_gemm(&pend[i], ln.side(wg_rr++ & 1)));
+    // every 900-row parameter gradient queued so far goes into ONE grouped launch (petr_wgrad_grouped: a workgroup owns an
+    // output tile for the whole K range, no atomics) on side stream 0; what does not fit its layout rules (the 10-wide class
+    // logits, bf16-routed token contractions, the forward-shaped query_pos slabs) stays a petr_gemm launch, on side stream 1 first
+    static const bool grouped_on = env_on("PETR_WGRAD_GROUPED");
+    petr_wgrad_item grp[PETR_WGRAD_MAX];
+    bool taken[24];
+    int ng = 0;
+    for (int i = 0; i < n_pend; ++i) {
+      const petr_gemm_args& g = pend[i];
+      taken[i] = grouped_on && ng < PETR_WGRAD_MAX && !g.a_kcontig && !g.b_kcontig && g.flags == PETR_GEMM_ATOMIC && g.nb0 == 1 &&
+                 g.nb1 == 1 && g.k_seg <= 0 && !g.a2 && !g.bias && !g.r && !(g.M & 63) && !(g.N & 63) && !(g.lda & 3) && !(g.ldb & 3) &&
+                 aligned16(g.a) && aligned16(g.b);
+      if (!taken[i]) continue;
+      petr_wgrad_item& w = grp[ng++];
+      w.dy = g.a; w.lda = g.lda; w.x = g.b; w.ldb = g.ldb; w.dw = g.c; w.ldc = g.ldc; w.db = g.a_colsum;
+      w.M = g.M; w.N = g.N; w.K = g.K;
+      // token-sized K (the final stage's K / V projection and position-embedding weights): slices of >= 16 K steps until the
+      // item has ~512 workgroups; 900-row items keep one owner per tile
+      const long tiles = (long)(g.M / 64) * (g.N / 64);
+      long ks = g.K > 4096 ? cdiv(512, tiles) : 1;
+      const long max_ks = cdiv(cdiv(g.K, 32), 16);
+      w.ksplit = (int)(ks > max_ks ? max_ks : ks < 1 ? 1 : ks);
+    }
+    if (ng) RUN(petr_wgrad_grouped(grp, ng, ln.side(0)));
+    for (int i = 0; i < n_pend; ++i)
+      if (!taken[i]) RUN(petr_gemm(&pend[i], ln.side(++wg_rr & 1)));
     n_pend = 0;
     return PETR_OK;
   };

@@ -108,6 +108,15 @@ def linear(x, w, bias=None, relu=False, residual=None, a2=None, a2_rows=0, a2_nc
     return out
 
 
+def wgrad_grouped(items):
+    """``petr_wgrad_grouped``: items = [(dy [K, M], x [K, N], dw [M, N] (+=), db [M] or None, ksplit)], one launch."""
+    arr = (_C.WgradItem * len(items))()
+    for i, (dy, x, dw, db, ks) in enumerate(items):
+        arr[i] = _C.WgradItem(_ptr(_f32(dy)), dy.stride(0), _ptr(_f32(x)), x.stride(0), _ptr(dw), dw.stride(0),
+                              _ptr(db) if db is not None else None, dw.shape[0], dw.shape[1], dy.shape[0], ks)
+    _C.check(_C.lib().petr_wgrad_grouped(arr, len(items), _stream()), 'petr_wgrad_grouped')
+
+
 def dropout_mask(drop, rows, cols, device='cuda'):
     """The keep mask (bool [rows, cols]) a kernel applies for drop = (seed, site, p): parity tests hand it to the oracle."""
     L = _C.lib()

@@ -10,7 +10,9 @@ from petr_amd.ops import _ptr, _bhsd, _stream
 p = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
 Lb = _C.lib()
 g = torch.Generator().manual_seed(0)
-NAMES = ('prologue', 'S/dP mfma', 'exp+dV/dK+ds->lds', 'barrier1', 'stage+dQ mfma+red', 'barrier2', 'sum+atomics', 'epilogue')
+SK = os.environ.get('PETR_MHA_BWD_SK', '1') != '0'
+NAMES = (('visit prologue', 'S/dP mfma', 'exp+dV/dK+ds->lds', 'barrier', 'dQ operands+stage+gload', 'dQ mfma+atomics', '-', 'dK/dV flush') if SK else
+         ('prologue', 'S/dP mfma', 'exp+dV/dK+ds->lds', 'barrier1', 'stage+dQ mfma+red', 'barrier2', 'sum+atomics', 'epilogue'))
 for name, Q, L in (('self', 900, 900), ('c5', 900, 4224), ('p4_1600', 900, 24000)):
     mk = lambda n: torch.randn(1, n, 256, generator=g).cuda().view(1, n, 8, 32).permute(0, 2, 1, 3)
     q, do, k, v = mk(Q), mk(Q), mk(L), mk(L)
@@ -38,7 +40,7 @@ for name, Q, L in (('self', 900, 900), ('c5', 900, 4224), ('p4_1600', 900, 24000
     torch.cuda.synchronize()
     acc = ws[:10].cpu().tolist()
     tiles, wgs = acc[8] / n, acc[9] / n
-    print(f'{name} Q={Q} L={L} drop={p}: {e0.elapsed_time(e1) / n * 1e3:.1f} us/launch, {wgs:.0f} workgroups, {tiles:.0f} tile visits')
+    print(f'{name} Q={Q} L={L} drop={p}: {e0.elapsed_time(e1) / n * 1e3:.1f} us/launch, {wgs:.0f} workgroups / pair visits, {tiles:.0f} tile visits')
     tot = sum(acc[:8]) / n
     for i, nm in enumerate(NAMES):
         per = acc[i] / n / (wgs if i in (0, 7) else tiles)

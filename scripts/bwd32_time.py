@@ -30,9 +30,10 @@ for name, Q, L in SHAPES:
     dv = torch.zeros(1, L, 256, device='cuda').view(1, L, 8, 32).permute(0, 2, 1, 3)
     nbytes = Lb.petr_mha_bwd_workspace_bytes(1, 8, Q, L)
     ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device='cuda')
+    bits = ops.dropout_bits(drop, 8, Q, L)[1] if drop is not None and os.environ.get('BITS', '1') != '0' else None   # key-major words
     a = _C.MhaBwdArgs(_ptr(q), *_bhsd(q), _ptr(k), *_bhsd(k), _ptr(v), *_bhsd(v), _ptr(o), *_bhsd(o), _ptr(do), *_bhsd(do),
                       _ptr(lse), None, _ptr(dq), *_bhsd(dq), _ptr(dk), *_bhsd(dk), _ptr(dv), *_bhsd(dv), 1, 8, Q, L,
-                      32 ** -0.5, _ptr(ws), nbytes, _C.dropout(drop))
+                      32 ** -0.5, _ptr(ws), nbytes, _C.dropout(drop), _ptr(bits) if bits is not None else None)
     us = t(lambda: _C.check(Lb.petr_mha_bwd(C.byref(a), _stream()), 'petr_mha_bwd'))
     fl = 5 * 2.0 * Q * L * 256
     print(f'{name:8s} Q={Q} L={L:6d}: {us:8.1f} us  {fl / us * 1e-6:6.1f} TFLOP/s ({fl / us * 1e-6 / 157.3:.3f} of the fp32 MFMA peak)', flush=True)

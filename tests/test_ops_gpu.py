@@ -187,6 +187,39 @@ def test_layernorm_fwd_bwd(ops):
     assert torch.isfinite(yn).all() and (yn[3] == 0).all()
 
 
+def test_wgrad_grouped(ops):
+    """petr_wgrad_grouped: the weight / bias gradients of one decoder layer's linear maps in one launch (strided operand
+    views as the executor passes them, ragged K = 900, a K-split item with atomics) against fp64, accumulating (+=)."""
+    g = torch.Generator().manual_seed(21)
+    K = 900
+    qkv = torch.randn(K, 768, generator=g)
+    xs = [torch.randn(K, n, generator=g) for n in (256, 2048, 256)]
+    dys = [qkv[:, :512], torch.randn(K, 256, generator=g), torch.randn(K, 2048, generator=g), qkv[:, 512:]]
+    xin = [xs[0], xs[1], xs[2], xs[0]]
+    big_dy, big_x = torch.randn(4224, 256, generator=g), torch.randn(4224, 192, generator=g)
+    items, want = [], []
+    qkv_d = dev(qkv)
+    dyd = [qkv_d[:, :512], dev(dys[1]), dev(dys[2]), qkv_d[:, 512:]]
+    xd = [dev(x) for x in xs]
+    xind = [xd[0], xd[1], xd[2], xd[0]]
+    for dy, x, dy_d, x_d, with_b in zip(dys, xin, dyd, xind, (True, True, False, True)):
+        dw0 = torch.randn(dy.shape[1], x.shape[1], generator=g)
+        db0 = torch.randn(dy.shape[1], generator=g)
+        dw, db = dev(dw0), dev(db0)
+        items.append((dy_d, x_d, dw, db if with_b else None, 1))
+        want.append((dw0.double() + dy.double().t() @ x.double(), db0.double() + dy.double().sum(0), with_b))
+    dwb, dbb = torch.zeros(256, 192).cuda(), torch.zeros(256).cuda()
+    items.append((dev(big_dy), dev(big_x), dwb, dbb, 8))
+    want.append((big_dy.double().t() @ big_x.double(), big_dy.double().sum(0), True))
+    ops.wgrad_grouped(items)
+    for (dy_d, x_d, dw, db, _), (w, b, with_b) in zip(items, want):
+        assert relerr(dw, w) < 2e-6
+        if with_b:
+            assert relerr(db, b) < 2e-6
+    with pytest.raises(RuntimeError, match='multiples of 64'):
+        ops.wgrad_grouped([(dev(torch.randn(64, 10)), dev(torch.randn(64, 64)), torch.zeros(10, 64).cuda(), None, 1)])
+
+
 # ------------------------------------------------------------------ attention
 def _attn_ref(q, k, v, kpm, scale):
     s = torch.einsum('bhqd,bhkd->bhqk', q.double(), k.double()) * scale

@@ -11,7 +11,8 @@ upstream gradients) are resident in HBM before the timed region; ``img_metas`` s
 reference (float64 ``lidar2img`` inverted on the host every forward, petr_head.py:308-315).
 
 One JSON line on rank 0: metric/value/unit as BASELINE.json (samples/s fwd+bwd, whole job), plus
-  roofline      dominant kernel = cross-attention forward (mha_fwd_kernel): algorithmic FLOPs per launch
+  roofline      time-dominant kernel = cross-attention BACKWARD (mha_bwd_sk_kernel); roofline['forward'] = the cross-attention
+                forward (mha_fwd_kernel); each: algorithmic FLOPs per launch
                 (4*Q*L*C) / its mean launch duration measured with HIP events on the launch
                 stream inside real steps, against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
   cpu_baseline  the CPU oracle (a port of the reference's PyTorch path) timed on this box's host cores
@@ -149,6 +150,7 @@ def step_gflop(workload, batch):
     return batch * (3.0 * HEAD_FWD_GFLOP[workload] + 0.5 * ATTN_FWD_GFLOP[workload])
 
 
+PMC_TRAFFIC_FILES = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')     # newest first
 PROF_NAMES = {1: 'mha_fwd_self', 17: 'mha_fwd_cross', 2: 'mha_bwd_self', 18: 'mha_bwd_cross', 4: 'coords3d'}
 
 
@@ -418,7 +420,7 @@ def main():
             # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (scripts/pmc_traffic.sh,
             # method inside the file); only the workload / dtype / batch that was profiled gets a number, everything else null
             traffic, traffic_source = None, None
-            for fn in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+            for fn in PMC_TRAFFIC_FILES:
                 try:
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
                     ent = (pmc.get(f'{args.workload}_{args.dtype}') or pmc[args.workload])['mha_fwd_cross']
@@ -490,6 +492,31 @@ def main():
             us = kernels['mha_bwd_cross']['mean_us']
             kernels['mha_bwd_cross']['tflops'] = round(10.0 * B * Q * Ltok * 256 / (us * 1e-6) / 1e12, 2)
             kernels['mha_bwd_cross']['frac'] = round(kernels['mha_bwd_cross']['tflops'] / peak, 4)
+            # `roofline` describes the TIME-DOMINANT kernel of the step: the cross-attention backward (one launch per decoder
+            # layer; 10 Q L C algorithmic FLOP: five products).  The cross-attention forward keeps its object
+            # under roofline['forward'] (it was `roofline` itself in rounds 1-2).
+            fwd_obj = roofline
+            flops_b = 10.0 * B * Q * Ltok * 256
+            ach_b = flops_b / (us * 1e-6) / 1e12
+            traffic_b, src_b, alg_b = None, None, None
+            for fn in PMC_TRAFFIC_FILES:
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
+                    ent = (pmc.get(f'{args.workload}_{args.dtype}') or pmc[args.workload])['mha_bwd_cross']
+                    if B == 1 and ent.get('dtype', 'fp32') == args.dtype:
+                        traffic_b, alg_b = ent['traffic_bytes'], ent.get('algorithmic_min_bytes')
+                        src_b = f'profiles/{fn} (separate rocprofv3 --pmc passes)'
+                        break
+                except (OSError, KeyError, ValueError, TypeError):
+                    continue
+            n_layers = 6
+            roofline = {'kernel': ('mha_bwd_bf16_kernel' if args.dtype == 'bf16' else 'mha_bwd_sk_kernel') +
+                                  ' (cross-attention backward, one decoder layer): the time-dominant kernel of the step',
+                        'bound': 'mfma', 'achieved': round(ach_b, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach_b / peak, 4),
+                        'traffic': traffic_b, 'traffic_source': src_b, 'algorithmic_min_bytes': alg_b,
+                        'flops_per_launch': flops_b, 'mean_launch_us': us,
+                        'share_of_step': round(n_layers * us * 1e-3 / (elapsed / args.steps * 1e3), 4),
+                        'forward': fwd_obj}
         if 'coords3d' in kernels:
             us = kernels['coords3d']['mean_us']
             kernels['coords3d']['gbs'] = round(B * Ltok * 192 * 4 / (us * 1e-6) / 1e9, 1)   # volume bytes

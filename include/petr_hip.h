@@ -476,6 +476,16 @@ int petr_prof_end(float* ms, int* tags, int cap, int* n_out);
 int petr_fpn_upsample_add(float* dst, long sv, long sc, long sh, long sw, const float* src, int V, int C, int H, int W,
                           int Hs, int Ws, void* stream);
 
+/* Adjoint of petr_fpn_upsample_add (the gradient autograd sends through F.interpolate(mode='nearest') + add,
+ * models/necks/cp_fpn.py:175-186): dsrc[v, c, hs, ws] (+)= sum over the destination pixels (h, w) whose nearest source pixel is
+ * (hs, ws) of ddst[v*sv + c*sc + h*sh + w*sw]; dsrc NCHW [V, C, Hs, Ws], ddst addressed through element strides like the
+ * forward's dst.  accumulate: 0 overwrite, 1 add.  Gather form: one thread per source element, fixed summation order. */
+int petr_fpn_upsample_add_bwd(float* dsrc, const float* ddst, long sv, long sc, long sh, long sw, int V, int C, int H, int W,
+                              int Hs, int Ws, int accumulate, void* stream);
+/* src NCHW [V, C, H, W] -> the interior of a channels-last map dst [V, H+2, W+2, C] whose one-pixel border the caller keeps at
+ * zero: the layout the neck's 3x3 contraction reads (its backward needs the output gradient there; cp_fpn.py:190-192). */
+int petr_nchw_to_padded_nhwc(const float* src, float* dst, int V, int C, int H, int W, void* stream);
+
 /* small helpers used by the host executor */
 /* SELayer gate of PETRv2 (petrv2_head.py:55-60): out = x * sigmoid(u); bwd: dx = dout*sig, du = dout*x*sig*(1-sig) */
 int petr_gate_fwd(const float* x, const float* u, float* out, long n, void* stream);

@@ -142,6 +142,17 @@ __host__ __device__ __forceinline__ int petr_bits_slot(int c) { return 2 * ((c &
     }                                                                        \
   } while (0)
 
+// Tuning switches of the A/B builds.  The PRODUCT library never reads the environment: every switch is its compiled-in
+// default (petr_tune(name, dflt) folds to dflt), so the library has no hidden process-global inputs.  A diagnostic build
+// (make EXTRA=-DPETR_TUNING_ENV, scripts/ab_build.sh) reads the PETR_* variable once per call site instead: the same-box
+// A/B timing of the alternatives DESIGN.md records (devices differ by several per cent, so only same-box runs rank variants).
+#ifdef PETR_TUNING_ENV
+#include <stdlib.h>
+static inline int petr_tune(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+static inline constexpr int petr_tune(const char*, int dflt) { return dflt; }
+#endif
+
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

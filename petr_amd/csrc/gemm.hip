@@ -559,7 +559,7 @@ int launch_cfg(const petr_gemm_args& g, hipStream_t s) {
   // Measured and rejected as the default (same-box A/B, scripts/ab_env.sh, two rounds): c5 fp32 5.12 -> 5.20 ms/step,
   // p4-1600 fp32 11.18 -> 11.24, bf16 6.43 -> 6.51: the 900-row contractions are not waiting for memory (one 32 x 32
   // accumulator per wave = one dependent MFMA chain of 8 x 16 x 64 cycles), the extra registers only cost.
-  static const bool deep_on = getenv("PETR_GEMM_DEEP") && atoi(getenv("PETR_GEMM_DEEP")) != 0;
+  static const bool deep_on = petr_tune("PETR_GEMM_DEEP", 0) != 0;
   const int kseg_ = g.k_seg > 0 ? g.k_seg : g.K;
   const long ktiles_ = (long)(g.k_seg > 0 ? g.K / g.k_seg : 1) * cdiv(kseg_, BK);
   const bool deep = deep_on && VEC && (long)grid.x * grid.z <= 256 && ktiles_ / g.split_k >= 4;
@@ -907,7 +907,7 @@ extern "C" int petr_gemm(const petr_gemm_args* gp, void* stream) {
                                      PETR_GEMM_A_BF16 | PETR_GEMM_B_BF16 | PETR_GEMM_R_BF16)) && vec &&
                         (!g.a_kcontig || !(g.lda & 3)) && !(g.ldb & 3) && (g.a_kcontig || staged);
     // PETR_GEMM16_SIMPLE=0: everything through gemm_bf16.hip (same-box A/B of the two families)
-    static const bool simple_on = !(getenv("PETR_GEMM16_SIMPLE") && atoi(getenv("PETR_GEMM16_SIMPLE")) == 0);
+    static const bool simple_on = petr_tune("PETR_GEMM16_SIMPLE", 1) != 0;
     if (simple && (simple_on || g.a2)) return launch_bf16(g, s);
     return petr_gemm_bf16_general(g, s);
   }

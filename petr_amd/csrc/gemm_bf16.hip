@@ -634,7 +634,7 @@ int petr_gemm_bf16_general(const petr_gemm_args& g, hipStream_t s) {
   const int tm = (int)cdiv(g.M, GB_BM), tn = (int)cdiv(g.N, GB_BN);
   const bool a16 = (g.flags & PETR_GEMM_A_BF16) != 0, b16 = (g.flags & PETR_GEMM_B_BF16) != 0;
   // the deep-step kernel (K step 128, LDS epilogue) is the default; PETR_GEMM16_DEEP=0 selects the K-step-32 kernel
-  static const bool deep_on = !(getenv("PETR_GEMM16_DEEP") && atoi(getenv("PETR_GEMM16_DEEP")) == 0);
+  static const bool deep_on = petr_tune("PETR_GEMM16_DEEP", 1) != 0;
   // K slices: only short ones (<= 4 deep steps per slice: the split FFN contractions of the 900-row chain); long slices
   // (weight gradients over all tokens) stay with the double-buffered K-step-32 kernel, which measured 2x faster there
   const long deep_steps = (long)(g.k_seg > 0 ? g.K / g.k_seg : 1) * cdiv(kseg, GD_BK);

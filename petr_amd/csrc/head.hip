@@ -696,7 +696,7 @@ static int launch_weight_transposes(const float* Pm, float* Wm, const PL& P, con
   PETR_LAUNCH_CHECK("transpose_batch");
   return PETR_OK;
 }
-static bool env_on(const char* name) { const char* v = getenv(name); return !v || atoi(v) != 0; }    // default on
+static bool env_on(const char* name) { return petr_tune(name, 1) != 0; }    // default on; product builds: always on (common.h)
 // does the forward leave the transposed weight copies in the workspace?  (head_fwd makes them, head_bwd asks)
 template <class D>
 static bool fwd_transposes(const petr_head_config*, const D& d, int C) {
@@ -861,7 +861,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   uint16_t* mem16 = reinterpret_cast<uint16_t*>(Wm + W.mem);          // tok16: bf16 images in the front half of the
   uint16_t* mempos16 = reinterpret_cast<uint16_t*>(Wm + W.mempos);    // fp32 buffers, same element indexing
   if (tok16) RUN(petr_cast_bf16(Pm, p16, P.total, s));
-  static const bool ffn16_env = getenv("PETR_FFN16") && atoi(getenv("PETR_FFN16")) != 0;   // opt-in: the fused fp32 FFN kernels measured faster
+  static const bool ffn16_env = petr_tune("PETR_FFN16", 0) != 0;   // opt-in: the fused fp32 FFN kernels measured faster
   const bool ffn16 = tok16 && ffn16_env;
   // bf16 mode: the 1x1 convolutions over NCHW maps take the K-major variant of the bf16 contraction where it applies
   auto bf16_km = [&](const petr_gemm_args& q) {
@@ -877,7 +877,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   auto kv_project = [&](petr_gemm_args g, void* side, hipEvent_t* ev0) -> int {
     // opt-in (PETR_KV_FWD_SPLIT=1): same-box A/B on MI355X (scripts/ab_overlap.sh) was neutral at c5 and p4-1600, fp32
     // and bf16 (within 0.3 %), so the single batched contraction stays the default
-    static const bool split = getenv("PETR_KV_FWD_SPLIT") && atoi(getenv("PETR_KV_FWD_SPLIT")) != 0;
+    static const bool split = petr_tune("PETR_KV_FWD_SPLIT", 0) != 0;
     if (!ln.ctx || d.NL < 2 || !split) return petr_gemm(&g, side);
     const bool st16 = (g.flags & PETR_GEMM_STORE_BF16) != 0;     // bf16 store: c strides count 2-byte elements
     petr_gemm_args g0 = g;
@@ -1014,7 +1014,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   RUN(petr_fill(Wm + W.x0, 0.f, d.BQ * C + W.mha_sched_n, s));       // target = zeros (:95) + attention tickets
   // Dynamic K/V-tile tickets are opt-in (PETR_MHA_DYNAMIC=1): they make the grouping of the partial sums, and so
   // the low-order bits of the forward, depend on timing; the default static ranges keep the forward bit-reproducible.
-  static const bool mha_dynamic = getenv("PETR_MHA_DYNAMIC") && atoi(getenv("PETR_MHA_DYNAMIC")) != 0;
+  static const bool mha_dynamic = petr_tune("PETR_MHA_DYNAMIC", 0) != 0;
   int* sched = mha_dynamic ? reinterpret_cast<int*>(Wm + W.x0 + d.BQ * C) : nullptr;
   RUN(petr_add_rows(Wm + W.x0, E, Wm + W.lay[0].xe_in, d.BQ, d.Q, C, s));
   const float* x_in = Wm + W.x0;
@@ -1313,7 +1313,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   const uint16_t* p16 = reinterpret_cast<const uint16_t*>(Wm + W.p16);        // made by the forward (same parameters)
   auto Wp = [&](long off) -> const float* { return tok16 ? reinterpret_cast<const float*>(p16 + off) : Pm + off; };
   const int wflag = tok16 ? PETR_GEMM_B_BF16 : 0;
-  static const bool ffn16_env = getenv("PETR_FFN16") && atoi(getenv("PETR_FFN16")) != 0;   // opt-in: the fused fp32 FFN kernels measured faster
+  static const bool ffn16_env = petr_tune("PETR_FFN16", 0) != 0;   // opt-in: the fused fp32 FFN kernels measured faster
   const bool ffn16 = tok16 && ffn16_env;
   static const bool drop_bits_env = env_on("PETR_DROP_BITS");          // the forward generated them (same workspace)
   const bool use_bits = io->dropout_p > 0.f && drop_bits_env;
@@ -1326,7 +1326,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   // instead of two batched contractions in the final stage.  Measured and rejected as a default (same-box A/B,
   // scripts/ab_overlap.sh, two rounds): c5 fp32 5.09 -> 5.21 ms, p4-1600 bf16 6.98 -> 7.52 ms, p4-1600 fp32 neutral - the
   // main queue is ~85 % busy already, so token-sized work beside it takes CUs from the critical chain.
-  static const bool kv_overlap_env = getenv("PETR_KV_BWD_OVERLAP") && atoi(getenv("PETR_KV_BWD_OVERLAP")) != 0;
+  static const bool kv_overlap_env = petr_tune("PETR_KV_BWD_OVERLAP", 0) != 0;
   const bool kv_overlap = kv_overlap_env && ln.ctx != nullptr;
   const uint16_t* k16 = reinterpret_cast<const uint16_t*>(Wm + W.k_all);
   const uint16_t* v16 = reinterpret_cast<const uint16_t*>(Wm + W.v_all);
@@ -1487,7 +1487,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // stored hidden = relu(.) * keep/(1-p): (hidden > 0) is relu-mask AND keep; the 1/(1-p) rides on alpha
       // PETR_FUSE_LN_BWD: 3 (default) both FFN input gradients in one launch (petr_ffn_bwd: d_h stays on chip between them);
       // 2: LayerNorm backward + the FFN2 input gradient with its ReLU mask in petr_ln_bwd_proj (8 column blocks); 1: separate
-      static const int fuse_lvl = getenv("PETR_FUSE_LN_BWD") ? atoi(getenv("PETR_FUSE_LN_BWD")) : 3;
+      static const int fuse_lvl = petr_tune("PETR_FUSE_LN_BWD", 3);
       static const bool ffn_bwd16_env = env_on("PETR_FFN_BWD_FUSED_BF16");
       const bool ffn_bwd_fused = fuse_bwd && fuse_lvl >= 3 && W.ffn_fsplit > 0 && (!ffn16 || ffn_bwd16_env);
       const bool fuse_ffn2 = fuse_lvl >= 2;
@@ -1573,8 +1573,8 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // Opt-in (PETR_WGRAD_MIDFLUSH=1): interleaved three-round A/B on one box (scripts/ab_multi.sh) - c5 bf16 4.47 -> 4.54 ms,
       // v2-800 bf16 5.78 -> 5.86, p4-1600 bf16 6.04 -> 6.06, c5 fp32 4.94 -> 5.01: the second fork per layer costs more than
       // the overlap it removes, so the stage keeps its single flush at the end.
-      static const bool midflush = getenv("PETR_WGRAD_MIDFLUSH") && atoi(getenv("PETR_WGRAD_MIDFLUSH")) != 0;
-      static const bool flush_b = getenv("PETR_WGRAD_FLUSH_EARLY") && atoi(getenv("PETR_WGRAD_FLUSH_EARLY")) == 2;
+      static const bool midflush = petr_tune("PETR_WGRAD_MIDFLUSH", 0) != 0;
+      static const bool flush_b = petr_tune("PETR_WGRAD_FLUSH_EARLY", 1) == 2;
       if (defer && (midflush || flush_b)) RUN(flush_wgrads());
       // K / V projection backward of THIS layer (token-sized: the largest contractions of the backward) leaves the
       // critical path: dW_l and d_src (+)= dKV_l W_l go to the side streams right behind the attention backward that
@@ -1639,7 +1639,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // the next stage's first 57-workgroup kernel, where three quarters of the chip idle - not beside the next FFN backward,
       // which fills it (PETR_WGRAD_FLUSH_EARLY=0: at the end of the stage).  The in-projection's weight gradients queued below
       // leave with the next stage's fork, or at the end of the call.
-      static const int flush_early = getenv("PETR_WGRAD_FLUSH_EARLY") ? atoi(getenv("PETR_WGRAD_FLUSH_EARLY")) : 1;
+      static const int flush_early = petr_tune("PETR_WGRAD_FLUSH_EARLY", 1);
       if (defer && flush_early == 1) RUN(flush_wgrads());
       float* d_qkv = Wm + W.d_qkv + (long)l * d.BQ * 3 * C;
       RUN(mha_b(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,

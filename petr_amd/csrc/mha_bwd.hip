@@ -4,29 +4,25 @@
 // gets it from autograd through bmm/softmax/bmm and, because of cp.checkpoint :201-212, re-runs the
 // whole layer forward first).
 //
-// Structure (cdna guide, Appendix B "Attention backward", adapted to fp32 MFMA 32x32x2):
-//   workgroup = 4 waves = 128 keys of one (batch, head) x a slice of the query tiles;
-//   each wave owns 32 keys: its K and V rows live in registers for the whole sweep and its
-//   dK^T / dV^T accumulators (32x32 each) stay in registers, so dK/dV need no cross-wave sum.
+// Structure (cdna guide, Appendix B "Attention backward", adapted to fp32 MFMA):
+//   workgroup = 4 waves = 128 keys of one (batch, head) pair; each wave owns 32 keys: its K and V rows live in registers
+//   for the whole sweep and its dK^T / dV^T accumulators (32x32 each) stay in registers, so dK/dV need no cross-wave sum.
 //   Per 32-query tile, with the KEY ON THE LANE:
 //     S'  = Q K^T  (acc initialised to -LSE/scale + key bias)      -> p  = exp2(S' * scale*log2e)
 //     dP' = dO V^T (acc initialised to -delta)                     -> ds = p * dP'
 //     dV^T += dO^T p ,  dK^T += Q^T ds   : p / ds accumulators are used directly as B operands
-//     dQ   += ds K  : ds crosses LDS once (transpose key-on-lane -> query-on-lane); the four
-//                     waves' partial tiles are summed in LDS and added to global dQ with
-//                     128-byte-segment float atomics (two segments per wave instruction).
+//     dQ   += ds K  : ds crosses LDS once (key-on-lane -> [query][key] image); each wave then owns a 16 x 16 quadrant of the
+//                     dQ tile over ALL 128 keys (v_mfma_f32_16x16x4_f32) and adds it to global dQ with float atomics.
 //   LDS tiles of Q and dO use pitch 33 so that both the row-fragment read (lane = query) and the
 //   column-fragment read (lane = d) are conflict-free ds_read_b32.
 //   delta = rowsum(dO*O) is formed from the O tile that is loaded with Q and dO (no separate pass).
 // Outputs are ACCUMULATED (+=): the caller zero-fills them (the executor clears its gradient
-// workspace once).  dQ uses float atomics, so its low-order bits depend on arrival order.
+// workspace once).  dQ (and dK / dV of a pair shared by several workgroups) use float atomics, so their low-order bits
+// depend on arrival order.
 #include <stdlib.h>
 
 #include "common.h"
-#include <array>
 #include <type_traits>
-#include <map>
-#include <mutex>
 
 namespace {
 
@@ -49,305 +45,12 @@ constexpr int P33 = 33;
 #define STAMP(i) do { } while (0)
 #endif
 
-struct MhaBwdParams {
-  petr_mha_bwd_args a;
-  int nkb, q_splits;
-  int qt_cut[17];      // query-tile range of split s: [qt_cut[s], qt_cut[s+1]) - the splits may be UNEVEN (plan_q_splits)
-  int ordered;         // workgroup order inside an XCD: split-major (all first splits, then all second ...), see the kernel
-  int vec;             // q/do/k/v 16-byte loads legal
-  DropDev drop;        // the forward's probability dropout (thr == 0: off)
-  const uint32_t* drop_bits;   // key-major packed mask (petr_dropout_bits) or null: re-hash
-  int nqt32, lpad;             // its dimensions: ceil(Q/32) query tiles, 32 * ceil(L/32) keys per tile
-};
-
-// DROP: the forward multiplied the probabilities by keep/(1-p) after the softmax, so with m = keep/(1-p)
-//   dV += dO^T (p*m) ,  dP = m * (dO V^T) ,  ds = p * (dP - delta)   (delta = rowsum(dO*O) of the DROPPED output)
-// and the masks are regenerated from (seed, site, row, key), row = (b*H+h)*Q + q.
-template <bool HAS_MASK, bool VEC, bool DROP>
-__global__ __launch_bounds__(256, 2) void mha_bwd_kernel(const MhaBwdParams p) {
-  __shared__ __attribute__((aligned(16))) float Qs[32 * P33];
-  __shared__ __attribute__((aligned(16))) float dOs[32 * P33];
-  __shared__ __attribute__((aligned(16))) float dSs[4][32 * P33];
-  __shared__ __attribute__((aligned(16))) float Ks[128 * 32];
-  __shared__ __attribute__((aligned(16))) float red[4][32 * P33];
-  __shared__ float lse_s[32], dl_s[32];
-  __shared__ uint32_t rk_s[32];
-
-  const petr_mha_bwd_args& a = p.a;
-  const int total = p.nkb * a.B * a.H * p.q_splits;
-  int qs, rest;
-  if (p.ordered) {
-    // workgroup ids are dealt round-robin to the 8 XCDs and dispatched in order inside each: XCD x takes the (key block, head)
-    // pairs [x R/8, (x+1) R/8) and runs ALL their first (largest) splits before any second one - longest-first list
-    // scheduling of the uneven splits over the XCD's workgroup slots (R = pairs, a multiple of 8)
-    const int rx = (total / p.q_splits) >> 3;
-    const int x = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    qs = sq / rx;
-    rest = x * rx + (sq - qs * rx);
-  } else {
-    const int w = xcd_remap(blockIdx.x, total);
-    qs = w % p.q_splits;
-    rest = w / p.q_splits;
-  }
-  const int kb = rest % p.nkb;
-  const int bh = rest / p.nkb;
-  const int b = bh / a.H, hd = bh - b * a.H;
-
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int h = lane >> 5, c = lane & 31;
-  const int key0 = kb * 128 + wave * 32;
-  const int key = key0 + c;
-  const bool key_ok = key < a.L;
-  const int key_ld = key_ok ? key : a.L - 1;
-
-#ifdef PETR_DIAG_BWD_STAMPS
-  uint64_t st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  uint64_t st_last = __builtin_amdgcn_s_memtime();
-#endif
-  const float* qp = a.q + (long)b * a.q_bs + (long)hd * a.q_hs;
-  const float* gp = a.d_o + (long)b * a.do_bs + (long)hd * a.do_hs;
-  const float* kp = a.k + (long)b * a.k_bs + (long)hd * a.k_hs;
-  const float* vp = a.v + (long)b * a.v_bs + (long)hd * a.v_hs;
-
-  // ---- this wave's K / V rows: lane (c,h) holds row key, columns 16h..16h+15 ----
-  float kf[16], vf[16];
-  {
-    const float* ks = kp + (long)key_ld * a.k_rs + 16 * h;
-    const float* vs = vp + (long)key_ld * a.v_rs + 16 * h;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {   // unconditional loads (clamped row) + select
-      const float kx = ks[i], vx = vs[i];
-      kf[i] = key_ok ? kx : 0.f;
-      vf[i] = key_ok ? vx : 0.f;
-    }
-  }
-  // K also in LDS, natural [key][d], as the B operand of the dQ product (lane = d)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = t + 256 * i;
-    const int kr = idx >> 3, c4 = idx & 7;
-    const int kg = kb * 128 + kr;
-    const float* s = kp + (long)min(kg, a.L - 1) * a.k_rs + 4 * c4;
-    const bool ok = kg < a.L;
-    const float4 v = make_float4(s[0], s[1], s[2], s[3]);
-    *reinterpret_cast<float4*>(Ks + kr * 32 + 4 * c4) =
-        make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-  }
-  float key_bias = key_ok ? 0.f : -INFINITY;
-  if (HAS_MASK && key_ok && a.kpm[(long)b * a.L + key]) key_bias = -INFINITY;
-
-  f32x16 dKt, dVt;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) dKt[r] = dVt[r] = 0.f;
-
-  const int qtiles = (a.Q + 31) / 32;
-  const int qt_begin = p.qt_cut[qs];
-  const int qt_end = min(qtiles, p.qt_cut[qs + 1]);
-  const float inv_scale = 1.f / a.scale;
-  const float sc2 = a.scale * LOG2E;
-
-  // register prefetch of a query tile: thread -> (row = t>>3, 4 columns at 4*(t&7))
-  const float* op = a.o + (long)b * a.o_bs + (long)hd * a.o_hs;
-  float4 qreg, greg, oreg;
-  float lreg = 0.f;
-  // packed dropout mask: the word of this lane's key for the query tile travels with the tile's prefetch (dnext) and
-  // becomes current (dbits) when the tile is staged
-  const bool use_bits = DROP && p.drop_bits != nullptr;
-  uint32_t dnext = 0u, dbits = 0u;
-  // raw loads only (clamped rows): selects/negations happen at the LDS store so that nothing waits at the load
-  // Tile addresses are a wave-uniform base (scalar arithmetic) + a per-lane 32-bit offset computed once: the f32
-  // MFMA shares the vector issue port, and 32/64-bit integer multiplies are quarter rate.
-  const int ld_row = t >> 3, ld_c4 = t & 7;
-  const int q_off = ld_row * (int)a.q_rs + 4 * ld_c4, g_off = ld_row * (int)a.do_rs + 4 * ld_c4,
-            o_off = ld_row * (int)a.o_rs + 4 * ld_c4;
-  auto gload = [&](int qt) {
-    int qo = q_off, go = g_off, oo = o_off, lo = t & 31;
-    if (qt * 32 + 32 > a.Q) {   // wave-uniform: ragged last tile, rows beyond Q re-read row Q-1
-      const int rr = min(ld_row, a.Q - 1 - qt * 32);
-      qo = rr * (int)a.q_rs + 4 * ld_c4; go = rr * (int)a.do_rs + 4 * ld_c4; oo = rr * (int)a.o_rs + 4 * ld_c4;
-      lo = min(t & 31, a.Q - 1 - qt * 32);
-    }
-    const float* s = qp + (long)qt * 32 * a.q_rs + qo;
-    const float* g = gp + (long)qt * 32 * a.do_rs + go;
-    const float* o = op + (long)qt * 32 * a.o_rs + oo;
-    if (VEC) {
-      qreg = *reinterpret_cast<const float4*>(s);
-      greg = *reinterpret_cast<const float4*>(g);
-      oreg = *reinterpret_cast<const float4*>(o);
-    } else {
-      qreg = make_float4(s[0], s[1], s[2], s[3]);
-      greg = make_float4(g[0], g[1], g[2], g[3]);
-      oreg = make_float4(o[0], o[1], o[2], o[3]);
-    }
-    lreg = a.lse[(long)bh * a.Q + qt * 32 + lo];
-    if (use_bits) dnext = p.drop_bits[((long)bh * p.nqt32 + qt) * p.lpad + min(key0, p.lpad - 32) + petr_bits_slot(c)];
-  };
-
-  int dq_off[4];   // element (row, d) = (idx >> 5, idx & 31) of the 32 x 32 dQ tile, idx = t + 256 j
-#pragma unroll
-  for (int j = 0; j < 4; ++j) dq_off[j] = ((t + 256 * j) >> 5) * (int)a.dq_rs + (t & 31);
-
-  // registers -> LDS for query tile qt (raw loads were issued one tile earlier)
-  auto stage = [&](int qt) {
-    dbits = dnext;
-    const int row = t >> 3, c4 = t & 7;
-    const bool ok = qt * 32 + row < a.Q;
-    float* d = Qs + row * P33 + 4 * c4;
-    d[0] = ok ? qreg.x : 0.f; d[1] = ok ? qreg.y : 0.f; d[2] = ok ? qreg.z : 0.f; d[3] = ok ? qreg.w : 0.f;
-    float* e = dOs + row * P33 + 4 * c4;
-    e[0] = ok ? greg.x : 0.f; e[1] = ok ? greg.y : 0.f; e[2] = ok ? greg.z : 0.f; e[3] = ok ? greg.w : 0.f;
-    // delta[row] = sum_d dO*O of this (row, head): 8 lanes share a row -> three xor-shuffles, no extra kernel
-    float dl = (greg.x * oreg.x + greg.y * oreg.y) + (greg.z * oreg.z + greg.w * oreg.w);
-    dl += __shfl_xor(dl, 1, 64);
-    dl += __shfl_xor(dl, 2, 64);
-    dl += __shfl_xor(dl, 4, 64);
-    if (c4 == 0) dl_s[row] = ok ? -dl : 0.f;
-    if (t < 32) {
-      const bool rok = qt * 32 + t < a.Q;
-      lse_s[t] = rok ? -lreg * inv_scale : -INFINITY;   // rows beyond Q: -LSE/scale = -inf  =>  p = 0
-      if (DROP) rk_s[t] = drop_row_key(p.drop, (uint32_t)(bh * a.Q + min(qt * 32 + t, a.Q - 1)));
-    }
-  };
-
-  // Two barriers per query tile: the tile for the NEXT iteration is staged between them (its Q/dO images are free
-  // as soon as every wave has finished the four products of the current tile), so the barrier that publishes the
-  // dQ partials also publishes the next tile.
-  if (qt_begin < qt_end) {
-    gload(qt_begin);
-    stage(qt_begin);
-    if (qt_begin + 1 < qt_end) gload(qt_begin + 1);
-  }
-  __syncthreads();
-  STAMP(0);      // prologue: K / V rows, first tile staged
-  for (int qt = qt_begin; qt < qt_end; ++qt) {
-    f32x16 S, dP;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qr = mfma32_row(r, h);
-      S[r] = lse_s[qr] + key_bias;
-      dP[r] = DROP ? 0.f : dl_s[qr];
-    }
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      S = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[c * P33 + 16 * h + s], kf[s], S, 0, 0, 0);
-      dP = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[c * P33 + 16 * h + s], vf[s], dP, 0, 0, 0);
-    }
-    STAMP(1);    // S / dP products issued
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      S[r] = __builtin_amdgcn_exp2f(S[r] * sc2);   // p
-      if (DROP) {
-        const int qr = mfma32_row(r, h);
-        float m;
-        if (use_bits)      // wave-uniform: bit qr of the key's mask word instead of a hash
-          m = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe(dbits >> (4 * h), (r & 3) + 8 * (r >> 2), 1) & __float_as_uint(p.drop.scale));
-        else
-          m = drop_keep(rk_s[qr], (uint32_t)key, p.drop.thr) ? p.drop.scale : 0.f;
-        dP[r] = S[r] * (dP[r] * m + dl_s[qr]);     // ds = p * (m * dO.V - delta)
-        S[r] *= m;                                 // dropped probability: B operand of dV
-      } else {
-        dP[r] = S[r] * dP[r];                      // ds (without the softmax scale)
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int qr = mfma32_row(s, h);
-      dVt = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[qr * P33 + c], S[s], dVt, 0, 0, 0);
-      dKt = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qr * P33 + c], dP[s], dKt, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dSs[wave][mfma32_row(r, h) * P33 + c] = dP[r];
-    STAMP(2);    // exp / ds, dV / dK products, ds to LDS
-    __syncthreads();   // every wave is done with this tile's Q / dO / lse / delta images
-    STAMP(3);    // barrier 1
-    if (qt + 1 < qt_end) {
-      stage(qt + 1);
-      if (qt + 2 < qt_end) gload(qt + 2);
-    }
-
-    f32x16 dQp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dQp[r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-      dQp = __builtin_amdgcn_mfma_f32_32x32x2f32(dSs[wave][c * P33 + 16 * h + s], Ks[(wave * 32 + 16 * h + s) * 32 + c],
-                                                 dQp, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][mfma32_row(r, h) * 32 + c] = dQp[r];
-    STAMP(4);    // next tile staged, dQ product, partial tile to LDS
-    __syncthreads();
-    STAMP(5);    // barrier 2
-    {
-      float* dq = a.dq + (long)b * a.dq_bs + (long)hd * a.dq_hs + (long)qt * 32 * a.dq_rs;   // wave-uniform tile base
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = t + 256 * j;
-        const float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
-        if (qt * 32 + (idx >> 5) < a.Q) atomicAdd(dq + dq_off[j], v * a.scale);
-      }
-    }
-    STAMP(6);    // partial tiles summed, dQ atomics issued
-  }
-
-  // ---- dK / dV: transpose each wave's 32x32 accumulators through LDS, then row-major adds ----
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    red[wave][c * P33 + mfma32_row(r, h)] = dKt[r] * a.scale;
-    dSs[wave][c * P33 + mfma32_row(r, h)] = dVt[r];
-  }
-  __syncthreads();
-  {
-    float* dk = a.dk + (long)b * a.dk_bs + (long)hd * a.dk_hs;
-    float* dv = a.dv + (long)b * a.dv_bs + (long)hd * a.dv_hs;
-    const bool use_atomic = p.q_splits > 1;
-    // += with ALL loads of the old values issued before the first store (a load-add-store per element serialises
-    // sixteen dependent memory round trips at the end of every workgroup)
-    float oldk[16], oldv[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int idx = j * 64 + lane;
-      const int kg = min(key0 + (idx >> 5), a.L - 1);
-      oldk[j] = use_atomic ? 0.f : dk[(long)kg * a.dk_rs + (idx & 31)];
-      oldv[j] = use_atomic ? 0.f : dv[(long)kg * a.dv_rs + (idx & 31)];
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int idx = j * 64 + lane;
-      const int kr = idx >> 5, d = idx & 31;
-      const int kg = key0 + kr;
-      if (kg < a.L) {
-        const float gk = red[wave][kr * P33 + d], gv = dSs[wave][kr * P33 + d];
-        float* pk = dk + (long)kg * a.dk_rs + d;
-        float* pv = dv + (long)kg * a.dv_rs + d;
-        if (use_atomic) {
-          atomicAdd(pk, gk);
-          atomicAdd(pv, gv);
-        } else {
-          *pk = oldk[j] + gk;
-          *pv = oldv[j] + gv;
-        }
-      }
-    }
-  }
-#ifdef PETR_DIAG_BWD_STAMPS
-  STAMP(7);      // dK / dV epilogue issued (not drained)
-  if (t == 0) {
-    unsigned long long* out = reinterpret_cast<unsigned long long*>(a.ws);
-    for (int i = 0; i < 8; ++i) atomicAdd(out + i, (unsigned long long)st_acc[i]);
-    atomicAdd(out + 8, (unsigned long long)(qt_end > qt_begin ? qt_end - qt_begin : 0));
-    atomicAdd(out + 9, 1ull);
-  }
-#endif
-}
-
-
 // =====================================================================================================================
-// Persistent form (round 3).  What the stamps of the form above showed (scripts/bwd32_stamps.py, MI355X): the tile loop itself
-// keeps the matrix pipe ~80 % busy, but (i) at c5 the uneven query splits still leave a third of the workgroup slots' time
-// unused and every split workgroup ends with 41 000 cycles of dK / dV float atomics, and (ii) the dQ step - partial tiles of
-// the four waves through an LDS buffer, a second barrier, sum, atomics - takes 5 400 of a tile's 12 500 cycles for 1 024
-// cycles of matrix work.  Here:
+// Persistent schedule (round 3).  What in-kernel stamps of round 2's form - one workgroup per (key block, head, query split),
+// dQ partial tiles of the four waves summed through LDS behind a second barrier - showed (scripts/bwd32_stamps.py): the tile loop
+// kept the matrix pipe ~80 % busy, but (i) at c5 the uneven query splits still left a third of the workgroup slots' time
+// unused and every split workgroup ended with 41 000 cycles of dK / dV float atomics, and (ii) the dQ step took 5 400 of a
+// tile's 12 500 cycles for 1 024 cycles of matrix work.  Here:
 //   * ONE launch of G = (resident workgroups per CU) x CUs persistent workgroups.  The P (key block, head) pairs are dealt as
 //     floor(P / G) WHOLE pairs per workgroup (dK / dV of a whole pair: plain read-add-store, no atomics) and the remaining
 //     rem = P mod G pairs as one sequence of rem x nqt query tiles cut into G equal contiguous ranges (a range may cross
@@ -714,127 +417,6 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_sk_kernel(const MhaBwdSkParams
 #endif
 }
 
-int choose_q_splits(int B, int H, int Q, int L) {
-  const long base = cdiv(L, 128) * (long)B * H;
-  const int qtiles = (int)cdiv(Q, 32);
-  int best = 1;
-  double best_cost = 1e30;
-  for (int s = 1; s <= qtiles && s <= 16; ++s) {
-    const int per = (int)cdiv(qtiles, s);
-    if ((long)(s - 1) * per >= qtiles) continue;
-    // rounds of 256 workgroups x (query tiles per workgroup + its epilogue: with s > 1 every workgroup ends with 32 KB of dK / dV
-    // float atomics, ~2.5 tiles' worth).  Fits the same-box step times at c5 (s = 3 < 5 < 7 < 4 < 2 < 1) and for the
-    // self-attention (4 < 5 ~ 6 ~ 8 < 3 < 10 < 2); the earlier `rounds * per + s` picked 5 at c5.
-    const double cost = (double)cdiv(base * s, 256) * (per + (s > 1 ? 2.5 : 1.0));
-    if (cost <= best_cost + 1e-9) { best_cost = cost; best = s; }     // ties: the finer split (batch 2 at c5: 3 beats 2 by 1.4 %)
-  }
-  return best;
-}
-
-// Uneven query splits for long key ranges.  With R (key block, head) pairs and S even splits the R S equal workgroups fill
-// the chip's workgroup slots (2 per CU) in ceil(R S / 512) rounds, the last one mostly empty (c5: 264 pairs x 3 = 792 = 1.55
-// rounds, paid as 2).  Splits of DIFFERENT sizes, dispatched largest first, pack the slots like longest-first list scheduling:
-// c5 (19, 8, 2) tiles instead of (10, 10, 9) -> 21.5 instead of 25 tile-times per slot in the model below, p4-1408 (23, 6)
-// instead of one split -> 76.5 instead of 90.  Model: per XCD (R / 8 pairs, 64 slots) every workgroup costs its query tiles +
-// 2.5 (split: dK / dV atomic epilogue) or + 1.0 (unsplit); searched over all non-increasing compositions into <= 4 parts and
-// the even splits up to 16, memoised per shape.  Short key ranges (the self-attention) keep choose_q_splits' even split: their
-// workgroups are latency-bound in ways this model does not carry (it would take 8 splits where 4 measures best).
-struct QPlan { int n; int cut[17]; };
-static double simulate_slots(int rx, const int* sizes, int n, int slots, double e_split = 2.5) {
-  // greedy list scheduling of n groups of rx equal workgroups, in order, onto `slots` machines
-  double t[64];
-  for (int i = 0; i < slots; ++i) t[i] = 0.0;
-  const double e = n > 1 ? e_split : 1.0;
-  for (int g = 0; g < n; ++g)
-    for (int r = 0; r < rx; ++r) {
-      int m = 0;
-      for (int i = 1; i < slots; ++i)
-        if (t[i] < t[m]) m = i;
-      t[m] += sizes[g] + e;
-    }
-  double mx = 0.0;
-  for (int i = 0; i < slots; ++i) mx = t[i] > mx ? t[i] : mx;
-  return mx;
-}
-static void search_parts(int rx, int left, int k, int mx, int* cur, int depth, double* best, QPlan* plan) {
-  if (k == 1) {
-    if (left > mx || left < 1) return;
-    cur[depth] = left;
-    const double c = simulate_slots(rx, cur, depth + 1, 64);
-    if (c < *best - 1e-9) {
-      *best = c;
-      plan->n = depth + 1;
-      plan->cut[0] = 0;
-      for (int i = 0; i <= depth; ++i) plan->cut[i + 1] = plan->cut[i] + cur[i];
-    }
-    return;
-  }
-  for (int a = left - (k - 1) < mx ? left - (k - 1) : mx; a >= 1; --a) {
-    cur[depth] = a;
-    search_parts(rx, left - a, k - 1, a, cur, depth + 1, best, plan);
-  }
-}
-static QPlan plan_q_splits(int B, int H, int Q, int L) {
-  static std::mutex mu;
-  static std::map<std::array<int, 4>, QPlan> memo;
-  std::lock_guard<std::mutex> lock(mu);
-  const std::array<int, 4> key = {B, H, Q, L};
-  auto it = memo.find(key);
-  if (it != memo.end()) return it->second;
-  const int qtiles = (int)cdiv(Q, 32);
-  const long R = cdiv(L, 128) * (long)B * H;
-  QPlan plan;
-  auto even = [&](int sp) {
-    plan.n = sp;
-    const int per = (int)cdiv(qtiles, sp);
-    for (int i = 0; i <= sp; ++i) plan.cut[i] = i * per < qtiles ? i * per : qtiles;
-  };
-  // Where the model is trusted (standalone kernel times, scripts/bwd32_plan_sweep.sh): the big splits fit ONE round of slots
-  // (c5: 33 pairs per XCD, (19, 8, 2) 161 us against 169 even) or the unsplit schedule leaves a nearly empty last round
-  // (p4-1408: 132 = 2.06 rounds, (23, 6) 502 us against 582).  In between (v2-800: 94 = 1.47 rounds) every plan measured
-  // within +-4 % of unsplit - the chip-wide float-atomic rate, which the slot model does not carry, eats the packing gain -
-  // and the even heuristic stays.
-  const double rounds = (double)(R / 8) / 64.0;
-  const bool trusted = (rounds <= 1.0 || (rounds - (long)rounds > 0.0 && rounds - (long)rounds < 0.15)) &&
-                       qtiles <= 64;      // (the composition search is cubic in the tile count: 1 800 plans at 29 tiles)
-  if (L > 2048 && !(R & 7) && R / 8 <= 4096 && !trusted) {
-    // in between: EVEN splits only, chosen by the same slot model with the split epilogue priced at 4.5 tiles (v2-800: two
-    // even splits, 361 us against 376 unsplit alone, step 7.15 -> 7.04 ms; p4-1600: unsplit)
-    const int rx = (int)(R / 8);
-    double best = 1e30;
-    for (int sp = 1; sp <= 8 && sp <= qtiles; ++sp) {
-      const int per = (int)cdiv(qtiles, sp);
-      if ((long)(sp - 1) * per >= qtiles) continue;
-      int sizes[8];
-      for (int i = 0; i < sp; ++i) sizes[i] = (i + 1) * per <= qtiles ? per : qtiles - i * per;
-      const double c = simulate_slots(rx, sizes, sp, 64, 4.5);
-      if (c < best - 1e-9) { best = c; even(sp); }
-    }
-  } else if (L <= 2048 || (R & 7) || R / 8 > 4096) {
-    even(choose_q_splits(B, H, Q, L));
-  } else {
-    const int rx = (int)(R / 8);
-    double best = 1e30;
-    int cur[16];
-    for (int k = 1; k <= 4 && k <= qtiles; ++k) search_parts(rx, qtiles, k, qtiles, cur, 0, &best, &plan);
-    for (int sp = 5; sp <= 16 && sp <= qtiles; ++sp) {
-      const int per = (int)cdiv(qtiles, sp);
-      if ((long)(sp - 1) * per >= qtiles) continue;
-      int sizes[16];
-      for (int i = 0; i < sp; ++i) sizes[i] = (i + 1) * per <= qtiles ? per : qtiles - i * per;
-      const double c = simulate_slots(rx, sizes, sp, 64);
-      if (c < best - 1e-9) { best = c; even(sp); }
-    }
-  }
-  memo[key] = plan;
-  if (getenv("PETR_MHA_BWD_PLAN_PRINT")) {            // diagnostics: the plan of every new shape, once
-    fprintf(stderr, "mha_bwd plan B=%d H=%d Q=%d L=%d: %d split(s), query tiles", B, H, Q, L, plan.n);
-    for (int i = 0; i < plan.n; ++i) fprintf(stderr, " %d", plan.cut[i + 1] - plan.cut[i]);
-    fprintf(stderr, "\n");
-  }
-  return plan;
-}
-
 }  // namespace
 
 extern "C" size_t petr_mha_bwd_workspace_bytes(int B, int H, int Q, int L) {
@@ -848,118 +430,49 @@ extern "C" int petr_mha_bwd(const petr_mha_bwd_args* ap, void* stream) {
   PETR_CHECK(ap->B > 0 && ap->H > 0 && ap->Q > 0 && ap->L > 0, PETR_ERR_INVALID, "mha_bwd: bad shape");
   const size_t need = petr_mha_bwd_workspace_bytes(ap->B, ap->H, ap->Q, ap->L);
   PETR_CHECK(ap->ws && ap->ws_bytes >= need, PETR_ERR_WORKSPACE, "mha_bwd: workspace %zu < %zu bytes", ap->ws_bytes, need);
-  MhaBwdParams p;
-  p.a = *ap;
-  const petr_mha_bwd_args& a = p.a;
-  p.nkb = (int)cdiv(a.L, 128);
-  {
-    const int qtiles = (int)cdiv(a.Q, 32);
-    static const bool uneven_on = !(getenv("PETR_MHA_BWD_UNEVEN") && atoi(getenv("PETR_MHA_BWD_UNEVEN")) == 0);
-    QPlan plan;
-    int forced = 0;
-    if (const char* e = getenv(a.L <= a.Q ? "PETR_MHA_BWD_QSPLITS_SELF" : "PETR_MHA_BWD_QSPLITS")) {   // tuning overrides: even splits
-      const int v = atoi(e);
-      if (v >= 1 && v <= qtiles) forced = v;
-    }
-    const char* explicit_plan = a.L > a.Q ? getenv("PETR_MHA_BWD_PLAN") : nullptr;     // tuning: "23,6" = tiles per split
-    if (explicit_plan) {
-      plan.n = 0; plan.cut[0] = 0;
-      for (const char* c = explicit_plan; *c && plan.n < 16;) {
-        const int v = atoi(c);
-        if (v < 1) break;
-        plan.cut[plan.n + 1] = plan.cut[plan.n] + v;
-        ++plan.n;
-        while (*c && *c != ',') ++c;
-        if (*c == ',') ++c;
-      }
-      PETR_CHECK(plan.n >= 1 && plan.cut[plan.n] == qtiles, PETR_ERR_INVALID, "mha_bwd: PETR_MHA_BWD_PLAN must sum to %d query tiles", qtiles);
-    } else if (!forced && uneven_on) {
-      plan = plan_q_splits(a.B, a.H, a.Q, a.L);
-    } else {
-      plan.n = forced ? forced : choose_q_splits(a.B, a.H, a.Q, a.L);
-      const int per = (int)cdiv(qtiles, plan.n);
-      if ((long)(plan.n - 1) * per >= qtiles) plan.n = (int)cdiv(qtiles, per);      // an override that would leave an empty split
-      for (int i = 0; i <= plan.n; ++i) plan.cut[i] = i * per < qtiles ? i * per : qtiles;
-    }
-    p.q_splits = plan.n;
-    for (int i = 0; i <= 16; ++i) p.qt_cut[i] = i <= plan.n ? plan.cut[i] : qtiles;
-    const long R = (long)p.nkb * a.B * a.H;
-    p.ordered = !(R & 7) && uneven_on;
-  }
-  p.vec = aligned16(a.q) && aligned16(a.d_o) && !(a.q_bs & 3) && !(a.q_hs & 3) && !(a.q_rs & 3) && !(a.do_bs & 3) &&
-          !(a.do_hs & 3) && !(a.do_rs & 3);
-  hipStream_t s = (hipStream_t)stream;
-  {
-    static const int sk_mode = getenv("PETR_MHA_BWD_SK") ? atoi(getenv("PETR_MHA_BWD_SK")) : 1;     // (round-3 A/B switch)
-    static const int sk_slots = getenv("PETR_MHA_BWD_SK_SLOTS") ? atoi(getenv("PETR_MHA_BWD_SK_SLOTS")) : 0;
-    static const int sk_self = getenv("PETR_MHA_BWD_SK_SELF") ? atoi(getenv("PETR_MHA_BWD_SK_SELF")) : 1;
-    if (sk_mode && (a.L > a.Q || sk_self)) {
-      MhaBwdSkParams k;
-      k.a = a;
-      k.nkb = p.nkb;
-      k.nqt = (int)cdiv(a.Q, 32);
-      const long P = (long)k.nkb * a.B * a.H;
-      PETR_CHECK(P * k.nqt < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_bwd: too many (key block, head, query tile) units");
-      int cus = petr_num_cus();
-      PETR_CHECK(cus > 0, PETR_ERR_LAUNCH, "mha_bwd: cannot read the device's CU count");
-      // resident workgroups per CU: two (the kernel's LDS / register budget) while every workgroup still gets >= 8 query tiles;
-      // below that (the 900 x 900 self-attention: 1 856 tiles) a visit's fixed cost - K / V rows in, dK / dV out through float
-      // atomics, ~5 tiles' worth - outweighs the second wave per SIMD and one workgroup per CU is faster (measured: 38.7
-      // against 43.3 us at 900 x 900, 124.8 against 115.9 us at c5)
-      const int slots = sk_slots >= 1 && sk_slots <= 2 ? sk_slots : (P * k.nqt >= 16L * cus ? 2 : 1);
-      long G = (long)cus * slots;
-      if (G > P * k.nqt) G = P * k.nqt;
-      k.G = (int)G;
-      k.full_rounds = (int)(P / G);
-      k.rem = (int)(P % G);
-      const bool kv_vec = aligned16(a.k) && aligned16(a.v) && !(a.k_bs & 3) && !(a.k_hs & 3) && !(a.k_rs & 3) && !(a.v_bs & 3) &&
-                          !(a.v_hs & 3) && !(a.v_rs & 3) && aligned16(a.o) && !(a.o_bs & 3) && !(a.o_hs & 3) && !(a.o_rs & 3);
-      const int vec = p.vec && kv_vec;
-      PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "mha_bwd: dropout p=%g outside [0,1)", (double)a.drop.p);
-      PETR_CHECK((long)a.B * a.H * a.Q < (1L << 32), PETR_ERR_UNSUPPORTED, "mha_bwd: dropout row index needs B*H*Q < 2^32");
-      k.drop = make_drop(a.drop);
-      k.drop_bits = a.drop.p > 0.f ? a.drop_bits : nullptr;
-      k.nqt32 = k.nqt;
-      k.lpad = 32 * (int)cdiv(a.L, 32);
-      hipEvent_t ev0, ev1;
-      petr_prof_claim(PETR_PROF_MHA_BWD + 16 * (a.L > a.Q ? 1 : 0), &ev0, &ev1);
-      auto launch = [&](auto kern) { hipExtLaunchKernelGGL(kern, dim3((unsigned)k.G), dim3(256), 0, s, ev0, ev1, 0, k); };
-      const int dmode = k.drop.thr ? (k.drop_bits ? 2 : 1) : 0;
-      PETR_CHECK((long)a.Q * a.q_rs < (1L << 31) && (long)a.Q * a.do_rs < (1L << 31) && (long)a.Q * a.o_rs < (1L << 31) &&
-                     (long)a.Q * a.dq_rs < (1L << 31) && (long)k.nqt * k.lpad < (1L << 31),
-                 PETR_ERR_UNSUPPORTED, "mha_bwd: one (batch, head) slice of q / d_o / o / dq must span < 2^31 elements");
-#define PETR_SK_CASE(M, V)                                                              \
-  (dmode == 0 ? launch(mha_bwd_sk_kernel<M, V, 0>) : dmode == 1 ? launch(mha_bwd_sk_kernel<M, V, 1>) \
-                                                                : launch(mha_bwd_sk_kernel<M, V, 2>))
-      if (a.kpm) { if (vec) PETR_SK_CASE(true, true); else PETR_SK_CASE(true, false); }
-      else { if (vec) PETR_SK_CASE(false, true); else PETR_SK_CASE(false, false); }
-#undef PETR_SK_CASE
-      PETR_LAUNCH_CHECK("mha_bwd");
-      return PETR_OK;
-    }
-  }
-  // delta = rowsum(dO*O) is recomputed per query tile inside the kernel (O rides along with Q and dO)
-  const long total = (long)p.nkb * a.B * a.H * p.q_splits;
-  PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_bwd: grid too large");
-  hipEvent_t ev0, ev1;   // null unless bench.py's profiler is on: then they carry this dispatch's begin/end
-  petr_prof_claim(PETR_PROF_MHA_BWD + 16 * (a.L > a.Q ? 1 : 0), &ev0, &ev1);
+  MhaBwdSkParams k;
+  k.a = *ap;
+  const petr_mha_bwd_args& a = k.a;
+  k.nkb = (int)cdiv(a.L, 128);
+  k.nqt = (int)cdiv(a.Q, 32);
+  const long P = (long)k.nkb * a.B * a.H;
+  PETR_CHECK(P * k.nqt < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_bwd: too many (key block, head, query tile) units");
+  const int cus = petr_num_cus();
+  PETR_CHECK(cus > 0, PETR_ERR_LAUNCH, "mha_bwd: cannot read the device's CU count");
+  // Resident workgroups per CU: two (the kernel's LDS / register budget) while every workgroup still gets >= 8 query tiles;
+  // below that (the 900 x 900 self-attention: 1 856 tiles) a visit's fixed cost - K / V rows in, dK / dV out through float
+  // atomics, ~5 tiles' worth - outweighs the second wave per SIMD and one workgroup per CU is faster (measured, same box:
+  // 38.7 against 43.3 us at 900 x 900, 124.8 against 115.9 us at c5).  Everything else about the schedule follows from
+  // (P, nqt, CU count): see the kernel.
+  const int slots = P * k.nqt >= 16L * cus ? 2 : 1;
+  long G = (long)cus * slots;
+  if (G > P * k.nqt) G = P * k.nqt;
+  k.G = (int)G;
+  k.full_rounds = (int)(P / G);
+  k.rem = (int)(P % G);
+  auto rows_ok = [](const float* p, long bs, long hs, long rs) { return aligned16(p) && !(bs & 3) && !(hs & 3) && !(rs & 3); };
+  const bool vec = rows_ok(a.q, a.q_bs, a.q_hs, a.q_rs) && rows_ok(a.d_o, a.do_bs, a.do_hs, a.do_rs) && rows_ok(a.o, a.o_bs, a.o_hs, a.o_rs) &&
+                   rows_ok(a.k, a.k_bs, a.k_hs, a.k_rs) && rows_ok(a.v, a.v_bs, a.v_hs, a.v_rs);
   PETR_CHECK(a.drop.p >= 0.f && a.drop.p < 1.f, PETR_ERR_INVALID, "mha_bwd: dropout p=%g outside [0,1)", (double)a.drop.p);
   PETR_CHECK((long)a.B * a.H * a.Q < (1L << 32), PETR_ERR_UNSUPPORTED, "mha_bwd: dropout row index needs B*H*Q < 2^32");
-  p.drop = make_drop(a.drop);
-  p.drop_bits = a.drop.p > 0.f ? a.drop_bits : nullptr;
-  p.nqt32 = (int)cdiv(a.Q, 32);
-  p.lpad = 32 * (int)cdiv(a.L, 32);
-  auto launch = [&](auto kern) { hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), 0, s, ev0, ev1, 0, p); };
-  switch ((p.drop.thr ? 4 : 0) | (a.kpm ? 2 : 0) | (p.vec ? 1 : 0)) {
-    case 0: launch(mha_bwd_kernel<false, false, false>); break;
-    case 1: launch(mha_bwd_kernel<false, true, false>); break;
-    case 2: launch(mha_bwd_kernel<true, false, false>); break;
-    case 3: launch(mha_bwd_kernel<true, true, false>); break;
-    case 4: launch(mha_bwd_kernel<false, false, true>); break;
-    case 5: launch(mha_bwd_kernel<false, true, true>); break;
-    case 6: launch(mha_bwd_kernel<true, false, true>); break;
-    default: launch(mha_bwd_kernel<true, true, true>); break;
-  }
+  k.drop = make_drop(a.drop);
+  k.drop_bits = a.drop.p > 0.f ? a.drop_bits : nullptr;
+  k.nqt32 = k.nqt;
+  k.lpad = 32 * (int)cdiv(a.L, 32);
+  PETR_CHECK((long)a.Q * a.q_rs < (1L << 31) && (long)a.Q * a.do_rs < (1L << 31) && (long)a.Q * a.o_rs < (1L << 31) &&
+                 (long)a.Q * a.dq_rs < (1L << 31) && (long)k.nqt * k.lpad < (1L << 31),
+             PETR_ERR_UNSUPPORTED, "mha_bwd: one (batch, head) slice of q / d_o / o / dq must span < 2^31 elements");
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t ev0, ev1;   // null unless bench.py's profiler is on: then they carry this dispatch's begin/end
+  petr_prof_claim(PETR_PROF_MHA_BWD + 16 * (a.L > a.Q ? 1 : 0), &ev0, &ev1);
+  auto launch = [&](auto kern) { hipExtLaunchKernelGGL(kern, dim3((unsigned)k.G), dim3(256), 0, s, ev0, ev1, 0, k); };
+  const int dmode = k.drop.thr ? (k.drop_bits ? 2 : 1) : 0;
+#define PETR_SK_CASE(M, V)                                                                            \
+  (dmode == 0 ? launch(mha_bwd_sk_kernel<M, V, 0>) : dmode == 1 ? launch(mha_bwd_sk_kernel<M, V, 1>) \
+                                                                : launch(mha_bwd_sk_kernel<M, V, 2>))
+  if (a.kpm) { if (vec) PETR_SK_CASE(true, true); else PETR_SK_CASE(true, false); }
+  else { if (vec) PETR_SK_CASE(false, true); else PETR_SK_CASE(false, false); }
+#undef PETR_SK_CASE
   PETR_LAUNCH_CHECK("mha_bwd");
   return PETR_OK;
 }

@@ -525,20 +525,11 @@ extern "C" int petr_mha_bwd_bf16(const petr_mha_bwd_bf16_args* ap, void* stream)
   p.drop_bits = a.drop.p > 0.f ? a.drop_bits : nullptr;
   p.nqt32 = (int)cdiv(a.Q, 32);
   p.lpad = 32 * (int)cdiv(a.L, 32);
-  // two shapes of the same kernel, 256 keys per workgroup either way: (NW, KT) = (8, 1) - eight waves with one key tile
-  // each, one workgroup per CU - is the default; (4, 2) - four waves with two key tiles each, two workgroups per CU,
-  // PETR_MHA_BWD16_SHAPE=42 - was built to cut the LDS traffic per product by a third, but hipcc spills 27-40 registers of
-  // it into the tile loop and it measures 1.5-2x SLOWER (L = 24 000: 356 vs 192 us), so it stays an opt-in
-  int shape = 81;
-  if (const char* e = getenv("PETR_MHA_BWD16_SHAPE")) {
-    const int v = atoi(e);
-    if (v == 81 || v == 42) shape = v;
-  }
-  int qsp = choose_qsplits(a.B, a.H, a.Q, a.L, shape == 42 ? 2 : 1);
-  if (const char* e = getenv("PETR_MHA_BWD16_QSPLITS")) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= (int)cdiv(a.Q, 32)) qsp = v;
-  }
+  // (NW, KT) = (8, 1): eight waves with one 32-key tile each, one workgroup per CU.  The (4, 2) instantiation of the template -
+  // four waves with two key tiles each, two workgroups per CU - was built to cut the LDS traffic per product by a third, but
+  // hipcc spills 27-40 registers of it into the tile loop and it measured 1.5-2x slower (L = 24 000: 356 vs 192 us): not compiled
+  // into the library any more
+  int qsp = choose_qsplits(a.B, a.H, a.Q, a.L, 1);
   PETR_CHECK(!a.dkv_bf16 || a.dkv_overwrite, PETR_ERR_INVALID, "mha_bwd_bf16: dkv_bf16 needs dkv_overwrite");
   if (a.dkv_overwrite) qsp = 1;        // a stored dK / dV needs the whole query range in one workgroup per key block
   p.nkb = (int)cdiv(a.L, 256);
@@ -547,25 +538,19 @@ extern "C" int petr_mha_bwd_bf16(const petr_mha_bwd_bf16_args* ap, void* stream)
   if ((long)(qsp - 1) * p.qtiles_per_split >= cdiv(a.Q, 32)) {     // an override that would leave an empty split
     p.q_splits = (int)cdiv(cdiv(a.Q, 32), p.qtiles_per_split);
   }
-  static const int pair_on = [] { const char* v = getenv("PETR_MHA16_PAIR"); return !v || atoi(v) != 0; }();
+  static const int pair_on = petr_tune("PETR_MHA16_PAIR", 1) != 0;
   p.pair = pair_on && !(a.H & 1) && a.k_hs == 32 && a.v_hs == 32;
   const long total = (long)p.nkb * a.B * a.H * p.q_splits;
   PETR_CHECK(total < (1L << 31), PETR_ERR_UNSUPPORTED, "mha_bwd_bf16: grid too large");
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t ev0, ev1;   // null unless bench.py's profiler is on
   petr_prof_claim(PETR_PROF_MHA_BWD + 16 * (a.L > a.Q ? 1 : 0), &ev0, &ev1);
-  const unsigned threads = shape == 42 ? 256u : 512u;
-  auto launch = [&](auto kern) { hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(threads), 0, s, ev0, ev1, 0, p); };
-  const int variant = (shape == 42 ? 4 : 0) | (p.drop.thr ? 2 : 0) | (a.kpm ? 1 : 0);
-  switch (variant) {
+  auto launch = [&](auto kern) { hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), 0, s, ev0, ev1, 0, p); };
+  switch ((p.drop.thr ? 2 : 0) | (a.kpm ? 1 : 0)) {
     case 0: launch(mha_bwd_bf16_kernel<8, 1, false, false>); break;
     case 1: launch(mha_bwd_bf16_kernel<8, 1, true, false>); break;
     case 2: launch(mha_bwd_bf16_kernel<8, 1, false, true>); break;
-    case 3: launch(mha_bwd_bf16_kernel<8, 1, true, true>); break;
-    case 4: launch(mha_bwd_bf16_kernel<4, 2, false, false>); break;
-    case 5: launch(mha_bwd_bf16_kernel<4, 2, true, false>); break;
-    case 6: launch(mha_bwd_bf16_kernel<4, 2, false, true>); break;
-    default: launch(mha_bwd_bf16_kernel<4, 2, true, true>); break;
+    default: launch(mha_bwd_bf16_kernel<8, 1, true, true>); break;
   }
   PETR_LAUNCH_CHECK("mha_bwd_bf16");
   return PETR_OK;

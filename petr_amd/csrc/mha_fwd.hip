@@ -943,7 +943,7 @@ extern "C" int petr_mha_fwd_bf16(const petr_mha_fwd_bf16_args* ap, void* stream)
     p.ml_part = p.o_part + (size_t)ns * a.B * a.H * a.Q * 32;
   }
   p.q_vec = p.kv_vec = 0;
-  static const int pair_on = [] { const char* v = getenv("PETR_MHA16_PAIR"); return !v || atoi(v) != 0; }();
+  static const int pair_on = petr_tune("PETR_MHA16_PAIR", 1) != 0;
   p.pair = pair_on && !(a.H & 1) && a.k_hs == 32 && a.v_hs == 32;
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)p.nqb * a.B * a.H * ns;

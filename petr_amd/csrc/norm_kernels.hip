@@ -631,3 +631,74 @@ extern "C" int petr_fpn_upsample_add(float* dst, long sv, long sc, long sh, long
   PETR_LAUNCH_CHECK("fpn_upsample_add");
   return PETR_OK;
 }
+
+// ---- adjoint of the FPN top-down step: dsrc[v,c,hs,ws] (+)= sum of ddst over the destination pixels whose nearest source
+//      pixel is (hs, ws) (the gradient autograd sends through F.interpolate(mode='nearest') + add, cp_fpn.py:175-186) ----
+__global__ __launch_bounds__(256) void fpn_upsample_add_bwd_kernel(float* dsrc, const float* ddst, long sv, long sc, long sh, long sw,
+                                                                  int V, int C, int H, int W, int Hs, int Ws, int accumulate,
+                                                                  int c_fast) {
+  const long n = (long)V * C * Hs * Ws;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  int v, c, hs, ws;
+  if (c_fast) {      // channels-last gradient map: consecutive threads read consecutive channels
+    c = (int)(idx % C); long r = idx / C; ws = (int)(r % Ws); r /= Ws; hs = (int)(r % Hs); v = (int)(r / Hs);
+  } else {
+    ws = (int)(idx % Ws); long r = idx / Ws; hs = (int)(r % Hs); r /= Hs; c = (int)(r % C); v = (int)(r / C);
+  }
+  // the forward's map, evaluated exactly as fpn_upsample_add_kernel does: src(h) = min(int(floorf(h * scale)), in - 1)
+  const float sch = (float)Hs / (float)H, scw = (float)Ws / (float)W;
+  auto first_of = [](int s, float sc_, int n_in, int n_out) {      // smallest destination index that maps to a source >= s
+    int d = (int)floorf((float)s / sc_) - 1;
+    if (d < 0) d = 0;
+    while (d < n_out && min((int)floorf((float)d * sc_), n_in - 1) < s) ++d;
+    return d;
+  };
+  const int h0 = first_of(hs, sch, Hs, H), w0 = first_of(ws, scw, Ws, W);
+  float acc = 0.f;
+  for (int h = h0; h < H && min((int)floorf((float)h * sch), Hs - 1) == hs; ++h)
+    for (int w = w0; w < W && min((int)floorf((float)w * scw), Ws - 1) == ws; ++w)
+      acc += ddst[(long)v * sv + (long)c * sc + (long)h * sh + (long)w * sw];
+  float* o = dsrc + (((long)v * C + c) * Hs + hs) * Ws + ws;
+  *o = accumulate ? *o + acc : acc;
+}
+
+extern "C" int petr_fpn_upsample_add_bwd(float* dsrc, const float* ddst, long sv, long sc, long sh, long sw, int V, int C, int H,
+                                         int W, int Hs, int Ws, int accumulate, void* stream) {
+  PETR_CHECK(dsrc && ddst && V > 0 && C > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0, PETR_ERR_INVALID, "fpn_upsample_add_bwd: bad arguments");
+  const long n = (long)V * C * Hs * Ws;
+  hipLaunchKernelGGL(fpn_upsample_add_bwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dsrc, ddst, sv,
+                     sc, sh, sw, V, C, H, W, Hs, Ws, accumulate, sc == 1 ? 1 : 0);
+  PETR_LAUNCH_CHECK("fpn_upsample_add_bwd");
+  return PETR_OK;
+}
+
+// ---- NCHW [V, C, H, W] -> interior of a zero-bordered channels-last map [V, H+2, W+2, C] (the layout the 3x3 contraction of
+//      the neck reads: its backward needs the OUTPUT gradient in that layout).  32 x 32 (channel, pixel) tiles through LDS:
+//      reads coalesced along w, writes coalesced along c.  The border is the caller's (zero-filled once). ----
+__global__ __launch_bounds__(256) void nchw_to_padded_nhwc_kernel(const float* src, float* dst, int C, int H, int W) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  const int w0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int vh = blockIdx.z, v = vh / H, h = vh - v * H;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, w = w0 + tx;
+    tile[ty + 8 * i][tx] = (c < C && w < W) ? src[(((long)v * C + c) * H + h) * W + w] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int w = w0 + ty + 8 * i, c = c0 + tx;
+    if (c < C && w < W) dst[(((long)v * (H + 2) + h + 1) * (W + 2) + w + 1) * C + c] = tile[tx][ty + 8 * i];
+  }
+}
+
+extern "C" int petr_nchw_to_padded_nhwc(const float* src, float* dst, int V, int C, int H, int W, void* stream) {
+  PETR_CHECK(src && dst && V > 0 && C > 0 && H > 0 && W > 0, PETR_ERR_INVALID, "nchw_to_padded_nhwc: bad arguments");
+  PETR_CHECK((long)V * H <= 65535 && cdiv(C, 32) <= 65535, PETR_ERR_UNSUPPORTED, "nchw_to_padded_nhwc: V * H and C / 32 must be <= 65535");
+  hipLaunchKernelGGL(nchw_to_padded_nhwc_kernel, dim3((unsigned)cdiv(W, 32), (unsigned)cdiv(C, 32), (unsigned)(V * H)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, C, H, W);
+  PETR_LAUNCH_CHECK("nchw_to_padded_nhwc");
+  return PETR_OK;
+}

@@ -339,7 +339,7 @@ extern "C" int petr_sine3d_fwd(const petr_sine3d_args* a, void* stream) {
   PETR_CHECK(a->F > 0 && (a->F & 1) == 0, PETR_ERR_INVALID, "sine3d: num_feats must be even");
   Sine3dParams p{a->mask, a->dim_t, a->out, a->B, a->N, a->H, a->W, a->F, a->normalize, a->scale, a->eps, a->offset};
   const size_t rows_lds = ((size_t)a->F * (a->W + 1) + 2 * (size_t)a->F) * sizeof(float);
-  static const bool planes_on = !(getenv("PETR_SINE3D_PLANES") && atoi(getenv("PETR_SINE3D_PLANES")) == 0);
+  static const bool planes_on = petr_tune("PETR_SINE3D_PLANES", 1) != 0;
   if (!a->mask && planes_on && a->W % 4 == 0 && a->W + a->H + 1 <= 256 && aligned16(a->out)) {
     hipLaunchKernelGGL(sine3d_planes_kernel, dim3(a->F / 2, a->B * a->N), dim3(256), 0, (hipStream_t)stream, p);
     PETR_LAUNCH_CHECK("sine3d_planes");

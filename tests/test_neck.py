@@ -79,3 +79,93 @@ def test_cpfpn_baseline_shapes_gpu(chans, V, sizes):
         with torch.no_grad():
             out = head(petr_amd.glue.reshape_backbone_feats(list(got), 1), metas)
         assert torch.isfinite(out['all_cls_scores']).all()
+
+
+def _neck_grad_case(neck_cfg, inputs, seed, state=None, only_level0=False):
+    """forward + backward of petr_amd.CPFPN against torch autograd through the pinned CPU restatement (float64)."""
+    import petr_amd
+    neck = petr_amd.build_neck(neck_cfg)
+    if state is None:
+        torch.manual_seed(seed)
+        neck.init_weights()
+        with torch.no_grad():
+            for p in neck.parameters():
+                if p.dim() == 1:
+                    p.uniform_(-0.5, 0.5)          # non-zero biases
+    else:
+        neck.load_state_dict(state)
+    st64 = {k: v.detach().double().clone().requires_grad_(True) for k, v in neck.state_dict().items()}
+    xin = [x.double().clone().requires_grad_(True) for x in inputs]
+    want = NO.cpfpn_forward(st64, xin)
+    g = torch.Generator().manual_seed(seed + 1)
+    gouts = [torch.randn(w.shape, generator=g) for w in want]
+    loss = sum((w * go.double()).sum() for w, go in (list(zip(want, gouts))[:1] if only_level0 else zip(want, gouts)))
+    loss.backward()
+    neck = neck.cuda().train()
+    xg = [x.cuda().requires_grad_(True) for x in inputs]
+    got = neck(xg)
+    assert all(o.requires_grad for o in got)
+    if only_level0:          # what the detector does: only the position_level-0 map feeds the head (petr_head.py:381)
+        got[0].backward(gouts[0].cuda())
+    else:
+        torch.autograd.backward(list(got), [go.cuda() for go in gouts])
+
+    def err(a, b):
+        return ((a.detach().double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+    for a, b in zip(got, want):
+        assert err(a, b.detach()) < 2e-5
+    for i, (a, b) in enumerate(zip(xg, xin)):
+        assert a.grad is not None and err(a.grad, b.grad) < 2e-5, f'd_input[{i}]'
+    for name, p in neck.named_parameters():
+        assert p.grad is not None and err(p.grad, st64[name].grad) < 2e-5, name
+    return neck, xg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['cpfpn_toy', 'cpfpn_odd3'])
+def test_cpfpn_backward_golden_shapes_gpu(name):
+    """the reference fixtures' weights and inputs (two / three levels, odd sizes): every input and parameter gradient."""
+    fx, state, inputs, _ = _load(name)
+    cfg = dict(type='CPFPN', in_channels=[x.shape[1] for x in inputs], out_channels=64, num_outs=len(inputs))
+    _neck_grad_case(cfg, inputs, seed=5, state=state)
+    _neck_grad_case(cfg, inputs, seed=6, state=state, only_level0=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('chans,V,sizes', [([256, 512], 6, [(32, 88), (16, 44)]), ([96, 128], 12, [(20, 50), (10, 25)])])
+def test_cpfpn_backward_baseline_shapes_gpu(chans, V, sizes):
+    """p4-sized maps (32x88 / 16x44, six views; channel counts reduced to bound the float64 CPU oracle) and the 800x320 map
+    of PETRv2 (W = 50: the scalar-load path), gradient accumulation (+=) on a second backward, and the refusal of CPU maps."""
+    g = torch.Generator().manual_seed(11)
+    inputs = [torch.randn(V, c, h, w, generator=g) for c, (h, w) in zip(chans, sizes)]
+    neck, xg = _neck_grad_case(dict(type='CPFPN', in_channels=chans, out_channels=256, num_outs=2), inputs, seed=3, only_level0=True)
+    g1 = {n: p.grad.clone() for n, p in neck.named_parameters()}
+    out = neck(xg)
+    out[0].backward(torch.ones_like(out[0]))
+    out = neck(xg)
+    out[0].backward(torch.ones_like(out[0]))          # autograd accumulates: .grad = g1 + 2 * (gradient of the all-ones upstream)
+    for n, p in neck.named_parameters():
+        assert torch.isfinite(p.grad).all() and not torch.equal(p.grad, g1[n])
+
+
+@pytest.mark.gpu
+def test_cpfpn_into_head_training_step_gpu():
+    """neck -> [B, N, C, H, W] view -> PETRHead (train mode) -> backward: the head's d_feats reaches the neck's parameters and
+    the backbone maps (the producer of the 256-channel map inside the fwd + bwd step)."""
+    import petr_amd
+    from oracle import petr_oracle as O
+    torch.manual_seed(1)
+    neck = petr_amd.build_neck(dict(type='CPFPN', in_channels=[64, 128], out_channels=256, num_outs=2))
+    neck.init_weights()
+    neck = neck.cuda().train()
+    head = petr_amd.build_head(petr_amd.petr_head_cfg(num_query=64)).cuda().train()
+    metas = O.synthetic_img_metas(1, 6, (256, 704), seed=1)
+    g = torch.Generator().manual_seed(2)
+    xs = [torch.randn(6, 64, 16, 44, generator=g).cuda().requires_grad_(True), torch.randn(6, 128, 8, 22, generator=g).cuda().requires_grad_(True)]
+    feats = petr_amd.glue.reshape_backbone_feats(list(neck(xs)), 1)
+    out = head(feats, metas)
+    (out['all_cls_scores'].sum() + out['all_bbox_preds'].sum()).backward()
+    for x in xs:
+        assert x.grad is not None and torch.isfinite(x.grad).all() and x.grad.abs().max().item() > 0
+    for n, p in neck.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max().item() > 0, n

@@ -663,15 +663,15 @@ def test_gemm_bf16_batched_segments_and_nchw_output(ops):
 BF16_BWD_TOL = 2e-2      # max-norm relative error of dq / dk / dv against fp64 autograd on the same bf16-rounded K / V
 
 
-@pytest.mark.parametrize('B,H,Q,L,masked,drop,kt', [
-    (1, 8, 900, 4224, False, None, 1), (1, 8, 900, 4224, False, (3, 2, 0.1), 1), (1, 2, 70, 333, True, None, 1),
-    (2, 3, 31, 65, False, (5, 1, 0.3), 1), (1, 1, 1, 1, False, None, 1), (1, 4, 129, 1000, True, (8, 4, 0.1), 1),
-    (1, 8, 900, 4224, False, (3, 2, 0.1), 2), (1, 2, 200, 700, True, None, 2), (1, 8, 900, 12000, False, None, 1),
-    (1, 8, 900, 24000, False, None, 1), (1, 8, 900, 24000, False, (3, 2, 0.1), 1), (1, 8, 900, 16896, True, (9, 1, 0.1), 1)])
-def test_mha_bwd_bf16(ops, B, H, Q, L, masked, drop, kt, monkeypatch):
+@pytest.mark.parametrize('B,H,Q,L,masked,drop', [
+    (1, 8, 900, 4224, False, None), (1, 8, 900, 4224, False, (3, 2, 0.1)), (1, 2, 70, 333, True, None),
+    (2, 3, 31, 65, False, (5, 1, 0.3)), (1, 1, 1, 1, False, None), (1, 4, 129, 1000, True, (8, 4, 0.1)),
+    (1, 2, 200, 700, True, None), (1, 8, 900, 12000, False, None),
+    (1, 8, 900, 24000, False, None), (1, 8, 900, 24000, False, (3, 2, 0.1)), (1, 8, 900, 16896, True, (9, 1, 0.1))])
+def test_mha_bwd_bf16(ops, B, H, Q, L, masked, drop):
     """petr_mha_bwd_bf16 (gradient of petr_mha_fwd_bf16) vs fp64 autograd through softmax attention on the same
-    bf16-rounded K / V (and the same exported dropout mask); kt = key tiles per wave: both shapes of the kernel."""
-    monkeypatch.setenv('PETR_MHA_BWD16_SHAPE', '42' if kt == 2 else '81')      # (4 waves x 2 key tiles) / (8 waves x 1)
+    bf16-rounded K / V (and the same exported dropout mask)."""
+    kt = 1
     g = torch.Generator().manual_seed(Q * 3 + L + kt)
     q, k, v = (torch.randn(B, H, n, 32, generator=g) for n in (Q, L, L))
     do = torch.randn(B, H, Q, 32, generator=g)
@@ -706,7 +706,7 @@ def test_mha_bwd_bf16(ops, B, H, Q, L, masked, drop, kt, monkeypatch):
     def err(got, want):      # max-norm error relative to max(|want|, 0.05): with ONE key the true dq / dk are exactly zero
         return (got.double().cpu() - want).abs().max().item() / max(want.abs().max().item(), 0.05)
     e = [err(dq, qd.grad), err(dk, kd.grad), err(dv, vd.grad)]
-    print(f'mha_bwd_bf16 B{B} H{H} Q{Q} L{L} kt{kt}: dq {e[0]:.2e} dk {e[1]:.2e} dv {e[2]:.2e}')
+    print(f'mha_bwd_bf16 B{B} H{H} Q{Q} L{L}: dq {e[0]:.2e} dk {e[1]:.2e} dv {e[2]:.2e}')
     assert max(e) < BF16_BWD_TOL, e
     # size-independent identities: sum_k dV = sum_q (P*keep)^T dO has column sums equal to ... checked in test_properties
     assert torch.isfinite(dq).all() and torch.isfinite(dk).all() and torch.isfinite(dv).all()

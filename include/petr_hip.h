@@ -561,7 +561,7 @@ int petr_loss_fwd_bwd(const petr_loss_args* a, void* stream);
  * core/bbox/util.py:60-87, petr_head.py:745): for the n top-k entries `index` (into the flattened
  * [Q*num_classes] scores, as torch.topk returns them) of ONE sample: boxes [n,9] = denormalised box (z at
  * the gravity centre, or moved to the bottom centre), labels [n] = index % num_classes, keep [n] = centre
- * inside post_center_range (and score > score_threshold if > 0).                                  */
+ * inside post_center_range (and score > score_threshold if score_threshold >= 0; negative: the reference's score_threshold=None).                                  */
 typedef struct {
   const float* bbox_preds; const int64_t* index; const float* scores;
   float* boxes; int64_t* labels; uint8_t* keep;
@@ -574,7 +574,7 @@ int petr_decode_boxes(const petr_decode_args* a, void* stream);
 /* NMSFreeCoder.decode_single COMPLETE on the device (core/bbox/coders/nms_free_coder.py:48-97 + petr_head.py:730-751), one
  * launch for all samples of a batch: scores = sigmoid(cls_scores[b]) ; top-k of the flattened [Q*num_classes] scores
  * (sorted, descending: torch.topk) ; labels = index % num_classes ; boxes = denormalised bbox_preds[b][index / num_classes]
- * (z at the bottom centre if bottom_center) ; keep = centre inside post_center_range (and score > score_threshold if > 0).
+ * (z at the bottom centre if bottom_center) ; keep = centre inside post_center_range (and score > score_threshold if score_threshold >= 0; negative: the reference's score_threshold=None).
  *     cls_scores [B,Q,num_classes] LOGITS, bbox_preds [B,Q,code]; outputs [B,k,...]; k <= 1024; if Q*num_classes < k the
  *     tail entries have keep = 0 and index = -1.  index = the flat index torch.topk would return.                      */
 typedef struct {

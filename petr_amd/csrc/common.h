@@ -153,6 +153,19 @@ static inline int petr_tune(const char* name, int dflt) { const char* v = getenv
 static inline constexpr int petr_tune(const char*, int dflt) { return dflt; }
 #endif
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: raised once per (kernel, device) - one bit
+// per device ordinal in a per-call-site word (racing first calls set the same attribute twice, harmlessly)
+#include <atomic>
+struct PetrLdsLimit { std::atomic<unsigned long long> done{0ull}; };
+static inline void petr_raise_lds_limit(PetrLdsLimit& st, const void* kern, int bytes) {
+  int dev = 0;
+  const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+  const unsigned long long bit = known ? 1ull << dev : 0ull;
+  if (known && (st.done.load(std::memory_order_relaxed) & bit)) return;
+  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (known) st.done.fetch_or(bit, std::memory_order_relaxed);
+}
+
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

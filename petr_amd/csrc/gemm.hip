@@ -569,11 +569,8 @@ int launch_cfg(const petr_gemm_args& g, hipStream_t s) {
     constexpr size_t lds_bytes =                                                                                \
         2 * (size_t)BK * (Stage<BM, BK, AKC, VEC, A2>::LD + Stage<BN, BK, BKC, VEC, false>::LD) * 4;              \
     auto kern = gemm_kernel<BM, BN, WM, WN, BK, AKC, BKC, VEC, A2>;                                                 \
-    static bool attr_set = false;                                                                               \
-    if (lds_bytes > 65536 && !attr_set) {                                                                       \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-      attr_set = true;                                                                                          \
-    }                                                                                                           \
+    static PetrLdsLimit lds_limit;                                                                              \
+    if (lds_bytes > 65536) petr_raise_lds_limit(lds_limit, (const void*)kern, (int)lds_bytes);                  \
     if (deep) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, AKC, BKC, VEC, A2, 4>), grid, block, lds_bytes, s, g,   \
                                  tiles_m, tiles_n);                                                              \
     else hipLaunchKernelGGL(kern, grid, block, lds_bytes, s, g, tiles_m, tiles_n);                              \

@@ -652,11 +652,8 @@ int petr_gemm_bf16_general(const petr_gemm_args& g, hipStream_t s) {
 #define PETR_GD(AKC, BKC, A16, B16)                                                                                      \
   do {                                                                                                                   \
     auto kern = gemm_bf16_deep_kernel<AKC, BKC, A16, B16>;                                                               \
-    static bool attr_set = false;                                                                                        \
-    if (!attr_set) {                                                                                                     \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GD_LDS_BYTES);       \
-      attr_set = true;                                                                                                   \
-    }                                                                                                                    \
+    static PetrLdsLimit lds_limit;                                                                                       \
+    petr_raise_lds_limit(lds_limit, (const void*)kern, (int)GD_LDS_BYTES);                                               \
     hipLaunchKernelGGL(kern, grid, block, GD_LDS_BYTES, s, g, tm, tn, vec_epi);                                          \
   } while (0)
 #define PETR_GD2(AKC, BKC)                                  \

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void decode_boxes_kernel(petr_decode_args a) {
   a.labels[i] = a.index[i] % a.num_classes;
   bool keep = cx >= a.post_center_range[0] && cy >= a.post_center_range[1] && cz >= a.post_center_range[2] &&
               cx <= a.post_center_range[3] && cy <= a.post_center_range[4] && cz <= a.post_center_range[5];
-  if (a.score_threshold > 0.f) keep = keep && a.scores[i] > a.score_threshold;
+  if (a.score_threshold >= 0.f) keep = keep && a.scores[i] > a.score_threshold;
   a.keep[i] = keep ? 1 : 0;
 }
 
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(1024) void decode_topk_kernel(petr_decode_topk_args
     o[7] = a.code > 8 ? s[8] : 0.f; o[8] = a.code > 9 ? s[9] : 0.f;
     bool keep = cx >= a.post_center_range[0] && cy >= a.post_center_range[1] && cz >= a.post_center_range[2] &&
                 cx <= a.post_center_range[3] && cy <= a.post_center_range[4] && cz <= a.post_center_range[5];
-    if (a.score_threshold > 0.f) keep = keep && score > a.score_threshold;
+    if (a.score_threshold >= 0.f) keep = keep && score > a.score_threshold;
     a.scores[o_i] = score;
     a.labels[o_i] = idx % a.num_classes;
     a.index[o_i] = idx;

@@ -175,28 +175,12 @@ class NMSFreeCoder:
     def encode(self):
         pass
 
-    def decode_single(self, cls_scores, bbox_preds, bottom_center=False):
-        if self.post_center_range is None:
-            raise NotImplementedError('Need to reorganize output as a batch, only support post_center_range is not None for now!')
-        L = _C.lib()
-        scores, idx = cls_scores.sigmoid().view(-1).topk(self.max_num)      # selection: torch (plumbing)
-        n = idx.numel()
-        bbox_preds = bbox_preds.contiguous().float()
-        boxes = torch.empty((n, 9), dtype=torch.float32, device=scores.device)
-        labels = torch.empty((n,), dtype=torch.long, device=scores.device)
-        keep = torch.empty((n,), dtype=torch.uint8, device=scores.device)
-        a = _C.DecodeArgs(_ptr(bbox_preds), _ptr(idx), _ptr(scores.contiguous()), _ptr(boxes), _ptr(labels), _ptr(keep), n,
-                          self.num_classes, bbox_preds.shape[-1], (C.c_float * 6)(*[float(v) for v in self.post_center_range]),
-                          float(self.score_threshold) if self.score_threshold else 0.0, int(bottom_center))
-        _C.check(L.petr_decode_boxes(C.byref(a), _stream()), 'petr_decode_boxes')
-        mask = keep.bool()
-        return {'bboxes': boxes[mask], 'scores': scores[mask], 'labels': labels[mask]}
-
-    def decode(self, preds_dicts, bottom_center=False):
-        """All samples of the batch in ONE launch (petr_decode_topk): sigmoid, top-``max_num`` selection, gather, box
-        denormalisation and the range filter run on the device; torch only allocates the outputs and applies the keep
-        mask (a boolean index: the number of kept boxes is data dependent, as in the reference)."""
-        cls, box = preds_dicts['all_cls_scores'][-1], preds_dicts['all_bbox_preds'][-1]
+    def _decode_batch(self, cls, box, bottom_center):
+        """[B, Q, NC] logits + [B, Q, CS] boxes -> per-sample dicts, ONE launch (petr_decode_topk): sigmoid, top-``max_num``
+        selection, gather, box denormalisation and the range filter run on the device; torch only allocates the outputs and
+        applies the keep mask (a boolean index: the number of kept boxes is data dependent, as in the reference).
+        Order among equal scores: by logit descending, then flattened (query, class) index ascending - the reference's
+        ``sigmoid().topk()`` leaves the order of equal fp32 scores to the implementation."""
         if self.post_center_range is None:
             raise NotImplementedError('Need to reorganize output as a batch, only support post_center_range is not None for now!')
         L = _C.lib()
@@ -209,9 +193,9 @@ class NMSFreeCoder:
         labels = torch.empty((B, k), dtype=torch.long, device=dev)
         index = torch.empty((B, k), dtype=torch.long, device=dev)
         keep = torch.empty((B, k), dtype=torch.uint8, device=dev)
+        thr = float(self.score_threshold) if self.score_threshold is not None else -1.0      # negative: no score filter (None)
         a = _C.DecodeTopkArgs(_ptr(cls), _ptr(box), _ptr(boxes), _ptr(scores), _ptr(labels), _ptr(keep), _ptr(index), B, Q, NC,
-                              box.shape[-1], k, (C.c_float * 6)(*[float(v) for v in self.post_center_range]),
-                              float(self.score_threshold) if self.score_threshold else 0.0, int(bottom_center))
+                              box.shape[-1], k, (C.c_float * 6)(*[float(v) for v in self.post_center_range]), thr, int(bottom_center))
         _C.check(L.petr_decode_topk(C.byref(a), _stream()), 'petr_decode_topk')
         self._last_index = index
         out = []
@@ -219,6 +203,14 @@ class NMSFreeCoder:
             m = keep[i].bool()
             out.append({'bboxes': boxes[i][m], 'scores': scores[i][m], 'labels': labels[i][m]})
         return out
+
+    def decode_single(self, cls_scores, bbox_preds, bottom_center=False):
+        """nms_free_coder.py:48-97 for one sample: the same device path as ``decode`` with a batch of one."""
+        return self._decode_batch(cls_scores[None], bbox_preds[None], bottom_center)[0]
+
+    def decode(self, preds_dicts, bottom_center=False):
+        """nms_free_coder.py:99-120: the last decoder level of every sample."""
+        return self._decode_batch(preds_dicts['all_cls_scores'][-1], preds_dicts['all_bbox_preds'][-1], bottom_center)
 
 
 def get_bboxes(coder, preds_dicts, img_metas, rescale=False):

@@ -381,13 +381,18 @@ def test_head_p4_1408_forward_bf16_attention(pa):
 # (scripts/diag_bf16_grads.py, DESIGN.md section 4 "bf16 training step"): every bf16 OPERATOR agrees with fp64 on the same
 # rounded operands to 2e-5 (contractions) / 3e-3 L2 (attention backward), tests/test_ops_gpu.py.  At the HEAD level the
 # random-init decoder attends almost uniformly, so the query-specific part of every hidden state is a ~1/sqrt(L) residual
-# of large common components (the keys share a big mean), and rounding K / V / P to 8 bits perturbs that residual by
-# 8-20 % while the outputs move by 2e-4 ... 5e-4 of their range; the gradients inherit a 3-9 % L2 deviation (cosine
-# >= 0.995 per tensor at c5 / p4-1408; the small 12-view PETRv2 branch tensors reach 17 %).  Bars: outputs 1e-3 of the
-# range (REL_BF16); per tensor L2 <= 0.25 and cosine >= 0.97; whole flat gradient L2 <= 0.10; tensors whose true gradient
-# is identically zero (softmax shift invariance) or below 1e-3 of the largest gradient entry: absolute error <= 1e-3 of
-# that entry.
-def _bf16_grad_case(pa, head, oracle, feats, metas, g_cls, g_box, masks=None, l2_bar=0.25, cos_bar=0.97, flat_bar=0.10,
+# of large common components, and rounding P / ds / K / V to 8 bits perturbs that residual while the outputs move by
+# 2e-4 ... 5e-4 of their range; the gradients inherit a 4-5 % L2 deviation of the whole flat gradient, 4-8 % per tensor
+# (cosine >= 0.997), the same at c5, p4-1408, p4-1600 and v2-800 (round 3, all five cases below: flat 0.041 ... 0.050, worst
+# tensor 0.076 / cosine 0.9971).  Round 3 built the "centre the keys before rounding" cure the round-2 notes proposed
+# (key' = bf16(memory + pos - per-sample mean): exact for the softmax) and measured NO change (flat 0.048 -> 0.047,
+# 0.041 -> 0.042, 0.045 -> 0.044, 0.049 -> 0.050, 0.049 -> 0.047), so the common key mean is not what bounds these
+# numbers and the code was removed again; the rounding of the probabilities and of ds is inherent to bf16 matrix operands.
+# Bars (tightened in round 3 to the measured level): outputs 3e-3 of the range (REL_BF16_TRAIN); per tensor L2 <= 0.10 and
+# cosine >= 0.995; whole flat gradient L2 <= 0.06; tensors whose true gradient is identically zero (softmax shift
+# invariance) or below 1e-3 of the largest gradient entry (PETRv2's per-task reg heads on a synthetic upstream gradient:
+# entries 1e-6 of gmax, where an fp32 run differs from fp64 by as much): absolute error <= 1e-3 of that entry.
+def _bf16_grad_case(pa, head, oracle, feats, metas, g_cls, g_box, masks=None, l2_bar=0.10, cos_bar=0.995, flat_bar=0.06,
                     out_bar=REL_BF16_TRAIN):
     want, wgrads, wfeat = _oracle_grads(oracle, feats, metas, g_cls, g_box, torch.float64, masks)
     head.attn_dtype = 'bf16'

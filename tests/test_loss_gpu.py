@@ -240,6 +240,19 @@ def test_get_bboxes_golden(head, golden_dir):
     # NMSFreeCoder.decode keeps the gravity centre
     dec = head.bbox_coder.decode(preds)
     assert rel(dec[1]['bboxes'][:, 2] - dec[1]['bboxes'][:, 5] * 0.5, fx['bboxes1'][:, 2]) < 1e-5
+    # decode_single (nms_free_coder.py:48-97) is the same device path with a batch of one
+    for i in range(len(dec)):
+        one = head.bbox_coder.decode_single(preds['all_cls_scores'][-1][i], preds['all_bbox_preds'][-1][i])
+        for k in ('bboxes', 'scores', 'labels'):
+            assert torch.equal(one[k], dec[i][k])
+    # score_threshold: None keeps everything in range, a value filters on score > value (the reference's comparison)
+    import copy
+    coder = copy.copy(head.bbox_coder)
+    coder.score_threshold = 0.3
+    thr = coder.decode(preds)
+    for a, b in zip(thr, dec):
+        m = b['scores'] > 0.3
+        assert torch.equal(a['scores'], b['scores'][m]) and torch.equal(a['bboxes'], b['bboxes'][m])
 
 
 @pytest.mark.parametrize('B,Q,NC,k,quant', [(3, 900, 10, 300, False), (1, 900, 10, 300, True), (2, 20, 10, 300, False),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # MFMA / VALU / LDS utilisation counters of the four cross-attention kernels on the shapes bench.py times:
 # rocprofv3 --pmc passes (counters only, never with a trace domain; program directly after "--") over the timed-only bench
-# command for the headline (c5 fp32: mha_fwd_kernel, mha_bwd_kernel) and for p4_1600 bf16 (mha_fwd_bf16_kernel,
+# command for the headline (c5 fp32: mha_fwd_kernel, mha_bwd_sk_kernel) and for p4_1600 bf16 (mha_fwd_bf16_kernel,
 # mha_bwd_bf16_kernel).  Cross-attention launches are told from self-attention ones by the key count carried in the grid
 # (the parser keeps the launches with the largest grid of each kernel name).  Writes gpurun_out/r03_pmc_attention.txt.
 cd $GRAFT_REPO_ROOT
@@ -31,7 +31,7 @@ for i in range(1, 5):
     for f in glob.glob(f'/tmp/pmca_{wl}_{dt}_{i}/**/*counter_collection.csv', recursive=True):
         rows += list(csv.DictReader(open(f)))
 def short(n):
-    for k in ('mha_fwd_bf16_kernel', 'mha_bwd_bf16_kernel', 'mha_fwd_kernel', 'mha_bwd_kernel'):
+    for k in ('mha_fwd_bf16_kernel', 'mha_bwd_bf16_kernel', 'mha_fwd_kernel', 'mha_bwd_sk_kernel', 'mha_bwd_kernel'):
         if k in n:
             return k
     return None
@@ -43,7 +43,7 @@ for r in rows:
     k = short(r['Kernel_Name'])
     if k and int(r['Grid_Size']) == grid[k]:
         vals[k][r['Counter_Name']].append(float(r['Counter_Value']))
-cyc_per_mfma = {'mha_fwd_kernel': 64, 'mha_bwd_kernel': 64, 'mha_fwd_bf16_kernel': 32, 'mha_bwd_bf16_kernel': 32}
+cyc_per_mfma = {'mha_fwd_kernel': 64, 'mha_bwd_kernel': 64, 'mha_bwd_sk_kernel': 64, 'mha_fwd_bf16_kernel': 32, 'mha_bwd_bf16_kernel': 32}
 for k, cs in vals.items():
     if (dt == 'fp32') != ('bf16' not in k):
         continue

@@ -1,11 +1,13 @@
-"""Parse the counter_collection CSVs of scripts/pmc_traffic_r02.sh into gpurun_out/r02_pmc_traffic.json.
+"""Parse the counter_collection CSVs of scripts/pmc_traffic_r02.sh / _r03.sh into gpurun_out/<round>_pmc_traffic.json
+(round tag = first argument, default r03).
 traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch: the counters are in KiB and gfx950's FETCH_SIZE reports
 half of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM)."""
-import csv, glob, json, os, statistics
+import csv, glob, json, os, statistics, sys
+ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPES = {'c5': 6 * 16 * 44, 'p4_1600': 6 * 40 * 100}
 out = {'_how': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in SEPARATE passes (counters only) over `python3 bench.py --workload W '
-               '--dtype D --steps 4 --warmup 2 --timed-only` (MI355X, round 2; scripts/pmc_traffic_r02.sh).  Counter unit KiB; '
+               '--dtype D --steps 4 --warmup 2 --timed-only` (MI355X; scripts/pmc_traffic_' + ROUND + '.sh).  Counter unit KiB; '
                'traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE counts half of a wide coalesced read). '
                'Cross- and self-attention launches of the fp32 kernels alternate in dispatch order (forward: self, cross; backward: '
                'cross, self); the bf16 kernels only run the cross-attention.  Medians over the launches of 6 steps.  '
@@ -27,7 +29,7 @@ for wl, dt in (('c5', 'fp32'), ('p4_1600', 'bf16')):
             if 'mha_fwd_bf16_kernel' in name: key = 'fwd16'
             elif 'mha_bwd_bf16_kernel' in name: key = 'bwd16'
             elif 'mha_fwd_kernel' in name: key = 'fwd'
-            elif 'mha_bwd_kernel' in name: key = 'bwd'
+            elif 'mha_bwd_kernel' in name or 'mha_bwd_sk_kernel' in name: key = 'bwd'
             elif 'coords3d_kernel' in name: key = 'coords3d'
             if dt == 'bf16' and key in ('fwd', 'bwd'):
                 continue                      # bf16 mode: the fp32 attention kernels only run the 900-key self-attention
@@ -55,5 +57,5 @@ for wl, dt in (('c5', 'fp32'), ('p4_1600', 'bf16')):
                 e['algorithmic_min_bytes'] = 2 * Ltok * 256 * eb + 2 * Ltok * 256 * 4 + 4 * 900 * 256 * 4
             ent[names[k]] = e
     out[f'{wl}_{dt}'] = ent
-json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'r02_pmc_traffic.json'), 'w'), indent=1)
+json.dump(out, open(os.path.join(ROOT, 'gpurun_out', ROUND + '_pmc_traffic.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))

@@ -494,6 +494,11 @@ int petr_gate_bwd(const float* dout, const float* x, const float* u, float* dx, 
 int petr_add_rows(const float* x, const float* e, float* out, long M, int e_rows, int C, void* stream);
 /* the same sum with bf16 x and bf16 out (bf16 mode of the head: memory and key = memory + key_pos live as bf16) */
 int petr_add_rows_bf16(const uint16_t* x, const float* e, uint16_t* out, long M, int e_rows, int C, void* stream);
+/* key = memory + key_pos where key_pos = e1 + e2 arrives as two halves (3D position encoder petr_head.py:286-334, adapt_pos3d
+ * :400-402, produced on different streams): out[m,:] = x[m,:] + e1[m,:] + e2[m,:], and e1 += e2 in place (pos_embed, the sum
+ * the reference builds at :402).  _bf16: x and out are bf16 (the bf16 mode's memory / key images). */
+int petr_add_rows2(const float* x, float* e1, const float* e2, float* out, long M, int C, void* stream);
+int petr_add_rows2_bf16(const uint16_t* x, float* e1, const float* e2, uint16_t* out, long M, int C, void* stream);
 int petr_fill(float* p, float v, long n, void* stream);
 int petr_axpy(float* y, const float* x, float alpha, long n, void* stream); /* y += alpha*x */
 /* out[m,:] = sum_p x[p*stride + m*C..] (+ bias) (+ residual); generic partial reducer */

@@ -253,7 +253,7 @@ struct LayerW {
   long qkv, ao_s, lse_s, z0, mean0, rstd0, x1, xe1, qc, ao_c, lse_c, z1, mean1, rstd1, x2, hff, z2, mean2, rstd2, xe_in;
 };
 struct WOff {
-  long posemb, qe_h, qe, vol, sine, mem, h1, h2, pos, mempos, p16, k_all, v_all, x0;
+  long posemb, qe_h, qe, vol, sine, mem, h1, h2, pos, pos2, mempos, p16, k_all, v_all, x0;
   long bits, bits_cross_n, bits_self_n;      // [NL][cross | self] key-major words
   LayerW lay[8];
   long xs, mean_p, rstd_p, outs;
@@ -302,6 +302,7 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
   W.h1 = wb.add("pe_hidden", d.BL * 4 * C);
   W.h2 = wb.add("sine_hidden", d.BL * 4 * C);
   W.pos = wb.add("pos_embed", d.BL * C);
+  W.pos2 = wb.add("pos_embed_adapt", d.BL * C);      // adapt_pos3d half of the key position embedding until the two are joined
   W.mempos = wb.add("mempos", d.BL * C);
   {   // packed attention-dropout masks (training mode), key-major, per layer: the forward kernels leave them, the backward reads
     W.bits_cross_n = (long)d.B * d.NH * cdiv(d.L, 32) * 32 * cdiv(d.Q, 32);
@@ -925,6 +926,17 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     if (hid16) g.flags |= PETR_GEMM_BF16 | PETR_GEMM_STORE_BF16;      // bf16 hidden (same element indexing, 2-byte elements)
     g.flags |= wflag;
     RUN(petr_gemm(&g, s2));
+    // adapt_pos3d's second conv (petr_head.py:400-402) right here, into its own buffer: it used to accumulate into pos_embed on
+    // side 1 BEHIND the position encoder's second conv - 62 us at c5 in the middle of the chain the first cross-attention waits
+    // for (coords3d -> conv -> conv -> [this] -> key = memory + pos -> K projection).  The two halves now meet in petr_add_rows2.
+    // (PETR_ADAPT_PARALLEL=0, diagnostic builds: the old order)
+    if (petr_tune("PETR_ADAPT_PARALLEL", 1) != 0) {
+      g = lin_fwd(Wm + W.h2, Wp(P.ad_w2), Pm + P.ad_b2, Wm + W.pos2, d.BL, C, 4 * C);
+      if (attn_bf16) g.flags |= PETR_GEMM_BF16;
+      if (hid16) g.flags |= PETR_GEMM_A_BF16;
+      g.flags |= wflag;
+      RUN(petr_gemm(&g, s2));
+    }
   }
   // ---- side 1: 3D position embedding (petr_head.py:286-334): coords3d, conv 3D->4C, ReLU, conv 4C->C ----
   {
@@ -966,16 +978,21 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
       RUN(petr_gemm(&g, s1));
       RUN(petr_gate_fwd(Wm + W.pe1, Wm + W.fpe_u, Wm + W.pos, d.BL * C, s1));
     }
-    // pos += adapt_pos3d(sine) (petr_head.py:400-402)
-    g = lin_fwd(Wm + W.h2, Wp(P.ad_w2), Pm + P.ad_b2, Wm + W.pos, d.BL, C, 4 * C);
-    if (attn_bf16) { g.flags = PETR_GEMM_BF16; g.r = Wm + W.pos; g.ldr = C; }   // same sum with pos as the residual operand
-    else g.flags = PETR_GEMM_ACCUMULATE;
-    if (hid16) g.flags |= PETR_GEMM_A_BF16;
-    g.flags |= wflag;
-    RUN(petr_gemm(&g, s1));
-    // key = memory + key_pos (petr_transformer.py:343-344), once for all layers
-    if (tok16) RUN(petr_add_rows_bf16(mem16, Wm + W.pos, mempos16, d.BL, 0, C, s1));
-    else RUN(petr_add_rows(Wm + W.mem, Wm + W.pos, Wm + W.mempos, d.BL, 0, C, s1));
+    // key = memory + key_pos (petr_transformer.py:343-344), once for all layers; key_pos = pos_embed + adapt_pos3d(sine)
+    // (petr_head.py:400-402) is formed in the same pass (the sum stays in pos_embed)
+    if (petr_tune("PETR_ADAPT_PARALLEL", 1) != 0) {
+      if (tok16) RUN(petr_add_rows2_bf16(mem16, Wm + W.pos, Wm + W.pos2, mempos16, d.BL, C, s1));
+      else RUN(petr_add_rows2(Wm + W.mem, Wm + W.pos, Wm + W.pos2, Wm + W.mempos, d.BL, C, s1));
+    } else {
+      g = lin_fwd(Wm + W.h2, Wp(P.ad_w2), Pm + P.ad_b2, Wm + W.pos, d.BL, C, 4 * C);
+      if (attn_bf16) { g.flags = PETR_GEMM_BF16; g.r = Wm + W.pos; g.ldr = C; }   // same sum with pos as the residual operand
+      else g.flags = PETR_GEMM_ACCUMULATE;
+      if (hid16) g.flags |= PETR_GEMM_A_BF16;
+      g.flags |= wflag;
+      RUN(petr_gemm(&g, s1));
+      if (tok16) RUN(petr_add_rows_bf16(mem16, Wm + W.pos, mempos16, d.BL, 0, C, s1));
+      else RUN(petr_add_rows(Wm + W.mem, Wm + W.pos, Wm + W.mempos, d.BL, 0, C, s1));
+    }
     // K_l = (mem+pos) Wk_l^T + bk_l for ALL layers: [B][NL][L][C]
     g = gemm0();
     g.a = Wm + W.mempos; g.lda = C; g.a_kcontig = 1; g.a_bs0 = d.L * C;

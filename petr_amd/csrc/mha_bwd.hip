@@ -395,8 +395,10 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_sk_kernel(const MhaBwdSkParams
           float* pk = dk + (long)kg * a.dk_rs + d;
           float* pv = dv + (long)kg * a.dv_rs + d;
           if (use_atomic) {
+#ifndef PETR_DIAG_BWD_NOFLUSH      // (timing-only diagnostic build: what the partial pieces' dK / dV atomics cost)
             atomicAdd(pk, gk);
             atomicAdd(pv, gv);
+#endif
           } else {
             *pk = oldk[j] + gk;
             *pv = oldv[j] + gv;

@@ -572,6 +572,61 @@ extern "C" int petr_add_rows_bf16(const uint16_t* x, const float* e, uint16_t* o
   return PETR_OK;
 }
 
+// key = memory + (pos_a + pos_b) with the sum pos_a += pos_b left in place: the two halves of the key position embedding
+// (3D position encoder, adapt_pos3d) come from different streams and are only joined here (head.hip forward)
+__global__ __launch_bounds__(256) void add_rows2_kernel(const float4* x, float4* e1, const float4* e2, float4* out, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 a = x[i], b = e1[i], c = e2[i];
+  const float4 pe = make_float4(b.x + c.x, b.y + c.y, b.z + c.z, b.w + c.w);
+  e1[i] = pe;
+  out[i] = make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, a.w + pe.w);
+}
+__global__ __launch_bounds__(256) void add_rows2_bf16_kernel(const uint4* x, float4* e1, const float4* e2, uint4* out, long n8) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 a = x[i];
+  float4 b0 = e1[2 * i], b1 = e1[2 * i + 1];
+  const float4 c0 = e2[2 * i], c1 = e2[2 * i + 1];
+  b0 = make_float4(b0.x + c0.x, b0.y + c0.y, b0.z + c0.z, b0.w + c0.w);
+  b1 = make_float4(b1.x + c1.x, b1.y + c1.y, b1.z + c1.z, b1.w + c1.w);
+  e1[2 * i] = b0;
+  e1[2 * i + 1] = b1;
+  auto lo = [](uint32_t w) { return __uint_as_float(w << 16); };
+  auto hi = [](uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); };
+  auto pk = [](float u, float v) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 o = {(__bf16)u, (__bf16)v};
+    return __builtin_bit_cast(uint32_t, o);
+  };
+  uint4 o;
+  o.x = pk(lo(a.x) + b0.x, hi(a.x) + b0.y);
+  o.y = pk(lo(a.y) + b0.z, hi(a.y) + b0.w);
+  o.z = pk(lo(a.z) + b1.x, hi(a.z) + b1.y);
+  o.w = pk(lo(a.w) + b1.z, hi(a.w) + b1.w);
+  out[i] = o;
+}
+
+extern "C" int petr_add_rows2(const float* x, float* e1, const float* e2, float* out, long M, int C, void* stream) {
+  PETR_CHECK(x && e1 && e2 && out && M > 0 && C > 0 && (C & 3) == 0 && aligned16(x) && aligned16(e1) && aligned16(e2) && aligned16(out),
+             PETR_ERR_INVALID, "add_rows2: bad argument");
+  const long n4 = M * C / 4;
+  hipLaunchKernelGGL(add_rows2_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)e1,
+                     (const float4*)e2, (float4*)out, n4);
+  PETR_LAUNCH_CHECK("add_rows2");
+  return PETR_OK;
+}
+
+extern "C" int petr_add_rows2_bf16(const uint16_t* x, float* e1, const float* e2, uint16_t* out, long M, int C, void* stream) {
+  PETR_CHECK(x && e1 && e2 && out && M > 0 && C > 0 && (C & 7) == 0 && aligned16(x) && aligned16(e1) && aligned16(e2) && aligned16(out),
+             PETR_ERR_INVALID, "add_rows2_bf16: bad argument");
+  const long n8 = M * C / 8;
+  hipLaunchKernelGGL(add_rows2_bf16_kernel, dim3((unsigned)cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (float4*)e1,
+                     (const float4*)e2, (uint4*)out, n8);
+  PETR_LAUNCH_CHECK("add_rows2_bf16");
+  return PETR_OK;
+}
+
 extern "C" int petr_gate_fwd(const float* x, const float* u, float* out, long n, void* stream) {
   PETR_CHECK(x && u && out && n > 0, PETR_ERR_INVALID, "gate_fwd: bad argument");
   hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, u, out, n);

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the PETR_* switches only act on a tuning build: scripts/ab_build.sh tune -DPETR_TUNING_ENV; export PETR_HIP_LIB=.../libpetr_hip_tune.so)
 # same-box A/B of several "VAR=value" settings (each given as one quoted argument, may hold several assignments),
 # interleaved over 3 rounds, medians printed: scripts/ab_multi.sh "wl:dtype ..." "A=1" "A=0" "A=1 B=0" ...
 CFGS=$1; shift

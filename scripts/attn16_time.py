@@ -33,10 +33,7 @@ for drop in (None, (1, 2, 0.1)):
     o, lse = ops.mha_fwd_bf16(q, kb, vb, drop=drop)
     o = o.permute(0, 2, 1, 3).contiguous().view(1, Q, 8, 32).permute(0, 2, 1, 3)
     print(f'L={L} drop={drop is not None}: fwd16 {t(lambda: ops.mha_fwd_bf16(q, kb, vb, drop=drop)):.1f} us (incl. alloc)', end='')
-    for kt in ('81', '42'):
-        os.environ['PETR_MHA_BWD16_SHAPE'] = kt
-        for qs in ('1', '2'):
-            os.environ['PETR_MHA_BWD16_QSPLITS'] = qs
-            print(f'  bwd16[kt{kt},qs{qs}] {t(lambda: ops.mha_bwd_bf16(q, kb, vb, o, do, lse, drop=drop)):.1f}', end='')
-    of, lsef = ops.mha_fwd(q, kf, vf, drop=drop)
-    print(f'  | fp32 fwd {t(lambda: ops.mha_fwd(q, kf, vf, drop=drop)):.1f} bwd {t(lambda: ops.mha_bwd(q, kf, vf, of, do, lsef, drop=drop)):.1f}')
+    print(f'  bwd16 {t(lambda: ops.mha_bwd_bf16(q, kb, vb, o, do, lse, drop=drop)):.1f}', end='')
+    print(f'  fwd32 {t(lambda: ops.mha_fwd(q, kf, vf, drop=drop)):.1f}  bwd32 ', end='')
+    o32, lse32 = ops.mha_fwd(q, kf, vf, drop=drop)
+    print(f'{t(lambda: ops.mha_bwd(q, kf, vf, o32, do, lse32, drop=drop)):.1f} us')

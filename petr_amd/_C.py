@@ -293,6 +293,7 @@ def lib():
         raise PetrHipError(f'{LIB_PATH} is stale: missing exports {missing}; rebuild it')
     L.petr_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     L.petr_ctx_destroy.argtypes = [C.c_void_p]
+    L.petr_ctx_side_stream.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.petr_ctx_join_into.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.petr_head_layout.argtypes = [C.POINTER(HeadConfig), C.POINTER(HeadLayout)]
     L.petr_head_workspace_bytes.argtypes = [C.POINTER(HeadConfig)]
@@ -318,7 +319,7 @@ EXPORTS = [
     'petr_mha_bwd', 'petr_mha_bwd_bf16_workspace_bytes', 'petr_mha_bwd_bf16', 'petr_bbox_epilogue_fwd', 'petr_bbox_epilogue_bwd', 'petr_fill', 'petr_axpy', 'petr_add_rows', 'petr_gate_fwd', 'petr_gate_bwd', 'petr_prof_begin', 'petr_prof_end',
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
-    'petr_ctx_create', 'petr_ctx_destroy', 'petr_ctx_join_into', 'petr_dropout_mask', 'petr_dropout_bits_words', 'petr_dropout_bits', 'petr_loss_workspace_bytes', 'petr_loss_fwd_bwd',
+    'petr_ctx_create', 'petr_ctx_destroy', 'petr_ctx_join_into', 'petr_ctx_side_stream', 'petr_dropout_mask', 'petr_dropout_bits_words', 'petr_dropout_bits', 'petr_loss_workspace_bytes', 'petr_loss_fwd_bwd',
     'petr_decode_boxes', 'petr_decode_topk', 'petr_fpn_upsample_add', 'petr_wgrad_grouped', 'petr_fpn_upsample_add_bwd', 'petr_nchw_to_padded_nhwc', 'petr_add_rows2', 'petr_add_rows2_bf16',
 ]
 

@@ -164,6 +164,12 @@ extern "C" int petr_ctx_join_into(petr_ctx* c, void* main_stream, void* target_s
   return PETR_OK;
 }
 
+extern "C" int petr_ctx_side_stream(petr_ctx* c, int i, void** stream) {
+  PETR_CHECK(c && stream && i >= 0 && i < c->n_side, PETR_ERR_INVALID, "ctx_side_stream: bad argument");
+  *stream = (void*)c->side[i];
+  return PETR_OK;
+}
+
 extern "C" int petr_ctx_destroy(petr_ctx* c) {
   if (!c) return PETR_OK;
   for (int i = 0; i < c->n_side; ++i) (void)hipStreamDestroy(c->side[i]);

@@ -516,6 +516,17 @@ class PETRHead(nn.Module):
         _C.check(L.petr_head_fwd(C.byref(run.cfg), C.byref(io), stream), 'petr_head_fwd')
         return run.cls, run.bbox
 
+    def side_stream(self, i=1):
+        """Side stream ``i`` of this head's stream context as a ``torch.cuda.ExternalStream`` (None without a context): the
+        gradient exchange rides on it instead of opening one more stream (HIP multiplexes streams onto 4 hardware queues)."""
+        ctx = self._context()
+        if ctx is None:
+            return None
+        h = C.c_void_p()
+        if _C.lib().petr_ctx_side_stream(ctx, int(i), C.byref(h)) != 0:
+            return None
+        return torch.cuda.ExternalStream(h.value, device=self._flat.device)
+
     def join_streams_into(self, target_stream):
         """Make ``target_stream`` (a torch.cuda.Stream) wait for everything this head has enqueued so far on the
         current stream and on its side streams (petr_ctx_join_into): used by the gradient exchange between backward

@@ -250,6 +250,44 @@ def extra_workload(workload, dev, num_query, steps, warmup):
     return res
 
 
+def neck_fold_leg(dev, num_query, steps):
+    """SURVEY 8(f) rank 4, inference: backbone maps -> CPFPN -> PETRHead.forward at the maps of BASELINE configs[3]
+    (petr_vovnet_gridmask_p4_1600x640.py:38-42: 768 / 1024 channels at 40x100 / 20x50, six views), once as the reference
+    composes it (3x3 output conv -> NCHW map -> input_proj) and once with input_proj folded into the 3x3 conv
+    (CPFPN.forward_folded -> PETRHead.forward_projected)."""
+    import petr_amd
+    torch.manual_seed(0)
+    neck = petr_amd.build_neck(dict(type='CPFPN', in_channels=[768, 1024], out_channels=256, num_outs=2))
+    neck.init_weights()
+    neck = neck.to(dev).eval()
+    head = petr_amd.build_head(petr_amd.petr_head_cfg(num_query=num_query)).to(dev).eval()
+    metas = synthetic_metas(1, 6, (640, 1600), seed=0)
+    g = torch.Generator().manual_seed(77)
+    xs = [torch.randn(6, 768, 40, 100, generator=g).to(dev), torch.randn(6, 1024, 20, 50, generator=g).to(dev)]
+
+    def plain():
+        head(petr_amd.glue.reshape_backbone_feats(list(neck(xs)), 1), metas)
+
+    def folded():
+        head.forward_projected(neck.forward_folded(xs, head).view(1, 6, 40, 100, 256), metas)
+
+    res = {'what': 'inference forward, backbone maps (6 x 768 x 40 x 100, 6 x 1024 x 20 x 50) -> CPFPN -> PETRHead, ms per sample'}
+    with torch.no_grad():
+        for dt in ('fp32', 'bf16'):
+            head.attn_dtype = dt
+            for name, fn in (('neck_then_input_proj', plain), ('input_proj_folded', folded)):
+                for _ in range(5):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    fn()
+                torch.cuda.synchronize()
+                res[f'{name}_{dt}_ms'] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+    head.release()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -572,6 +610,10 @@ def main():
             workloads[name] = extra_workload(name, dev, Q, steps=min(args.steps, 20), warmup=min(max(args.warmup, 3), 5))
             log(f'workload {name}: fp32 {workloads[name]["fp32"]["ms_per_step"]} ms/step, '
                 f'bf16 {workloads[name]["bf16"]["ms_per_step"]} ms/step')
+    neck_leg = None
+    if workloads is not None:
+        neck_leg = neck_fold_leg(dev, Q, steps=min(args.steps, 20))
+        log(f'neck fold leg: {neck_leg}')
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, B, Q, train=was_training)
@@ -598,7 +640,7 @@ def main():
             'step_frac_of_peak': None if args.fwd_only else round(step_gflop(args.workload, B) / ms_step / peak, 4),
             'sustained': sustained,
             'roofline': roofline, 'kernels': kernels, 'cpu_baseline': cpu, 'with_loss': loss_leg,
-            'bf16': bf16_leg, 'workloads': workloads,
+            'bf16': bf16_leg, 'workloads': workloads, 'neck_fold': neck_leg,
         }
         if cpu and fwd_ms:
             out['fwd_speedup_vs_cpu'] = round((B / (fwd_ms * 1e-3)) / cpu['fwd_value'], 1)

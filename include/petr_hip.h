@@ -661,6 +661,10 @@ typedef struct {
                                  * bf16 and the cross-attention runs petr_mha_fwd_bf16 / petr_mha_bwd_bf16; parameters,
                                  * gradients, softmax, LayerNorm and the query-sized work stay fp32.  petr_head_bwd must
                                  * get the forward's value */
+  const float* memory_in;       /* NULL, or the PROJECTED memory [B, N*H*W, C] (token-major, fp32) made upstream - a neck whose
+                                 * last conv absorbed input_proj (cp_fpn.py:190-192 followed by petr_head.py:390 is one 3x3 conv
+                                 * with weights W_proj W_3x3): petr_head_fwd then skips input_proj and never reads `feats` (may be
+                                 * NULL).  Inference only: the fold has no separate input_proj gradient, petr_head_bwd refuses. */
 } petr_head_io;
 size_t petr_head_workspace_bytes(const petr_head_config* cfg);
 int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io, void* stream);

@@ -216,7 +216,8 @@ class HeadIO(C.Structure):
                        ('dim_t', C.c_void_p), ('mask', C.c_void_p), ('time_div', C.c_float),
                        ('all_cls_scores', C.c_void_p), ('all_bbox_preds', C.c_void_p),
                        ('ws', C.c_void_p), ('ws_bytes', C.c_size_t), ('ctx', C.c_void_p),
-                       ('dropout_p', C.c_float), ('dropout_seed', C.c_uint64), ('attn_bf16', C.c_int))
+                       ('dropout_p', C.c_float), ('dropout_seed', C.c_uint64), ('attn_bf16', C.c_int),
+                       ('memory_in', C.c_void_p))
 
 
 class HeadGrads(C.Structure):

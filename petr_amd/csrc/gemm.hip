@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const petr_gemm_args g, const
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn0 + j * 32 + c;
     const int nc = min(n, g.N - 1);                 // clamped for loads; stores are predicated
-    const float bv = bias ? bias[nc] : 0.f;
+    const float bv = (bias && !(flags & PETR_GEMM_BIAS_M)) ? bias[nc] : 0.f;   // BIAS_M: the vector has M entries, not N
     const long ccol = g.c_nblk > 0 ? (long)(nc / g.c_nblk) * g.c_nblk_stride + (nc % g.c_nblk) : (long)nc;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {

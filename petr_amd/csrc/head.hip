@@ -825,7 +825,7 @@ extern "C" int petr_head_bwd_stage_range(const petr_head_config* cfg, int stage,
 // =============================================================================================
 extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io, void* stream) {
   RUN(check_config(cfg));
-  PETR_CHECK(io && io->params && io->feats && io->img2lidar && io->depth && io->dim_t && io->all_cls_scores &&
+  PETR_CHECK(io && io->params && (io->feats || io->memory_in) && io->img2lidar && io->depth && io->dim_t && io->all_cls_scores &&
                  io->all_bbox_preds && io->ws,
              PETR_ERR_INVALID, "head_fwd: null pointer");
   PETR_CHECK(!cfg->has_mask || io->mask, PETR_ERR_INVALID, "head_fwd: has_mask without a mask");
@@ -836,8 +836,10 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   build_ws(cfg, &W, nullptr);
   PETR_CHECK(io->ws_bytes >= (size_t)W.total * sizeof(float), PETR_ERR_WORKSPACE, "head_fwd: workspace %zu < %zu bytes",
              io->ws_bytes, (size_t)W.total * sizeof(float));
-  PETR_CHECK(aligned16(io->params) && aligned16(io->ws) && aligned16(io->feats), PETR_ERR_INVALID,
-             "head_fwd: params / ws / feats must be 16-byte aligned");
+  PETR_CHECK(aligned16(io->params) && aligned16(io->ws) && aligned16(io->feats) && aligned16(io->memory_in), PETR_ERR_INVALID,
+             "head_fwd: params / ws / feats / memory_in must be 16-byte aligned");
+  PETR_CHECK(!io->memory_in || !(io->dropout_p > 0.f), PETR_ERR_UNSUPPORTED,
+             "head_fwd: memory_in (input_proj folded into the producer) is an inference path; dropout_p must be 0");
   const float* Pm = io->params;
   float* Wm = (float*)io->ws;
   const int C = d.C;
@@ -905,13 +907,19 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   // ---- side 2: input_proj (petr_head.py:390) + sine 3D (positional_encoding.py:58-100) + adapt_pos3d hidden ----
   {
     petr_gemm_args g = gemm0();   // NCHW view [C_in][HW] read as an M-contiguous operand -> token-major memory
-    g.a = io->feats; g.lda = d.HW; g.a_kcontig = 0; g.a_bs0 = (long)d.Cin * d.HW;
-    g.b = Wp(P.in_w); g.ldb = d.Cin; g.b_kcontig = 1;
-    g.c = Wm + W.mem; g.ldc = C; g.c_bs0 = (long)d.HW * C; g.bias = Pm + P.in_b;
-    g.M = d.HW; g.N = C; g.K = d.Cin; g.nb0 = V;
-    if (bf16_km(g)) g.flags |= PETR_GEMM_BF16;
-    if (tok16) g.flags |= wflag | PETR_GEMM_STORE_BF16;         // memory as bf16
-    RUN(petr_gemm(&g, s2));
+    if (io->memory_in) {          // input_proj already applied by the producer (petr_hip.h): take its tokens as they are
+      if (tok16) RUN(petr_cast_bf16(io->memory_in, mem16, d.BL * C, s2));
+      else PETR_CHECK(hipMemcpyAsync(Wm + W.mem, io->memory_in, (size_t)d.BL * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)s2) == hipSuccess,
+                      PETR_ERR_LAUNCH, "head_fwd: copy of memory_in failed");
+    } else {
+      g.a = io->feats; g.lda = d.HW; g.a_kcontig = 0; g.a_bs0 = (long)d.Cin * d.HW;
+      g.b = Wp(P.in_w); g.ldb = d.Cin; g.b_kcontig = 1;
+      g.c = Wm + W.mem; g.ldc = C; g.c_bs0 = (long)d.HW * C; g.bias = Pm + P.in_b;
+      g.M = d.HW; g.N = C; g.K = d.Cin; g.nb0 = V;
+      if (bf16_km(g)) g.flags |= PETR_GEMM_BF16;
+      if (tok16) g.flags |= wflag | PETR_GEMM_STORE_BF16;         // memory as bf16
+      RUN(petr_gemm(&g, s2));
+    }
     petr_sine3d_args b;
     memset(&b, 0, sizeof b);
     b.mask = kpm; b.dim_t = io->dim_t; b.out = Wm + W.sine; b.B = d.B; b.N = d.N; b.H = d.H; b.W = d.W; b.F = C / 2;
@@ -1249,6 +1257,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
 extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io, const petr_head_grads* gr,
                              int stage_begin, int stage_end, void* stream) {
   RUN(check_config(cfg));
+  PETR_CHECK(!(io && io->memory_in), PETR_ERR_UNSUPPORTED, "head_bwd: the forward ran on memory_in (folded input_proj): inference only");
   PETR_CHECK(io && io->params && io->feats && io->ws && io->all_bbox_preds && gr && gr->d_cls && gr->d_bbox && gr->d_params,
              PETR_ERR_INVALID, "head_bwd: null pointer");
   const Dims d = make_dims(cfg);

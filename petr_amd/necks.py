@@ -104,8 +104,69 @@ class CPFPN(nn.Module):
         params += [self.fpn_convs[0].conv.weight, self.fpn_convs[0].conv.bias]
         return _CPFPNFunction.apply(self, len(xs), *xs, *params)
 
+    # ------------------------------------------------------------------ inference: the head's input_proj folded into the 3x3 conv
+    def _folded_w3(self, head):
+        """input_proj(conv3x3(x)) = one 3x3 conv: W' = W_proj W_3 ([out', out] x [out, c, dy, dx]), b' = W_proj b_3 + b_proj
+        (cp_fpn.py:190-192 followed by petr_head.py:390; valid because the reference puts no norm / activation between them).
+        Formed once per weight version in float64 on the host, packed [dy][out'][dx*C + c] like the unfolded weights."""
+        w3, b3 = self.fpn_convs[0].conv.weight, self.fpn_convs[0].conv.bias
+        wp, bp = head.input_proj.weight, head.input_proj.bias
+        key = tuple((t.data_ptr(), t._version) for t in (w3, b3, wp, bp)) + (w3.device,)
+        cached = getattr(self, '_folded', None)
+        if cached is None or cached[0] != key:
+            C_ = self.out_channels
+            Ch = wp.shape[0]
+            assert wp.shape[1] == C_, f'input_proj expects {wp.shape[1]} channels, the neck produces {C_}'
+            wp64 = wp.detach().double().cpu().view(Ch, C_)
+            wf = (wp64 @ w3.detach().double().cpu().view(C_, -1)).view(Ch, C_, 3, 3)
+            bf = wp64 @ b3.detach().double().cpu() + bp.detach().double().cpu()
+            packed = wf.permute(2, 0, 3, 1).contiguous().view(3, Ch, 3 * C_).float().to(w3.device)
+            self._folded = (key, packed, bf.float().to(w3.device))
+        return self._folded[1], self._folded[2]
+
+    def forward_folded(self, inputs, head):
+        """Inference path of SURVEY §8(f) rank 4: level 0 of the neck with ``head.input_proj`` folded into the 3x3 output conv,
+        written token-major.  Returns the head's projected memory ``[V, H, W, embed_dims]`` (V = B * N views; reshape to
+        ``[B, N, H, W, C]`` for ``PETRHead.forward_projected``): the NCHW map of level 0 and the 1x1 contraction over it - one
+        full feature-map round trip - do not exist.  No gradient (the fold has no separate parameters)."""
+        assert len(inputs) == len(self.in_channels)
+        if self.start_level != 0 or head.position_level != 0:
+            raise _C.PetrHipError('forward_folded: the 3x3 output conv belongs to backbone level 0 (cp_fpn.py:128) = position_level 0')
+        xs = [inputs[i + self.start_level].detach() for i in range(len(self.lateral_convs))]
+        for x in xs:
+            if not x.is_cuda or x.dtype != torch.float32:
+                raise _C.PetrHipError('CPFPN.forward_folded expects fp32 CUDA maps; there is no CPU fallback')
+        C_ = self.out_channels
+        wf, bf = self._folded_w3(head)
+        Ch = wf.shape[1]
+        with torch.no_grad():
+            _, pad = self._laterals_topdown(xs)
+            V, Hp, Wp_, _ = pad.shape
+            H, W = Hp - 2, Wp_ - 2
+            mem = torch.empty((V, H, W, Ch), dtype=torch.float32, device=pad.device)
+            ops.gemm_raw(a=pad, lda=C_, a_kcontig=1, a_bs0=(H + 2) * (W + 2) * C_, a_bs1=(W + 2) * C_, b=wf, ldb=3 * C_, b_kcontig=1,
+                         c=mem, ldc=Ch, c_bs0=H * W * Ch, c_bs1=W * Ch, bias=bf, M=W, N=Ch, K=9 * C_, nb0=V, nb1=H, k_seg=3 * C_,
+                         a_seg_stride=(W + 2) * C_, b_seg_stride=Ch * 3 * C_, flags=0, alpha=1.0)
+        return mem
+
     # ------------------------------------------------------------------ forward arithmetic (libpetr_hip.so)
     def _forward_impl(self, xs):
+        C_ = self.out_channels
+        V = xs[0].shape[0]
+        dev = xs[0].device
+        lat, pad = self._laterals_topdown(xs)
+        H, W = pad.shape[1] - 2, pad.shape[2] - 2
+        # 3x3 output conv of level 0 (cp_fpn.py:190-192): one contraction, K = 9*C in three kernel-row segments
+        w3 = self._packed_w3()
+        conv3 = self.fpn_convs[0].conv
+        out0 = torch.empty((V, C_, H, W), dtype=torch.float32, device=dev)
+        ops.gemm_raw(a=w3, lda=3 * C_, a_kcontig=1, b=pad, ldb=C_, b_kcontig=1, b_bs0=(H + 2) * (W + 2) * C_, b_bs1=(W + 2) * C_,
+                     c=out0, ldc=H * W, c_bs0=C_ * H * W, c_bs1=W, bias=conv3.bias.detach(), M=C_, N=W, K=9 * C_, nb0=V, nb1=H,
+                     k_seg=3 * C_, a_seg_stride=C_ * 3 * C_, b_seg_stride=(W + 2) * C_, flags=_C.GEMM_BIAS_M, alpha=1.0)
+        return [out0] + lat[1:], pad
+
+    def _laterals_topdown(self, xs):
+        """lateral 1x1 convs + top-down adds: (lat list with lat[0] = None, zero-bordered channels-last level-0 map)."""
         C_ = self.out_channels
         dev = xs[0].device
         V = xs[0].shape[0]
@@ -140,14 +201,7 @@ class CPFPN(nn.Module):
                 Hd, Wd = lat[i - 1].shape[2:]
                 _C.check(L.petr_fpn_upsample_add(lat[i - 1].data_ptr(), C_ * Hd * Wd, Hd * Wd, Wd, 1, lat[i].data_ptr(), V, C_,
                                                  Hd, Wd, Hs, Ws, ops._stream()), 'petr_fpn_upsample_add')
-        # 3x3 output conv of level 0 (cp_fpn.py:190-192): one contraction, K = 9*C in three kernel-row segments
-        w3 = self._packed_w3()
-        conv3 = self.fpn_convs[0].conv
-        out0 = torch.empty((V, C_, H, W), dtype=torch.float32, device=dev)
-        ops.gemm_raw(a=w3, lda=3 * C_, a_kcontig=1, b=pad, ldb=C_, b_kcontig=1, b_bs0=(H + 2) * (W + 2) * C_, b_bs1=(W + 2) * C_,
-                     c=out0, ldc=H * W, c_bs0=C_ * H * W, c_bs1=W, bias=conv3.bias.detach(), M=C_, N=W, K=9 * C_, nb0=V, nb1=H,
-                     k_seg=3 * C_, a_seg_stride=C_ * 3 * C_, b_seg_stride=(W + 2) * C_, flags=_C.GEMM_BIAS_M, alpha=1.0)
-        return [out0] + lat[1:], pad
+        return lat, pad
 
     # ------------------------------------------------------------------ backward arithmetic (libpetr_hip.so)
     def _backward_impl(self, xs, pad, grads, need_dx):

@@ -378,9 +378,13 @@ class PETRHead(nn.Module):
                     p.grad = gv
 
     # ------------------------------------------------------------------ host-side input preparation
-    def _prepare(self, feats, img_metas):
-        B, N, Cin, H, W = feats.shape
-        assert Cin == self.in_channels, f'expected {self.in_channels} input channels, got {Cin}'
+    def _prepare(self, feats, img_metas, projected=False):
+        if projected:       # feats = the projected memory [B, N, H, W, C] (forward_projected)
+            B, N, H, W, Cm = feats.shape
+            assert Cm == self.embed_dims, f'expected {self.embed_dims} memory channels, got {Cm}'
+        else:
+            B, N, Cin, H, W = feats.shape
+            assert Cin == self.in_channels, f'expected {self.in_channels} input channels, got {Cin}'
         assert len(img_metas) == B
         pad_h, pad_w, _ = img_metas[0]['pad_shape'][0]
         mask_np = padding_mask_closed_form(img_metas, N, (H, W))
@@ -470,11 +474,11 @@ class PETRHead(nn.Module):
         ts = np.asarray([np.asarray(m['timestamp']) for m in img_metas], dtype=np.float32).reshape(batch_size, -1, 6)
         return float((ts[:, 1, :] - ts[:, 0, :]).mean(-1)[0])
 
-    def _launch_forward(self, run, feats):
+    def _launch_forward(self, run, feats, projected=False):
         with torch.cuda.device(self._flat.device):       # streams / side streams of the head's own device
-            return self._launch_forward_impl(run, feats)
+            return self._launch_forward_impl(run, feats, projected)
 
-    def _launch_forward_impl(self, run, feats):
+    def _launch_forward_impl(self, run, feats, projected=False):
         L = _C.lib()
         B, N = run.cfg.B, run.cfg.N
         run.feats = feats.contiguous()
@@ -482,7 +486,8 @@ class PETRHead(nn.Module):
         run.bbox = torch.empty((self._nl, B, self.num_query, self.code_size), dtype=torch.float32, device=feats.device)
         io = _C.HeadIO()
         io.params = self._flat.data_ptr()
-        io.feats = run.feats.data_ptr()
+        io.feats = None if projected else run.feats.data_ptr()
+        io.memory_in = run.feats.data_ptr() if projected else None
         io.img2lidar = run.img2lidar.data_ptr()
         io.depth = self._depth.data_ptr()
         io.dim_t = self._dim_t.data_ptr()
@@ -598,6 +603,24 @@ class PETRHead(nn.Module):
         else:
             cls, bbox = self._launch_forward(run, x)
             self._free_ws[run.key].append(run.ws)     # stream-ordered reuse: the next forward runs after this one
+        self._last_run = run
+        return {'all_cls_scores': cls, 'all_bbox_preds': bbox, 'enc_cls_scores': None, 'enc_bbox_preds': None}
+
+    def forward_projected(self, memory, img_metas):
+        """Inference entry for a producer that already applied ``input_proj`` ("fusing [the neck's] last
+        conv with input_proj removes one full feature-map round trip"; ``CPFPN.forward_folded``): ``memory`` is the projected
+        map, channels-last ``[B, N, H, W, embed_dims]`` fp32 = the token order of reference petr_transformer.py:90.  Everything
+        behind petr_head.py:390 is the ordinary forward; there is no gradient through this entry (``eval()`` only)."""
+        if not memory.is_cuda or memory.dtype != torch.float32:
+            raise _C.PetrHipError('PETRHead.forward_projected expects an fp32 CUDA tensor [B, N, H, W, C]')
+        if self.training:
+            raise _C.PetrHipError('PETRHead.forward_projected is an inference path (the folded conv has no input_proj gradient): call eval()')
+        self._ensure_flat()
+        run = self._prepare(memory, img_metas, projected=True)
+        run.time_div = self._time_div(img_metas, memory.shape[0])
+        with torch.no_grad():
+            cls, bbox = self._launch_forward(run, memory, projected=True)
+        self._free_ws[run.key].append(run.ws)
         self._last_run = run
         return {'all_cls_scores': cls, 'all_bbox_preds': bbox, 'enc_cls_scores': None, 'enc_bbox_preds': None}
 

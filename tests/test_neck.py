@@ -169,3 +169,66 @@ def test_cpfpn_into_head_training_step_gpu():
         assert x.grad is not None and torch.isfinite(x.grad).all() and x.grad.abs().max().item() > 0
     for n, p in neck.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max().item() > 0, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('chans,sizes,pad_hw,attn_dtype', [([768, 1024], [(40, 100), (20, 50)], (640, 1600), 'fp32'),
+                                                           ([768, 1024], [(40, 100), (20, 50)], (640, 1600), 'bf16'),
+                                                           ([1024, 2048], [(32, 88), (16, 44)], (512, 1408), 'fp32'),
+                                                           ([96, 128], [(20, 50), (10, 25)], (320, 800), 'fp32')])
+def test_cpfpn_folded_input_proj_gpu(chans, sizes, pad_hw, attn_dtype):
+    """SURVEY 8(f)-4's fold (cp_fpn.py:190-192 followed by petr_head.py:390 as ONE 3x3 conv, token-major output): the
+    projected memory equals what neck -> head.input_proj produces, and so do the head's outputs; the oracle composition
+    (float64 conv3x3 then conv1x1) checks the memory independently."""
+    import petr_amd
+    from oracle import petr_oracle as O
+    torch.manual_seed(5)
+    neck = petr_amd.build_neck(dict(type='CPFPN', in_channels=chans, out_channels=256, num_outs=2))
+    neck.init_weights()
+    with torch.no_grad():
+        for m in neck.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                m.bias.uniform_(-0.1, 0.1)                     # the fold must carry W_proj b_3 + b_proj
+    head = petr_amd.build_head(petr_amd.petr_head_cfg(num_query=100))
+    with torch.no_grad():
+        head.input_proj.bias.uniform_(-0.1, 0.1)
+    g = torch.Generator().manual_seed(11)
+    V = 6
+    inputs = [torch.randn(V, c, h, w, generator=g) for c, (h, w) in zip(chans, sizes)]
+    with torch.no_grad():       # float64 composition through the pinned restatement
+        sd64 = {k: v.double() for k, v in neck.state_dict().items()}
+        lvl0 = NO.cpfpn_forward(sd64, [x.double() for x in inputs])[0]
+        want_mem = torch.nn.functional.conv2d(lvl0, head.input_proj.weight.double(), head.input_proj.bias.double()).permute(0, 2, 3, 1)
+    neck, head = neck.cuda().eval(), head.cuda().eval()
+    head.attn_dtype = attn_dtype
+    metas = O.synthetic_img_metas(1, V, pad_hw, seed=4)
+    xs = [x.cuda() for x in inputs]
+    mem = neck.forward_folded(xs, head)
+    H, W = sizes[0]
+    assert mem.shape == (V, H, W, 256)
+    err = (mem.cpu().double() - want_mem).abs().max().item() / want_mem.abs().max().item()
+    assert err < 2e-5, err
+    with torch.no_grad():
+        ref = head(petr_amd.glue.reshape_backbone_feats(list(neck(xs)), 1), metas)
+        ref_mem = head.workspace_view('memory').clone()
+        got = head.forward_projected(mem.view(1, V, H, W, 256), metas)
+        got_mem = head.workspace_view('memory').clone()
+    if attn_dtype == 'fp32':
+        assert (got_mem - ref_mem).abs().max().item() <= 2e-5 * ref_mem.abs().max().item()
+    tol = 2e-4 if attn_dtype == 'fp32' else 3e-2           # bf16 mode: memory is rounded to bf16 on both routes, from values 1e-6 apart
+    for k in ('all_cls_scores', 'all_bbox_preds'):
+        d = (got[k] - ref[k]).abs().max().item()
+        assert d <= tol * max(1.0, ref[k].abs().max().item()), (k, d)
+    # a changed weight re-folds
+    with torch.no_grad():
+        head.input_proj.weight.mul_(0.5)
+        head._ensure_flat()
+    mem2 = neck.forward_folded(xs, head)
+    with torch.no_grad():
+        want2 = torch.nn.functional.conv2d(lvl0, head.input_proj.weight.detach().cpu().double(), head.input_proj.bias.detach().cpu().double()).permute(0, 2, 3, 1)
+    assert (mem2.cpu().double() - want2).abs().max().item() / want2.abs().max().item() < 2e-5
+    # inference only: refused in train mode, and no gradient is recorded
+    assert not got['all_cls_scores'].requires_grad
+    head.train()
+    with pytest.raises(RuntimeError, match='inference path'):
+        head.forward_projected(mem.view(1, V, H, W, 256), metas)

@@ -686,6 +686,29 @@ int petr_head_bwd_stage_range(const petr_head_config* cfg, int stage, long* begi
 int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io, const petr_head_grads* g,
                   int stage_begin, int stage_end, void* stream);
 
+/* One prediction branch of the head in ONE launch (SURVEY K10 "branches as one kernel"; reference petr_head.py:226-247 builds
+ * `cls_branches` = (Linear, LayerNorm, ReLU) x 2 + Linear and `reg_branches` = (Linear, ReLU) x 2 + Linear, applied to every
+ * decoder level at :440-460): y1 = act(x W1^T + b1), y2 = act(y1 W2^T + b2), out = y2 W3^T + b3 with act = ReLU(LayerNorm(.))
+ * when g1 / g2 are given (class branch) and ReLU otherwise (box branch).  A workgroup owns 32 rows for the whole chain: the two
+ * 256 x 256 products stream their k-major weights (w1t / w2t: TRANSPOSED copies [in][out]) past rows that never leave LDS, the
+ * last n_out-wide product (n_out <= 16; w3 in nn.Linear layout [n_out][256]; NULL: stop after y2 - PETRv2's RegLayer heads
+ * follow) is a dot product per output.  What the backward reads is written on the way when the pointer is given: h = pre-norm
+ * rows, y = activations, per-row mean / rstd.  `groups` > 1: PETRv2's deep-copied branches (petrv2_head.py:294-307) - group g
+ * owns rows [g rows, (g + 1) rows) and the parameters at + g * param_gs (transposed weights: + g * wt_gs).  C = 256 only.   */
+typedef struct {
+  const float* x;                                       /* [groups * rows, 256]                                    */
+  const float* w1t; const float* b1; const float* g1; const float* be1;
+  const float* w2t; const float* b2; const float* g2; const float* be2;
+  const float* w3; const float* b3;
+  long param_gs, wt_gs;
+  float* h1; float* y1; float* h2; float* y2;           /* optional [groups * rows, 256] each                      */
+  float* mean1; float* rstd1; float* mean2; float* rstd2;   /* optional [groups * rows] (class branch)             */
+  float* out; int n_out;                                /* [groups * rows, n_out]                                  */
+  int rows, groups;
+  float eps;                                            /* LayerNorm epsilon                                       */
+} petr_branch_fwd_args;
+int petr_branch_fwd(const petr_branch_fwd_args* a, void* stream);
+
 /* named views into the forward workspace, for tests and for the per-module Python API
  * ("memory", "pos_embed", "query_embed", "outs_dec", "coords3d", "sine", "k_all", "v_all", ...)   */
 int petr_head_ws_view(const petr_head_config* cfg, const char* name, long* offset_floats, long* numel);

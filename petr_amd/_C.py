@@ -141,6 +141,15 @@ class WgradItem(C.Structure):        # petr_wgrad_item
                        ('ldc', C.c_long), ('db', C.c_void_p), ('M', C.c_int), ('N', C.c_int), ('K', C.c_int), ('ksplit', C.c_int))
 
 
+class BranchFwdArgs(C.Structure):    # petr_branch_fwd_args
+    _fields_ = _fields(('x', C.c_void_p), ('w1t', C.c_void_p), ('b1', C.c_void_p), ('g1', C.c_void_p), ('be1', C.c_void_p),
+                       ('w2t', C.c_void_p), ('b2', C.c_void_p), ('g2', C.c_void_p), ('be2', C.c_void_p),
+                       ('w3', C.c_void_p), ('b3', C.c_void_p), ('param_gs', C.c_long), ('wt_gs', C.c_long),
+                       ('h1', C.c_void_p), ('y1', C.c_void_p), ('h2', C.c_void_p), ('y2', C.c_void_p),
+                       ('mean1', C.c_void_p), ('rstd1', C.c_void_p), ('mean2', C.c_void_p), ('rstd2', C.c_void_p),
+                       ('out', C.c_void_p), ('n_out', C.c_int), ('rows', C.c_int), ('groups', C.c_int), ('eps', C.c_float))
+
+
 class MhaBwdArgs(C.Structure):
     _fields_ = _fields(
         ('q', C.c_void_p), ('q_bs', C.c_long), ('q_hs', C.c_long), ('q_rs', C.c_long),
@@ -284,6 +293,7 @@ def lib():
     L.petr_add_rows2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
     L.petr_add_rows2_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
     L.petr_wgrad_grouped.argtypes = [C.POINTER(WgradItem), C.c_int, C.c_void_p]
+    L.petr_branch_fwd.argtypes = [C.POINTER(BranchFwdArgs), C.c_void_p]
     L.petr_fpn_upsample_add.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
     L.petr_axpy.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_long, C.c_void_p]
     L.petr_reduce_partials.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
@@ -321,7 +331,7 @@ EXPORTS = [
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
     'petr_ctx_create', 'petr_ctx_destroy', 'petr_ctx_join_into', 'petr_ctx_side_stream', 'petr_dropout_mask', 'petr_dropout_bits_words', 'petr_dropout_bits', 'petr_loss_workspace_bytes', 'petr_loss_fwd_bwd',
-    'petr_decode_boxes', 'petr_decode_topk', 'petr_fpn_upsample_add', 'petr_wgrad_grouped', 'petr_fpn_upsample_add_bwd', 'petr_nchw_to_padded_nhwc', 'petr_add_rows2', 'petr_add_rows2_bf16',
+    'petr_decode_boxes', 'petr_decode_topk', 'petr_fpn_upsample_add', 'petr_wgrad_grouped', 'petr_branch_fwd', 'petr_fpn_upsample_add_bwd', 'petr_nchw_to_padded_nhwc', 'petr_add_rows2', 'petr_add_rows2_bf16',
 ]
 
 

@@ -258,6 +258,7 @@ struct WOff {
   LayerW lay[8];
   long xs, mean_p, rstd_p, outs;
   long c1, c1_mean, c1_rstd, c1n, c2, c2_mean, c2_rstd, c2n, r1, r2, reg_raw;
+  long br_t;
   long th_h, pe1, fpe_h, fpe_u;          // PETRv2: task-head hiddens [G][5][RG,C]; SELayer buffers [BL,C]
   long d_th_h, d_pe1, d_fpe_h, d_fpe_u;
   long ffn_part; int ffn_split, ffn_fsplit;
@@ -432,6 +433,8 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
     t.sa_out = wb.add("wT_sa_out", (long)C * C);
     t.sa_in = wb.add("wT_sa_in", (long)C * 3 * C);
   }
+  // transposed copies of the two 256 x 256 weights of the class and the box branch, per branch group: [cls 0, cls 1, reg 0, reg 1]
+  W.br_t = wb.add("wT_branches", (long)(c->shared_branches ? 1 : d.NL) * 4 * C * C);
   W.d_mempos = wb.add("d_mempos", d.BL * C);
   W.d_mem = wb.add("d_mem", d.BL * C);
   W.d_hpe[0] = wb.add("d_hpe", d.BL * 4 * C);
@@ -644,7 +647,7 @@ static int mha_b_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, l
 // One batched transposition per backward (36 matrices, ~35 MB read + written, on a side stream beside the branch
 // backward) turns every decoder-layer input gradient into a forward-shaped contraction.
 struct TrEntry { const float* src; float* dst; long ld; int rows, cols, tile0; };     // dst[c][r] = src[r * ld + c]
-struct TrBatch { int n; TrEntry e[48]; };
+struct TrBatch { int n; TrEntry e[64]; };
 __global__ __launch_bounds__(256) void transpose_batch_kernel(const TrBatch b) {
   __shared__ float tile[32][33];
   int ei = 0;
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(const TrBatch b) {
 // forward and by the FFN input gradients), `rest` = the attention projections (read by the backward's input gradients)
 template <class PL, class WL>
 static int launch_weight_transposes(const float* Pm, float* Wm, const PL& P, const WL& W, int NL, int C, int F, bool ffn, bool rest,
-                                    hipStream_t st) {
+                                    hipStream_t st, int branch_groups = 0) {
   TrBatch tb;
   tb.n = 0;
   int tiles = 0;
@@ -691,6 +694,13 @@ static int launch_weight_transposes(const float* Pm, float* Wm, const PL& P, con
       add(Pm + lp.sa_out_w, t.sa_out, C, C);
       add(Pm + lp.sa_in_w, t.sa_in, 3 * C, C);
     }
+  }
+  for (int gi = 0; gi < branch_groups; ++gi) {      // petr_branch_fwd's k-major weights (forward only)
+    const long o = W.br_t + (long)gi * 4 * C * C, po = (long)gi * P.br_stride;
+    add(Pm + P.cls_w[0] + po, o, C, C);
+    add(Pm + P.cls_w[1] + po, o + (long)C * C, C, C);
+    add(Pm + P.reg_w[0] + po, o + (long)2 * C * C, C, C);
+    add(Pm + P.reg_w[1] + po, o + (long)3 * C * C, C, C);
   }
   if (!tiles) return PETR_OK;
   hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles), dim3(256), 0, st, tb);
@@ -903,7 +913,13 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   const bool ffn_fused = ffn_fused_env && !ffn16 && W.ffn_fsplit > 0;
   // the 16- / 32-row kernels (petr_attn_out_ln, petr_ln_proj, petr_ffn_fwd) stream their weights k-major: transposed copies of
   // the decoder weights, made here once per forward (the backward's input-gradient contractions read them too)
-  if (fwd_transposes(cfg, d, C)) RUN(launch_weight_transposes(Pm, Wm, P, W, d.NL, C, d.F, true, true, (hipStream_t)s));
+  // one launch per prediction branch (petr_branch_fwd) instead of contraction / LayerNorm chains (PETR_BRANCH_FUSED=0, diagnostic
+  // builds: the chains); same condition as the transposed decoder weights it shares the launch with
+  const int BG = cfg->shared_branches ? 1 : d.NL;
+  const bool branch_fused = fwd_transposes(cfg, d, C) && petr_tune("PETR_BRANCH_FUSED", 1) != 0 && d.ncls <= 16 && d.code <= 16 &&
+                            36 + 4 * BG <= 64;
+  if (fwd_transposes(cfg, d, C))
+    RUN(launch_weight_transposes(Pm, Wm, P, W, d.NL, C, d.F, true, true, (hipStream_t)s, branch_fused ? BG : 0));
   // ---- side 2: input_proj (petr_head.py:390) + sine 3D (positional_encoding.py:58-100) + adapt_pos3d hidden ----
   {
     petr_gemm_args g = gemm0();   // NCHW view [C_in][HW] read as an M-contiguous operand -> token-major memory
@@ -1200,16 +1216,31 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     return g;
   };
   ln.fork(0);
+  petr_branch_fwd_args br;
+  memset(&br, 0, sizeof br);
+  br.x = Wm + W.outs; br.param_gs = P.br_stride; br.wt_gs = (long)4 * C * C; br.rows = (int)RG; br.groups = G; br.eps = 1e-5f;
   {
-    petr_gemm_args g = grouped(lin_fwd(Wm + W.outs, Pm + P.reg_w[0], Pm + P.reg_b[0], Wm + W.r1, RG, C, C), C, C);
-    g.flags = PETR_GEMM_RELU;
-    RUN(petr_gemm(&g, s1));
-    g = grouped(lin_fwd(Wm + W.r1, Pm + P.reg_w[1], Pm + P.reg_b[1], Wm + W.r2, RG, C, C), C, C);
-    g.flags = PETR_GEMM_RELU;
-    RUN(petr_gemm(&g, s1));
-    if (!cfg->with_multi) {
-      g = grouped(lin_fwd(Wm + W.r2, Pm + P.reg_w[2], Pm + P.reg_b[2], Wm + W.reg_raw, RG, d.code, C), C, d.code);
+    petr_gemm_args g;
+    if (branch_fused) {       // (Linear, ReLU) x 2 [+ Linear]: r1, r2 are what the backward reads
+      petr_branch_fwd_args b = br;
+      b.w1t = Wm + W.br_t + (long)2 * C * C; b.b1 = Pm + P.reg_b[0];
+      b.w2t = Wm + W.br_t + (long)3 * C * C; b.b2 = Pm + P.reg_b[1];
+      b.y1 = Wm + W.r1; b.y2 = Wm + W.r2;
+      if (!cfg->with_multi) { b.w3 = Pm + P.reg_w[2]; b.b3 = Pm + P.reg_b[2]; b.out = Wm + W.reg_raw; b.n_out = d.code; }
+      RUN(petr_branch_fwd(&b, s1));
+    } else {
+      g = grouped(lin_fwd(Wm + W.outs, Pm + P.reg_w[0], Pm + P.reg_b[0], Wm + W.r1, RG, C, C), C, C);
+      g.flags = PETR_GEMM_RELU;
       RUN(petr_gemm(&g, s1));
+      g = grouped(lin_fwd(Wm + W.r1, Pm + P.reg_w[1], Pm + P.reg_b[1], Wm + W.r2, RG, C, C), C, C);
+      g.flags = PETR_GEMM_RELU;
+      RUN(petr_gemm(&g, s1));
+    }
+    if (!cfg->with_multi) {
+      if (!branch_fused) {
+        g = grouped(lin_fwd(Wm + W.r2, Pm + P.reg_w[2], Pm + P.reg_b[2], Wm + W.reg_raw, RG, d.code, C), C, d.code);
+        RUN(petr_gemm(&g, s1));
+      }
     } else {
       // RegLayer task heads (petrv2_head.py:81-95): 5 x (Linear, ReLU, Linear -> (2,1,3,2,2)), concatenated
       g = grouped(lin_fwd(Wm + W.r2, Pm + P.th_w1, Pm + P.th_b1, Wm + W.th_h, RG, C, C), C, 5 * C);
@@ -1231,7 +1262,15 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     a.time_div = cfg->with_time ? io->time_div : 0.f; a.eps = 1e-5f;
     RUN(petr_bbox_epilogue_fwd(&a, s1));
   }
-  {
+  if (branch_fused) {         // (Linear, LayerNorm, ReLU) x 2 + Linear: the class scores
+    petr_branch_fwd_args b = br;
+    b.w1t = Wm + W.br_t; b.b1 = Pm + P.cls_b[0]; b.g1 = Pm + P.cls_g[0]; b.be1 = Pm + P.cls_be[0];
+    b.w2t = Wm + W.br_t + (long)C * C; b.b2 = Pm + P.cls_b[1]; b.g2 = Pm + P.cls_g[1]; b.be2 = Pm + P.cls_be[1];
+    b.w3 = Pm + P.cls_w[2]; b.b3 = Pm + P.cls_b[2]; b.out = io->all_cls_scores; b.n_out = d.ncls;
+    b.h1 = Wm + W.c1; b.y1 = Wm + W.c1n; b.h2 = Wm + W.c2; b.y2 = Wm + W.c2n;
+    b.mean1 = Wm + W.c1_mean; b.rstd1 = Wm + W.c1_rstd; b.mean2 = Wm + W.c2_mean; b.rstd2 = Wm + W.c2_rstd;
+    RUN(petr_branch_fwd(&b, s));
+  } else {
     petr_gemm_args g = grouped(lin_fwd(Wm + W.outs, Pm + P.cls_w[0], Pm + P.cls_b[0], Wm + W.c1, RG, C, C), C, C);
     RUN(petr_gemm(&g, s));
     for (int gi = 0; gi < G; ++gi)

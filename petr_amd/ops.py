@@ -117,6 +117,61 @@ def wgrad_grouped(items):
     _C.check(_C.lib().petr_wgrad_grouped(arr, len(items), _stream()), 'petr_wgrad_grouped')
 
 
+def branch_fwd(x, w1, b1, w2, b2, w3=None, b3=None, ln1=None, ln2=None, eps=1e-5, save=True):
+    """``petr_branch_fwd``: out = Linear3(act2(Linear2(act1(Linear1(x))))) over rows [G, rows, 256]; weights in nn.Linear layout
+    with a leading group dimension ([G, 256, 256], [G, 256], w3 [G, n_out, 256]); ln = (gamma [G, 256], beta [G, 256]) makes the
+    activation ReLU(LayerNorm(.)).  Returns a dict with out and the rows the backward reads (h1, y1, h2, y2, mean / rstd)."""
+    G, rows, Cc = x.shape
+    dev = x.device
+    w1t, w2t = w1.transpose(1, 2).contiguous(), w2.transpose(1, 2).contiguous()
+    # one flat parameter buffer per kind so that every pointer shares the group stride
+    def cat(*ts):
+        flat = torch.cat([t.reshape(G, -1) for t in ts], dim=1).contiguous()
+        offs, o = [], 0
+        for t in ts:
+            offs.append(o)
+            o += t[0].numel()
+        return flat, offs
+    ts = [b1, b2] + ([w3, b3] if w3 is not None else []) + (list(ln1) if ln1 else []) + (list(ln2) if ln2 else [])
+    pad = (-sum(t[0].numel() for t in ts)) % 4
+    if pad:
+        ts.append(torch.zeros(G, pad, device=dev))
+    flat, offs = cat(*[_f32(t) for t in ts])
+    ptr = lambda i: flat.data_ptr() + 4 * offs[i]
+    a = _C.BranchFwdArgs()
+    a.x = _ptr(_f32(x))
+    a.w1t, a.w2t, a.wt_gs = _ptr(w1t), _ptr(w2t), Cc * Cc
+    a.b1, a.b2, a.param_gs = ptr(0), ptr(1), flat.shape[1]
+    i = 2
+    n_out = 0
+    if w3 is not None:
+        a.w3, a.b3 = ptr(i), ptr(i + 1)
+        n_out = w3.shape[1]
+        i += 2
+    if ln1:
+        a.g1, a.be1 = ptr(i), ptr(i + 1)
+        i += 2
+    if ln2:
+        a.g2, a.be2 = ptr(i), ptr(i + 1)
+        i += 2
+    res = {}
+    if save:
+        for k in ('y1', 'y2') + (('h1',) if ln1 else ()) + (('h2',) if ln2 else ()):
+            res[k] = torch.empty((G, rows, Cc), dtype=torch.float32, device=dev)
+            setattr(a, k, _ptr(res[k]))
+        for k, on in (('mean1', ln1), ('rstd1', ln1), ('mean2', ln2), ('rstd2', ln2)):
+            if on:
+                res[k] = torch.empty((G, rows), dtype=torch.float32, device=dev)
+                setattr(a, k, _ptr(res[k]))
+    if w3 is not None:
+        res['out'] = torch.empty((G, rows, n_out), dtype=torch.float32, device=dev)
+        a.out, a.n_out = _ptr(res['out']), n_out
+    a.rows, a.groups, a.eps = rows, G, eps
+    _C.check(_C.lib().petr_branch_fwd(C.byref(a), _stream()), 'petr_branch_fwd')
+    res['_keep'] = (flat, w1t, w2t)
+    return res
+
+
 def dropout_mask(drop, rows, cols, device='cuda'):
     """The keep mask (bool [rows, cols]) a kernel applies for drop = (seed, site, p): parity tests hand it to the oracle."""
     L = _C.lib()

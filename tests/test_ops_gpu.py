@@ -187,6 +187,43 @@ def test_layernorm_fwd_bwd(ops):
     assert torch.isfinite(yn).all() and (yn[3] == 0).all()
 
 
+@pytest.mark.parametrize('G,rows,n_out,ln', [(1, 5400, 10, True), (1, 5400, 10, False), (6, 900, 10, True), (6, 900, 0, False),
+                                             (2, 37, 7, True), (1, 16, 16, False)])
+def test_branch_fwd(ops, G, rows, n_out, ln):
+    """petr_branch_fwd = the class branch (Linear, LayerNorm, ReLU) x 2 + Linear / the box branch (Linear, ReLU) x 2 + Linear of
+    reference petr_head.py:226-247 in one launch, against float64 torch; the rows the backward reads are checked too.  G = 6,
+    rows = 900: PETRv2's deep-copied branches (900 % 32 != 0: ragged last block per group); n_out = 0: trunk only."""
+    g = torch.Generator().manual_seed(100 + rows + n_out)
+    r = lambda *s: torch.randn(*s, generator=g)
+    x = r(G, rows, 256)
+    w1, w2 = r(G, 256, 256) / 16, r(G, 256, 256) / 16
+    b1, b2 = r(G, 256) * 0.1, r(G, 256) * 0.1
+    w3, b3 = (r(G, n_out, 256) / 16, r(G, n_out) * 0.1) if n_out else (None, None)
+    ln1 = (1 + 0.1 * r(G, 256), 0.1 * r(G, 256)) if ln else None
+    ln2 = (1 + 0.1 * r(G, 256), 0.1 * r(G, 256)) if ln else None
+    dv = lambda t: None if t is None else (tuple(u.cuda() for u in t) if isinstance(t, tuple) else t.cuda())
+    res = ops.branch_fwd(dv(x), dv(w1), dv(b1), dv(w2), dv(b2), dv(w3), dv(b3), ln1=dv(ln1), ln2=dv(ln2))
+    F = torch.nn.functional
+    for gi in range(G):
+        d = lambda t: t[gi].double()
+        h1 = d(x) @ d(w1).T + d(b1)
+        y1 = F.relu(F.layer_norm(h1, (256,), d(ln1[0]), d(ln1[1]), 1e-5)) if ln else F.relu(h1)
+        h2 = y1 @ d(w2).T + d(b2)
+        y2 = F.relu(F.layer_norm(h2, (256,), d(ln2[0]), d(ln2[1]), 1e-5)) if ln else F.relu(h2)
+        want = {'y1': y1, 'y2': y2}
+        if ln:
+            want.update(h1=h1, h2=h2, mean1=h1.mean(-1), mean2=h2.mean(-1),
+                        rstd1=1 / torch.sqrt(h1.var(-1, unbiased=False) + 1e-5), rstd2=1 / torch.sqrt(h2.var(-1, unbiased=False) + 1e-5))
+        if n_out:
+            want['out'] = y2 @ d(w3).T + d(b3)
+        for k, v in want.items():
+            got = res[k][gi].cpu().double()
+            assert got.shape == v.shape, k
+            err = (got - v).abs().max().item() / max(v.abs().max().item(), 1e-6)
+            assert err < 5e-6, (gi, k, err)
+    assert ('out' in res) == bool(n_out)
+
+
 def test_wgrad_grouped(ops):
     """petr_wgrad_grouped: the weight / bias gradients of one decoder layer's linear maps in one launch (strided operand
     views as the executor passes them, ragged K = 900, a K-split item with atomics) against fp64, accumulating (+=)."""

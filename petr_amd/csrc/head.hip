@@ -1411,18 +1411,20 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
     if (stage == 0) {
       // clear every += / atomic target of this backward pass; in bf16 mode dK / dV of all layers (the bulk of the range:
       // 2 x 6 x L x 256 floats) are stored by petr_mha_bwd_bf16 and need no zero-fill
+      // Only d_ref_tmp is touched by this stage: with side streams the bulk (d_qc, d_qkv and, in fp32 mode, dK / dV of all layers:
+      // 52 MB at c5, 295 MB at p4-1600) is cleared on side stream 1 beside the branch backward - the layer stages wait for that
+      // stream's event anyway (transposed weights) - instead of in front of it on the main stream (PETR_BWD_ZERO_SIDE=0: main)
       hipError_t e;
-      if (io->attn_bf16) {
-        e = hipMemsetAsync(Wm + W.zero_begin, 0, (size_t)(W.dk_all - W.zero_begin) * sizeof(float), ln.main);
-        if (e == hipSuccess)
-          e = hipMemsetAsync(Wm + W.d_ref_tmp, 0, (size_t)(W.zero_end - W.d_ref_tmp) * sizeof(float), ln.main);
-      } else {
-        e = hipMemsetAsync(Wm + W.zero_begin, 0, (size_t)(W.zero_end - W.zero_begin) * sizeof(float), ln.main);
-      }
+      const bool zero_side = dgrad_t && ln.ctx && petr_tune("PETR_BWD_ZERO_SIDE", 1) != 0;
+      const long bulk_end = io->attn_bf16 ? W.dk_all : W.d_ref_tmp;
+      if (dgrad_t) ln.fork(1);
+      e = hipMemsetAsync(Wm + W.zero_begin, 0, (size_t)(bulk_end - W.zero_begin) * sizeof(float),
+                         zero_side ? (hipStream_t)ln.side(1) : ln.main);
+      if (e == hipSuccess)
+        e = hipMemsetAsync(Wm + W.d_ref_tmp, 0, (size_t)(W.zero_end - W.d_ref_tmp) * sizeof(float), ln.main);
       PETR_CHECK(e == hipSuccess, PETR_ERR_LAUNCH, "head_bwd: memset failed: %s", hipGetErrorString(e));
       // transposed decoder weights for the layer stages' input gradients: side stream 1, beside the branch backward
       if (dgrad_t) {
-        ln.fork(1);
         // nothing to do when the forward made them (same parameters, same workspace)
         const bool have = fwd_transposes(cfg, d, C);
         RUN(launch_weight_transposes(Pm, Wm, P, W, d.NL, C, d.F, !have, !have, (hipStream_t)ln.side(1)));

@@ -709,6 +709,27 @@ typedef struct {
 } petr_branch_fwd_args;
 int petr_branch_fwd(const petr_branch_fwd_args* a, void* stream);
 
+/* Input-gradient chain of one prediction branch in ONE launch (the backward of petr_branch_fwd; what autograd does for
+ * petr_head.py:226-247): d_y2 = d_out W3 (or given: w3 = NULL, PETRv2's RegLayer heads produce it), d_h2 = act'(d_y2),
+ * d_y1 = d_h2 W2, d_h1 = act'(d_y1), d_x = d_h1 W1, with act' = ReLU mask (y > 0) followed - when g1 / g2 are given - by the
+ * LayerNorm backward (dz = rstd (g gamma - mean(g gamma) - xhat mean(g gamma xhat))), whose dgamma / dbeta are ADDED with float
+ * atomics.  Weights in nn.Linear layout ([out][in] is k-major for an input gradient: nothing is transposed).  d_h2 / d_h1 are
+ * written for the weight gradients (dW2 = d_h2^T y1, dW1 = d_h1^T x: petr_wgrad_grouped), d_x is overwritten.  32 rows per
+ * workgroup, groups as in petr_branch_fwd.  C = 256 only.                                                              */
+typedef struct {
+  const float* d_out; int n_out; const float* w3;      /* [groups * rows, n_out], [n_out, 256]; or                    */
+  const float* d_y2;                                    /* [groups * rows, 256] when w3 == NULL                        */
+  const float* y2; const float* h2; const float* mean2; const float* rstd2; const float* g2;
+  const float* w2;
+  const float* y1; const float* h1; const float* mean1; const float* rstd1; const float* g1;
+  const float* w1;
+  long param_gs;
+  float* d_h2; float* d_h1; float* d_x;                 /* [groups * rows, 256] each                                   */
+  float* dg2; float* dbe2; float* dg1; float* dbe1;     /* += ; group stride param_gs (class branch)                   */
+  int rows, groups;
+} petr_branch_bwd_args;
+int petr_branch_bwd(const petr_branch_bwd_args* a, void* stream);
+
 /* named views into the forward workspace, for tests and for the per-module Python API
  * ("memory", "pos_embed", "query_embed", "outs_dec", "coords3d", "sine", "k_all", "v_all", ...)   */
 int petr_head_ws_view(const petr_head_config* cfg, const char* name, long* offset_floats, long* numel);

@@ -150,6 +150,17 @@ class BranchFwdArgs(C.Structure):    # petr_branch_fwd_args
                        ('out', C.c_void_p), ('n_out', C.c_int), ('rows', C.c_int), ('groups', C.c_int), ('eps', C.c_float))
 
 
+class BranchBwdArgs(C.Structure):    # petr_branch_bwd_args
+    _fields_ = _fields(('d_out', C.c_void_p), ('n_out', C.c_int), ('w3', C.c_void_p), ('d_y2', C.c_void_p),
+                       ('y2', C.c_void_p), ('h2', C.c_void_p), ('mean2', C.c_void_p), ('rstd2', C.c_void_p), ('g2', C.c_void_p),
+                       ('w2', C.c_void_p),
+                       ('y1', C.c_void_p), ('h1', C.c_void_p), ('mean1', C.c_void_p), ('rstd1', C.c_void_p), ('g1', C.c_void_p),
+                       ('w1', C.c_void_p), ('param_gs', C.c_long),
+                       ('d_h2', C.c_void_p), ('d_h1', C.c_void_p), ('d_x', C.c_void_p),
+                       ('dg2', C.c_void_p), ('dbe2', C.c_void_p), ('dg1', C.c_void_p), ('dbe1', C.c_void_p),
+                       ('rows', C.c_int), ('groups', C.c_int))
+
+
 class MhaBwdArgs(C.Structure):
     _fields_ = _fields(
         ('q', C.c_void_p), ('q_bs', C.c_long), ('q_hs', C.c_long), ('q_rs', C.c_long),
@@ -294,6 +305,7 @@ def lib():
     L.petr_add_rows2_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
     L.petr_wgrad_grouped.argtypes = [C.POINTER(WgradItem), C.c_int, C.c_void_p]
     L.petr_branch_fwd.argtypes = [C.POINTER(BranchFwdArgs), C.c_void_p]
+    L.petr_branch_bwd.argtypes = [C.POINTER(BranchBwdArgs), C.c_void_p]
     L.petr_fpn_upsample_add.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
     L.petr_axpy.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_long, C.c_void_p]
     L.petr_reduce_partials.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
@@ -331,7 +343,7 @@ EXPORTS = [
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
     'petr_ctx_create', 'petr_ctx_destroy', 'petr_ctx_join_into', 'petr_ctx_side_stream', 'petr_dropout_mask', 'petr_dropout_bits_words', 'petr_dropout_bits', 'petr_loss_workspace_bytes', 'petr_loss_fwd_bwd',
-    'petr_decode_boxes', 'petr_decode_topk', 'petr_fpn_upsample_add', 'petr_wgrad_grouped', 'petr_branch_fwd', 'petr_fpn_upsample_add_bwd', 'petr_nchw_to_padded_nhwc', 'petr_add_rows2', 'petr_add_rows2_bf16',
+    'petr_decode_boxes', 'petr_decode_topk', 'petr_fpn_upsample_add', 'petr_wgrad_grouped', 'petr_branch_fwd', 'petr_branch_bwd', 'petr_fpn_upsample_add_bwd', 'petr_nchw_to_padded_nhwc', 'petr_add_rows2', 'petr_add_rows2_bf16',
 ]
 
 

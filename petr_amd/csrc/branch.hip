@@ -146,7 +146,191 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(const BrParams p) {
     a.out[(row0 + m0 + r) * a.n_out + o] = (s0 + s1) + (s2 + s3) + (a.b3 ? a.b3[pg + o] : 0.f);
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// petr_branch_bwd: the input-gradient chain of a branch, same shape as the forward - 32 rows per workgroup, two streamed 256 x 256
+// products (W2, W1 as stored: [out][in] is k-major for d_in = d_out W), everything between them in the accumulator layout
+// (lane: rows 16 rg + 4 q4 + i, columns c0, c0 + 1): ReLU mask from the saved activation, LayerNorm backward with row sums over
+// the 16 lanes of a row and the eight waves (one barrier for both sums), dgamma / dbeta as column sums over the lane's 8 rows and
+// the four lane groups of the wave (a wave covers all 32 rows of its 32 columns) -> one float atomic per column and workgroup.
+// ---------------------------------------------------------------------------------------------------------------
+struct BbParams {
+  petr_branch_bwd_args a;
+  int nrb;
+};
+
+__global__ __launch_bounds__(512) void branch_bwd_kernel(const BbParams p) {
+  __shared__ __attribute__((aligned(16))) float As[BR_ROWS * AO_PITCH];     // d_h2 rows
+  __shared__ __attribute__((aligned(16))) float Hs[BR_ROWS * AO_PITCH];     // d_h1 rows
+  __shared__ float red[2][8][BR_ROWS];
+  __shared__ float Ds[BR_ROWS][17];                                         // the block's d_out rows (n_out <= 16)
+  const petr_branch_bwd_args& a = p.a;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = blockIdx.x / p.nrb, rb = blockIdx.x - grp * p.nrb;
+  const int m0 = rb * BR_ROWS;
+  const long row0 = (long)grp * a.rows;
+  const int nl = lane & 15, q4 = lane >> 4;
+  const long pg = (long)grp * a.param_gs;
+  const int c0 = 32 * wave + 2 * nl;
+
+  const float* w2 = a.w2 + pg + 32 * wave;
+  const float* w1 = a.w1 + pg + 32 * wave;
+  const uint32_t lo = WStreamT<BR_RG>::lane_off(lane, AO_C);
+  WStreamT<BR_RG> ws;
+  ws.first(w2, AO_C, lo);
+
+  // ---- d_y2 in the accumulator layout ----
+  float u0[BR_RG][4], u1[BR_RG][4];
+  if (a.w3) {
+    if (t < BR_ROWS * 16) {
+      const int r = t >> 4, o = t & 15;
+      Ds[r][o] = (o < a.n_out) ? a.d_out[(row0 + min(m0 + r, a.rows - 1)) * a.n_out + o] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rg = 0; rg < BR_RG; ++rg)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) u0[rg][i] = u1[rg][i] = 0.f;
+    for (int o = 0; o < a.n_out; ++o) {
+      const float2 w = *reinterpret_cast<const float2*>(a.w3 + pg + (long)o * AO_C + c0);
+#pragma unroll
+      for (int rg = 0; rg < BR_RG; ++rg)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float dv = Ds[16 * rg + 4 * q4 + i][o];
+          u0[rg][i] += dv * w.x; u1[rg][i] += dv * w.y;
+        }
+    }
+  } else {
+#pragma unroll
+    for (int rg = 0; rg < BR_RG; ++rg)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float2 v = *reinterpret_cast<const float2*>(a.d_y2 + (row0 + min(m0 + 16 * rg + 4 * q4 + i, a.rows - 1)) * AO_C + c0);
+        u0[rg][i] = v.x; u1[rg][i] = v.y;
+      }
+  }
+
+  // gradient through ReLU [and LayerNorm] of one stage, in place: (u0, u1) = d_y -> d_h; rows beyond the group end become zero
+  auto act_bwd = [&](const float* y_save, const float* h_save, const float* mean_save, const float* rstd_save, const float* gamma,
+                     float* dgamma, float* dbeta, float* dst, float* dh_save) {
+    float xh0[BR_RG][4], xh1[BR_RG][4], rs[BR_RG][4];
+    float cg0 = 0.f, cg1 = 0.f, cb0 = 0.f, cb1 = 0.f;
+    float2 gm = make_float2(1.f, 1.f);
+    if (gamma) gm = *reinterpret_cast<const float2*>(gamma + c0);
+    float s1[BR_RG][4], s2[BR_RG][4];
+#pragma unroll
+    for (int rg = 0; rg < BR_RG; ++rg)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 16 * rg + 4 * q4 + i;
+        const bool ok = m < a.rows;
+        const long ro = (row0 + min(m, a.rows - 1)) * AO_C + c0;
+        const float2 y = *reinterpret_cast<const float2*>(y_save + ro);
+        float g0 = (ok && y.x > 0.f) ? u0[rg][i] : 0.f, g1 = (ok && y.y > 0.f) ? u1[rg][i] : 0.f;
+        if (gamma) {
+          const float2 hv = *reinterpret_cast<const float2*>(h_save + ro);
+          const float mean = mean_save[row0 + min(m, a.rows - 1)], rstd = rstd_save[row0 + min(m, a.rows - 1)];
+          xh0[rg][i] = (hv.x - mean) * rstd; xh1[rg][i] = (hv.y - mean) * rstd; rs[rg][i] = rstd;
+          cg0 += g0 * xh0[rg][i]; cg1 += g1 * xh1[rg][i]; cb0 += g0; cb1 += g1;
+          g0 *= gm.x; g1 *= gm.y;
+          s1[rg][i] = g0 + g1;
+          s2[rg][i] = g0 * xh0[rg][i] + g1 * xh1[rg][i];
+        }
+        u0[rg][i] = g0; u1[rg][i] = g1;
+      }
+    if (gamma) {
+      // both row sums behind one barrier
+#pragma unroll
+      for (int rg = 0; rg < BR_RG; ++rg)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x = s1[rg][i], z = s2[rg][i];
+          x += __shfl_xor(x, 1, 64); z += __shfl_xor(z, 1, 64);
+          x += __shfl_xor(x, 2, 64); z += __shfl_xor(z, 2, 64);
+          x += __shfl_xor(x, 4, 64); z += __shfl_xor(z, 4, 64);
+          x += __shfl_xor(x, 8, 64); z += __shfl_xor(z, 8, 64);
+          if (nl == 0) { red[0][wave][16 * rg + 4 * q4 + i] = x; red[1][wave][16 * rg + 4 * q4 + i] = z; }
+        }
+      __syncthreads();
+#pragma unroll
+      for (int rg = 0; rg < BR_RG; ++rg)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x = 0.f, z = 0.f;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) { x += red[0][w][16 * rg + 4 * q4 + i]; z += red[1][w][16 * rg + 4 * q4 + i]; }
+          const float m1 = x * (1.f / AO_C), m2 = z * (1.f / AO_C);
+          u0[rg][i] = rs[rg][i] * (u0[rg][i] - m1 - xh0[rg][i] * m2);
+          u1[rg][i] = rs[rg][i] * (u1[rg][i] - m1 - xh1[rg][i] * m2);
+        }
+      // column sums over the wave's 32 rows: the lane's 8, then the four lane groups
+      cg0 += __shfl_xor(cg0, 16, 64); cg1 += __shfl_xor(cg1, 16, 64); cb0 += __shfl_xor(cb0, 16, 64); cb1 += __shfl_xor(cb1, 16, 64);
+      cg0 += __shfl_xor(cg0, 32, 64); cg1 += __shfl_xor(cg1, 32, 64); cb0 += __shfl_xor(cb0, 32, 64); cb1 += __shfl_xor(cb1, 32, 64);
+      if (q4 == 0) {
+        if (dgamma) { atomicAdd(dgamma + c0, cg0); atomicAdd(dgamma + c0 + 1, cg1); }
+        if (dbeta) { atomicAdd(dbeta + c0, cb0); atomicAdd(dbeta + c0 + 1, cb1); }
+      }
+    }
+#pragma unroll
+    for (int rg = 0; rg < BR_RG; ++rg)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rl = 16 * rg + 4 * q4 + i, m = m0 + rl;
+        const float2 v = make_float2(u0[rg][i], u1[rg][i]);
+        *reinterpret_cast<float2*>(dst + rl * AO_PITCH + c0) = v;
+        if (dh_save && m < a.rows) *reinterpret_cast<float2*>(dh_save + (row0 + m) * AO_C + c0) = v;
+      }
+    __syncthreads();
+  };
+  act_bwd(a.y2, a.h2, a.mean2, a.rstd2, a.g2 ? a.g2 + pg : nullptr, a.dg2 ? a.dg2 + pg : nullptr, a.dbe2 ? a.dbe2 + pg : nullptr, As, a.d_h2);
+  {
+    f32x4 acc[BR_RG][2];
+#pragma unroll
+    for (int rg = 0; rg < BR_RG; ++rg) acc[rg][0] = acc[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ws.run(As + nl * AO_PITCH + 4 * q4, AO_PITCH, w2, AO_C, lo, w1, AO_C, lo, acc);
+#pragma unroll
+    for (int rg = 0; rg < BR_RG; ++rg)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { u0[rg][i] = acc[rg][0][i]; u1[rg][i] = acc[rg][1][i]; }
+  }
+  act_bwd(a.y1, a.h1, a.mean1, a.rstd1, a.g1 ? a.g1 + pg : nullptr, a.dg1 ? a.dg1 + pg : nullptr, a.dbe1 ? a.dbe1 + pg : nullptr, Hs, a.d_h1);
+  {
+    f32x4 acc[BR_RG][2];
+#pragma unroll
+    for (int rg = 0; rg < BR_RG; ++rg) acc[rg][0] = acc[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ws.run(Hs + nl * AO_PITCH + 4 * q4, AO_PITCH, w1, AO_C, lo, nullptr, AO_C, lo, acc);
+#pragma unroll
+    for (int rg = 0; rg < BR_RG; ++rg)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 16 * rg + 4 * q4 + i;
+        if (m < a.rows) *reinterpret_cast<float2*>(a.d_x + (row0 + m) * AO_C + c0) = make_float2(acc[rg][0][i], acc[rg][1][i]);
+      }
+  }
+}
 }  // namespace
+
+extern "C" int petr_branch_bwd(const petr_branch_bwd_args* ap, void* stream) {
+  PETR_CHECK(ap && ap->y2 && ap->w2 && ap->y1 && ap->w1 && ap->d_x && ap->rows > 0 && ap->groups > 0 &&
+                 ((ap->w3 && ap->d_out) || (!ap->w3 && ap->d_y2)),
+             PETR_ERR_INVALID, "branch_bwd: bad arguments");
+  const petr_branch_bwd_args& a = *ap;
+  PETR_CHECK(!a.w3 || (a.n_out > 0 && a.n_out <= 16), PETR_ERR_UNSUPPORTED, "branch_bwd: n_out=%d outside 1..16", a.n_out);
+  PETR_CHECK((!a.g2 || (a.h2 && a.mean2 && a.rstd2)) && (!a.g1 || (a.h1 && a.mean1 && a.rstd1)), PETR_ERR_INVALID,
+             "branch_bwd: a LayerNorm stage needs its pre-norm rows and statistics");
+  PETR_CHECK(aligned16(a.w2) && aligned16(a.w1) && aligned16(a.y2) && aligned16(a.y1) && aligned16(a.h2) && aligned16(a.h1) &&
+                 aligned16(a.d_h2) && aligned16(a.d_h1) && aligned16(a.d_x) && aligned16(a.d_y2) && (!a.w3 || aligned16(a.w3)) &&
+                 !(a.param_gs & 3),
+             PETR_ERR_INVALID, "branch_bwd: every [.., 256] operand must be 16-byte aligned (group stride a multiple of 4)");
+  BbParams p;
+  p.a = a;
+  p.nrb = (int)cdiv(a.rows, BR_ROWS);
+  hipLaunchKernelGGL(branch_bwd_kernel, dim3((unsigned)(p.nrb * a.groups)), dim3(512), 0, (hipStream_t)stream, p);
+  PETR_LAUNCH_CHECK("branch_bwd");
+  return PETR_OK;
+}
 
 extern "C" int petr_branch_fwd(const petr_branch_fwd_args* ap, void* stream) {
   PETR_CHECK(ap && ap->x && ap->w1t && ap->b1 && ap->w2t && ap->b2 && ap->rows > 0 && ap->groups > 0, PETR_ERR_INVALID,

@@ -1466,11 +1466,19 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       RUN(petr_bbox_epilogue_bwd(&a, gr->d_bbox, d_raw, Wm + W.d_ref_tmp, s));
       float* d_r2 = Wm + W.s0_r2;
       petr_gemm_args g;
+      // one launch per branch for the input-gradient chain (petr_branch_bwd; PETR_BRANCH_BWD_FUSED=0, diagnostic builds: the
+      // contraction / LayerNorm-backward chains below)
+      const bool bwd_fused = C == 256 && d.ncls <= 16 && d.code <= 16 && petr_tune("PETR_BRANCH_BWD_FUSED", 1) != 0;
+      petr_branch_bwd_args bb;
+      memset(&bb, 0, sizeof bb);
+      bb.param_gs = P.br_stride; bb.rows = (int)RG; bb.groups = G;
       if (!cfg->with_multi) {
         RUN(wgrad(gw(lin_wgrad(d_raw, d.code, Wm + W.r2, C, Gp + P.reg_w[2], Gp + P.reg_b[2], RG, d.code, C), d.code, C)));
-        g = gd(lin_dgrad(d_raw, Pm + P.reg_w[2], d_r2, RG, d.code, C), d.code, C, C);
-        g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.r2; g.ldr = C;
-        RUN(petr_gemm(&g, s));
+        if (!bwd_fused) {
+          g = gd(lin_dgrad(d_raw, Pm + P.reg_w[2], d_r2, RG, d.code, C), d.code, C, C);
+          g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.r2; g.ldr = C;
+          RUN(petr_gemm(&g, s));
+        }
       } else {
         static const int TH_DIMS[5] = {2, 1, 3, 2, 2}, TH_COL[5] = {0, 2, 3, 6, 8};
         float* d_th = Wm + W.d_th_h;
@@ -1496,38 +1504,66 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g.k_seg = C; g.a_seg_stride = RG * C; g.b_seg_stride = P.th_stride;
         RUN(petr_gemm(&g, s));
       }
-      RUN(wgrad(gw(lin_wgrad(d_r2, C, Wm + W.r1, C, Gp + P.reg_w[1], Gp + P.reg_b[1], RG, C, C), C, C)));
       float* d_r1 = Wm + W.s0_r1;
-      g = gd(lin_dgrad(d_r2, Pm + P.reg_w[1], d_r1, RG, C, C), C, C, C);
-      g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.r1; g.ldr = C;
-      RUN(petr_gemm(&g, s));
+      if (bwd_fused) {        // the rest of the chain in one launch: d_r2 (given, or from d_raw), d_r1, d_outs
+        petr_branch_bwd_args b = bb;
+        if (!cfg->with_multi) { b.d_out = d_raw; b.n_out = d.code; b.w3 = Pm + P.reg_w[2]; }
+        else b.d_y2 = d_r2;
+        b.y2 = Wm + W.r2; b.w2 = Pm + P.reg_w[1]; b.y1 = Wm + W.r1; b.w1 = Pm + P.reg_w[0];
+        b.d_h2 = d_r2; b.d_h1 = d_r1; b.d_x = Wm + W.d_outs;
+        RUN(petr_branch_bwd(&b, s));
+      }
+      RUN(wgrad(gw(lin_wgrad(d_r2, C, Wm + W.r1, C, Gp + P.reg_w[1], Gp + P.reg_b[1], RG, C, C), C, C)));
+      if (!bwd_fused) {
+        g = gd(lin_dgrad(d_r2, Pm + P.reg_w[1], d_r1, RG, C, C), C, C, C);
+        g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.r1; g.ldr = C;
+        RUN(petr_gemm(&g, s));
+      }
       RUN(wgrad(gw(lin_wgrad(d_r1, C, Wm + W.outs, C, Gp + P.reg_w[0], Gp + P.reg_b[0], RG, C, C), C, C)));
-      g = gd(lin_dgrad(d_r1, Pm + P.reg_w[0], Wm + W.d_outs, RG, C, C), C, C, C);
-      RUN(petr_gemm(&g, s));
+      if (!bwd_fused) {
+        g = gd(lin_dgrad(d_r1, Pm + P.reg_w[0], Wm + W.d_outs, RG, C, C), C, C, C);
+        RUN(petr_gemm(&g, s));
+      }
       // ---- cls branch: independent of the reg branch until the post-norm, so it runs beside it on side stream 0 and
       // leaves its input gradient in a buffer of its own (summed by the post-norm backward's prologue) ----
       void* sc = ln.side(0);          // (forked before the reg branch was enqueued, see above)
       RUN(wgrad(gw(lin_wgrad(gr->d_cls, d.ncls, Wm + W.c2n, C, Gp + P.cls_w[2], Gp + P.cls_b[2], RG, d.ncls, C), d.ncls, C)));
-      float* d_c2n = Wm + W.s0_c2n;
-      g = gd(lin_dgrad(gr->d_cls, Pm + P.cls_w[2], d_c2n, RG, d.ncls, C), d.ncls, C, C);
-      RUN(petr_gemm(&g, sc));
       float* d_c2 = Wm + W.s0_c2;
-      for (int gi = 0; gi < G; ++gi)
-        RUN(ln_bwd(Wm + W.c2 + gi * RG * C, Wm + W.c2_mean + gi * RG, Wm + W.c2_rstd + gi * RG, Pm + P.cls_g[1] + gi * P.br_stride,
-                   d_c2n + gi * RG * C, Wm + W.c2n + gi * RG * C, d_c2 + gi * RG * C, Gp + P.cls_g[1] + gi * P.br_stride,
-                   Gp + P.cls_be[1] + gi * P.br_stride, RG, C, PETR_LN_RELU, 0, sc));
-      RUN(wgrad(gw(lin_wgrad(d_c2, C, Wm + W.c1n, C, Gp + P.cls_w[1], Gp + P.cls_b[1], RG, C, C), C, C)));
-      float* d_c1n = Wm + W.s0_c1n;
-      g = gd(lin_dgrad(d_c2, Pm + P.cls_w[1], d_c1n, RG, C, C), C, C, C);
-      RUN(petr_gemm(&g, sc));
       float* d_c1 = Wm + W.s0_c1;
-      for (int gi = 0; gi < G; ++gi)
-        RUN(ln_bwd(Wm + W.c1 + gi * RG * C, Wm + W.c1_mean + gi * RG, Wm + W.c1_rstd + gi * RG, Pm + P.cls_g[0] + gi * P.br_stride,
-                   d_c1n + gi * RG * C, Wm + W.c1n + gi * RG * C, d_c1 + gi * RG * C, Gp + P.cls_g[0] + gi * P.br_stride,
-                   Gp + P.cls_be[0] + gi * P.br_stride, RG, C, PETR_LN_RELU, 0, sc));
+      if (bwd_fused) {
+        petr_branch_bwd_args b = bb;
+        b.d_out = gr->d_cls; b.n_out = d.ncls; b.w3 = Pm + P.cls_w[2];
+        b.y2 = Wm + W.c2n; b.h2 = Wm + W.c2; b.mean2 = Wm + W.c2_mean; b.rstd2 = Wm + W.c2_rstd; b.g2 = Pm + P.cls_g[1];
+        b.w2 = Pm + P.cls_w[1];
+        b.y1 = Wm + W.c1n; b.h1 = Wm + W.c1; b.mean1 = Wm + W.c1_mean; b.rstd1 = Wm + W.c1_rstd; b.g1 = Pm + P.cls_g[0];
+        b.w1 = Pm + P.cls_w[0];
+        b.d_h2 = d_c2; b.d_h1 = d_c1; b.d_x = Wm + W.s0_outs_c;
+        b.dg2 = Gp + P.cls_g[1]; b.dbe2 = Gp + P.cls_be[1]; b.dg1 = Gp + P.cls_g[0]; b.dbe1 = Gp + P.cls_be[0];
+        RUN(petr_branch_bwd(&b, sc));
+      } else {
+        float* d_c2n = Wm + W.s0_c2n;
+        g = gd(lin_dgrad(gr->d_cls, Pm + P.cls_w[2], d_c2n, RG, d.ncls, C), d.ncls, C, C);
+        RUN(petr_gemm(&g, sc));
+        for (int gi = 0; gi < G; ++gi)
+          RUN(ln_bwd(Wm + W.c2 + gi * RG * C, Wm + W.c2_mean + gi * RG, Wm + W.c2_rstd + gi * RG, Pm + P.cls_g[1] + gi * P.br_stride,
+                     d_c2n + gi * RG * C, Wm + W.c2n + gi * RG * C, d_c2 + gi * RG * C, Gp + P.cls_g[1] + gi * P.br_stride,
+                     Gp + P.cls_be[1] + gi * P.br_stride, RG, C, PETR_LN_RELU, 0, sc));
+      }
+      RUN(wgrad(gw(lin_wgrad(d_c2, C, Wm + W.c1n, C, Gp + P.cls_w[1], Gp + P.cls_b[1], RG, C, C), C, C)));
+      if (!bwd_fused) {
+        float* d_c1n = Wm + W.s0_c1n;
+        g = gd(lin_dgrad(d_c2, Pm + P.cls_w[1], d_c1n, RG, C, C), C, C, C);
+        RUN(petr_gemm(&g, sc));
+        for (int gi = 0; gi < G; ++gi)
+          RUN(ln_bwd(Wm + W.c1 + gi * RG * C, Wm + W.c1_mean + gi * RG, Wm + W.c1_rstd + gi * RG, Pm + P.cls_g[0] + gi * P.br_stride,
+                     d_c1n + gi * RG * C, Wm + W.c1n + gi * RG * C, d_c1 + gi * RG * C, Gp + P.cls_g[0] + gi * P.br_stride,
+                     Gp + P.cls_be[0] + gi * P.br_stride, RG, C, PETR_LN_RELU, 0, sc));
+      }
       RUN(wgrad(gw(lin_wgrad(d_c1, C, Wm + W.outs, C, Gp + P.cls_w[0], Gp + P.cls_b[0], RG, C, C), C, C)));
-      g = gd(lin_dgrad(d_c1, Pm + P.cls_w[0], Wm + W.s0_outs_c, RG, C, C), C, C, C);
-      RUN(petr_gemm(&g, sc));
+      if (!bwd_fused) {
+        g = gd(lin_dgrad(d_c1, Pm + P.cls_w[0], Wm + W.s0_outs_c, RG, C, C), C, C, C);
+        RUN(petr_gemm(&g, sc));
+      }
       ln.join(0);
       // ---- post_norm over all levels -> d_xs[l] ----
       RUN(ln_bwd(Wm + W.xs, Wm + W.mean_p, Wm + W.rstd_p, Pm + P.post_g, Wm + W.d_outs, nullptr, Wm + W.d_xs, Gp + P.post_g,

@@ -173,6 +173,55 @@ def branch_fwd(x, w1, b1, w2, b2, w3=None, b3=None, ln1=None, ln2=None, eps=1e-5
     return res
 
 
+def branch_bwd(fwd, w1, w2, w3=None, d_out=None, d_y2=None, ln1=None, ln2=None):
+    """``petr_branch_bwd`` on the tensors ``branch_fwd`` saved (``fwd``): returns dict(d_x, d_h1, d_h2[, dg1, dbe1, dg2, dbe2]).
+    Weights in nn.Linear layout with the group dimension in front; ln = (gamma [G, 256], beta) as in the forward."""
+    G, rows, Cc = fwd['y1'].shape
+    dev = fwd['y1'].device
+    # one flat buffer so that w1 / w2 / w3 / gamma share the group stride
+    ts = [w1, w2] + ([w3] if w3 is not None else []) + ([ln2[0]] if ln2 else []) + ([ln1[0]] if ln1 else [])
+    flat = torch.cat([_f32(t).reshape(G, -1) for t in ts], dim=1).contiguous()
+    offs, o = [], 0
+    for t in ts:
+        offs.append(o)
+        o += t[0].numel()
+    assert flat.shape[1] % 4 == 0
+    ptr = lambda i: flat.data_ptr() + 4 * offs[i]
+    a = _C.BranchBwdArgs()
+    a.w1, a.w2, a.param_gs = ptr(0), ptr(1), flat.shape[1]
+    i = 2
+    keep = [flat]
+    if w3 is not None:
+        d_out = _f32(d_out).contiguous()
+        a.w3, a.d_out, a.n_out = ptr(i), _ptr(d_out), w3.shape[1]
+        keep.append(d_out)
+        i += 1
+    else:
+        d_y2 = _f32(d_y2).contiguous()
+        a.d_y2 = _ptr(d_y2)
+        keep.append(d_y2)
+    res = {k: torch.empty((G, rows, Cc), dtype=torch.float32, device=dev) for k in ('d_x', 'd_h1', 'd_h2')}
+    grads = torch.zeros((G, flat.shape[1]), dtype=torch.float32, device=dev)     # dgamma in the parameters' own layout
+    betas = torch.zeros((G, flat.shape[1]), dtype=torch.float32, device=dev)
+    if ln2:
+        a.g2, a.h2, a.mean2, a.rstd2 = ptr(i), _ptr(fwd['h2']), _ptr(fwd['mean2']), _ptr(fwd['rstd2'])
+        a.dg2, a.dbe2 = grads.data_ptr() + 4 * offs[i], betas.data_ptr() + 4 * offs[i]
+        res['dg2'], res['dbe2'] = grads[:, offs[i]:offs[i] + Cc], betas[:, offs[i]:offs[i] + Cc]
+        i += 1
+    if ln1:
+        a.g1, a.h1, a.mean1, a.rstd1 = ptr(i), _ptr(fwd['h1']), _ptr(fwd['mean1']), _ptr(fwd['rstd1'])
+        a.dg1, a.dbe1 = grads.data_ptr() + 4 * offs[i], betas.data_ptr() + 4 * offs[i]
+        res['dg1'], res['dbe1'] = grads[:, offs[i]:offs[i] + Cc], betas[:, offs[i]:offs[i] + Cc]
+        i += 1
+    a.y1, a.y2 = _ptr(fwd['y1']), _ptr(fwd['y2'])
+    a.d_h2, a.d_h1, a.d_x = _ptr(res['d_h2']), _ptr(res['d_h1']), _ptr(res['d_x'])
+    a.rows, a.groups = rows, G
+    _C.check(_C.lib().petr_branch_bwd(C.byref(a), _stream()), 'petr_branch_bwd')
+    res['_keep'] = keep
+    res['_launch'] = lambda: _C.check(_C.lib().petr_branch_bwd(C.byref(a), _stream()), 'petr_branch_bwd')
+    return res
+
+
 def dropout_mask(drop, rows, cols, device='cuda'):
     """The keep mask (bool [rows, cols]) a kernel applies for drop = (seed, site, p): parity tests hand it to the oracle."""
     L = _C.lib()

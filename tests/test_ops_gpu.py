@@ -224,6 +224,52 @@ def test_branch_fwd(ops, G, rows, n_out, ln):
     assert ('out' in res) == bool(n_out)
 
 
+@pytest.mark.parametrize('G,rows,n_out,ln', [(1, 5400, 10, True), (1, 5400, 10, False), (6, 900, 10, True), (6, 900, 0, False),
+                                             (2, 37, 7, True)])
+def test_branch_bwd(ops, G, rows, n_out, ln):
+    """petr_branch_bwd against float64 autograd through the same (Linear, [LayerNorm,] ReLU) x 2 [+ Linear] chain: the input
+    gradient, the two pre-activation gradients the weight gradients are formed from, and the LayerNorm parameter gradients.
+    n_out = 0: the gradient of the second activation is given (PETRv2: the RegLayer heads produce it)."""
+    g = torch.Generator().manual_seed(200 + rows + n_out)
+    r = lambda *s: torch.randn(*s, generator=g)
+    x = r(G, rows, 256)
+    w1, w2 = r(G, 256, 256) / 16, r(G, 256, 256) / 16
+    b1, b2 = r(G, 256) * 0.1, r(G, 256) * 0.1
+    w3, b3 = (r(G, n_out, 256) / 16, r(G, n_out) * 0.1) if n_out else (None, None)
+    ln1 = (1 + 0.1 * r(G, 256), 0.1 * r(G, 256)) if ln else None
+    ln2 = (1 + 0.1 * r(G, 256), 0.1 * r(G, 256)) if ln else None
+    d_top = r(G, rows, n_out) if n_out else r(G, rows, 256)
+    dv = lambda t: None if t is None else (tuple(u.cuda() for u in t) if isinstance(t, tuple) else t.cuda())
+    fwd = ops.branch_fwd(dv(x), dv(w1), dv(b1), dv(w2), dv(b2), dv(w3), dv(b3), ln1=dv(ln1), ln2=dv(ln2))
+    res = ops.branch_bwd(fwd, dv(w1), dv(w2), dv(w3), d_out=dv(d_top) if n_out else None, d_y2=None if n_out else dv(d_top),
+                         ln1=dv(ln1), ln2=dv(ln2))
+    F = torch.nn.functional
+    for gi in range(G):
+        d = lambda t: t[gi].double()
+        xd = d(x).requires_grad_(True)
+        gam1, gam2 = (d(ln1[0]).requires_grad_(True), d(ln2[0]).requires_grad_(True)) if ln else (None, None)
+        bet1, bet2 = (d(ln1[1]).requires_grad_(True), d(ln2[1]).requires_grad_(True)) if ln else (None, None)
+        # ReLU as a multiplication by the mask the KERNEL saw (y > 0 of its own fp32 activations): a pre-activation within an
+        # ulp of zero may fall on the other side in float64, and one flipped mask element changes its whole LayerNorm row
+        m1, m2 = (fwd['y1'][gi] > 0).cpu().double(), (fwd['y2'][gi] > 0).cpu().double()
+        h1 = xd @ d(w1).T + d(b1)
+        h1.retain_grad()
+        y1 = (F.layer_norm(h1, (256,), gam1, bet1, 1e-5) if ln else h1) * m1
+        h2 = y1 @ d(w2).T + d(b2)
+        h2.retain_grad()
+        y2 = (F.layer_norm(h2, (256,), gam2, bet2, 1e-5) if ln else h2) * m2
+        top = (y2 @ d(w3).T + d(b3)) if n_out else y2
+        top.backward(d(d_top))
+        want = {'d_x': xd.grad, 'd_h1': h1.grad, 'd_h2': h2.grad}
+        if ln:
+            want.update(dg1=gam1.grad, dbe1=bet1.grad, dg2=gam2.grad, dbe2=bet2.grad)
+        for k, v in want.items():
+            got = res[k][gi].cpu().double()
+            assert got.shape == v.shape, k
+            err = (got - v).abs().max().item() / max(v.abs().max().item(), 1e-6)
+            assert err < (2e-5 if k.startswith('d_') else 1e-4), (gi, k, err)      # parameter sums: 5 400 float atomics
+
+
 def test_wgrad_grouped(ops):
     """petr_wgrad_grouped: the weight / bias gradients of one decoder layer's linear maps in one launch (strided operand
     views as the executor passes them, ragged K = 900, a K-split item with atomics) against fp64, accumulating (+=)."""

@@ -714,7 +714,8 @@ int petr_branch_fwd(const petr_branch_fwd_args* a, void* stream);
  * d_y1 = d_h2 W2, d_h1 = act'(d_y1), d_x = d_h1 W1, with act' = ReLU mask (y > 0) followed - when g1 / g2 are given - by the
  * LayerNorm backward (dz = rstd (g gamma - mean(g gamma) - xhat mean(g gamma xhat))), whose dgamma / dbeta are ADDED with float
  * atomics.  Weights in nn.Linear layout ([out][in] is k-major for an input gradient: nothing is transposed).  d_h2 / d_h1 are
- * written for the weight gradients (dW2 = d_h2^T y1, dW1 = d_h1^T x: petr_wgrad_grouped), d_x is overwritten.  32 rows per
+ * written for the weight gradients (dW2 = d_h2^T y1, dW1 = d_h1^T x: petr_wgrad_grouped), d_x is overwritten; dW3 / db3 can
+ * be formed here (dw3, db3).  32 rows per
  * workgroup, groups as in petr_branch_fwd.  C = 256 only.                                                              */
 typedef struct {
   const float* d_out; int n_out; const float* w3;      /* [groups * rows, n_out], [n_out, 256]; or                    */
@@ -727,6 +728,10 @@ typedef struct {
   float* d_h2; float* d_h1; float* d_x;                 /* [groups * rows, 256] each                                   */
   float* dg2; float* dbe2; float* dg1; float* dbe1;     /* += ; group stride param_gs (class branch)                   */
   int rows, groups;
+  float* dw3; float* db3;                               /* optional, += (float atomics), group stride param_gs: the last
+                                                         * Linear's parameter gradients d_out^T y2 [n_out, 256] and the
+                                                         * column sums of d_out [n_out] - a 10 x 256 x 5 400 contraction is
+                                                         * nothing for the workgroups that hold both operands anyway       */
 } petr_branch_bwd_args;
 int petr_branch_bwd(const petr_branch_bwd_args* a, void* stream);
 

@@ -158,7 +158,7 @@ class BranchBwdArgs(C.Structure):    # petr_branch_bwd_args
                        ('w1', C.c_void_p), ('param_gs', C.c_long),
                        ('d_h2', C.c_void_p), ('d_h1', C.c_void_p), ('d_x', C.c_void_p),
                        ('dg2', C.c_void_p), ('dbe2', C.c_void_p), ('dg1', C.c_void_p), ('dbe1', C.c_void_p),
-                       ('rows', C.c_int), ('groups', C.c_int))
+                       ('rows', C.c_int), ('groups', C.c_int), ('dw3', C.c_void_p), ('db3', C.c_void_p))
 
 
 class MhaBwdArgs(C.Structure):

@@ -212,6 +212,41 @@ __global__ __launch_bounds__(512) void branch_bwd_kernel(const BbParams p) {
       }
   }
 
+  // ---- the last Linear's parameter gradients from the operands this workgroup holds anyway: dW3[o][c] += sum_r d_out[r][o] y2[r][c]
+  //      (lane: its 8 rows x 2 columns, then the four lane groups of the wave), db3[o] += sum_r d_out[r][o] ----
+  if (a.w3 && a.dw3) {
+    float2 yv[BR_RG][4];
+#pragma unroll
+    for (int rg = 0; rg < BR_RG; ++rg)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 16 * rg + 4 * q4 + i;
+        const float2 y = *reinterpret_cast<const float2*>(a.y2 + (row0 + min(m, a.rows - 1)) * AO_C + c0);
+        yv[rg][i] = m < a.rows ? y : make_float2(0.f, 0.f);
+      }
+    for (int o = 0; o < a.n_out; ++o) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int rg = 0; rg < BR_RG; ++rg)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float dv = Ds[16 * rg + 4 * q4 + i][o];
+          s0 += dv * yv[rg][i].x; s1 += dv * yv[rg][i].y;
+        }
+      s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64);
+      s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
+      if (q4 == 0) {
+        atomicAdd(a.dw3 + pg + (long)o * AO_C + c0, s0);
+        atomicAdd(a.dw3 + pg + (long)o * AO_C + c0 + 1, s1);
+      }
+    }
+    if (a.db3 && t < a.n_out) {
+      float sb = 0.f;
+      for (int r = 0; r < BR_ROWS; ++r) sb += (m0 + r < a.rows) ? Ds[r][t] : 0.f;
+      atomicAdd(a.db3 + pg + t, sb);
+    }
+  }
+
   // gradient through ReLU [and LayerNorm] of one stage, in place: (u0, u1) = d_y -> d_h; rows beyond the group end become zero
   auto act_bwd = [&](const float* y_save, const float* h_save, const float* mean_save, const float* rstd_save, const float* gamma,
                      float* dgamma, float* dbeta, float* dst, float* dh_save) {

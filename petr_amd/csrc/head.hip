@@ -1473,7 +1473,10 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       memset(&bb, 0, sizeof bb);
       bb.param_gs = P.br_stride; bb.rows = (int)RG; bb.groups = G;
       if (!cfg->with_multi) {
-        RUN(wgrad(gw(lin_wgrad(d_raw, d.code, Wm + W.r2, C, Gp + P.reg_w[2], Gp + P.reg_b[2], RG, d.code, C), d.code, C)));
+        // (fused: the last Linear's 10 x 256 weight gradient is formed inside petr_branch_bwd - as a contraction of its own it was a
+        // 4-tile x 64-slice scalar-load launch of 40-55 us that sat beside the first cross-attention backward)
+        if (!bwd_fused)
+          RUN(wgrad(gw(lin_wgrad(d_raw, d.code, Wm + W.r2, C, Gp + P.reg_w[2], Gp + P.reg_b[2], RG, d.code, C), d.code, C)));
         if (!bwd_fused) {
           g = gd(lin_dgrad(d_raw, Pm + P.reg_w[2], d_r2, RG, d.code, C), d.code, C, C);
           g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.r2; g.ldr = C;
@@ -1507,7 +1510,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       float* d_r1 = Wm + W.s0_r1;
       if (bwd_fused) {        // the rest of the chain in one launch: d_r2 (given, or from d_raw), d_r1, d_outs
         petr_branch_bwd_args b = bb;
-        if (!cfg->with_multi) { b.d_out = d_raw; b.n_out = d.code; b.w3 = Pm + P.reg_w[2]; }
+        if (!cfg->with_multi) { b.d_out = d_raw; b.n_out = d.code; b.w3 = Pm + P.reg_w[2]; b.dw3 = Gp + P.reg_w[2]; b.db3 = Gp + P.reg_b[2]; }
         else b.d_y2 = d_r2;
         b.y2 = Wm + W.r2; b.w2 = Pm + P.reg_w[1]; b.y1 = Wm + W.r1; b.w1 = Pm + P.reg_w[0];
         b.d_h2 = d_r2; b.d_h1 = d_r1; b.d_x = Wm + W.d_outs;
@@ -1527,12 +1530,13 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // ---- cls branch: independent of the reg branch until the post-norm, so it runs beside it on side stream 0 and
       // leaves its input gradient in a buffer of its own (summed by the post-norm backward's prologue) ----
       void* sc = ln.side(0);          // (forked before the reg branch was enqueued, see above)
-      RUN(wgrad(gw(lin_wgrad(gr->d_cls, d.ncls, Wm + W.c2n, C, Gp + P.cls_w[2], Gp + P.cls_b[2], RG, d.ncls, C), d.ncls, C)));
+      if (!bwd_fused)
+        RUN(wgrad(gw(lin_wgrad(gr->d_cls, d.ncls, Wm + W.c2n, C, Gp + P.cls_w[2], Gp + P.cls_b[2], RG, d.ncls, C), d.ncls, C)));
       float* d_c2 = Wm + W.s0_c2;
       float* d_c1 = Wm + W.s0_c1;
       if (bwd_fused) {
         petr_branch_bwd_args b = bb;
-        b.d_out = gr->d_cls; b.n_out = d.ncls; b.w3 = Pm + P.cls_w[2];
+        b.d_out = gr->d_cls; b.n_out = d.ncls; b.w3 = Pm + P.cls_w[2]; b.dw3 = Gp + P.cls_w[2]; b.db3 = Gp + P.cls_b[2];
         b.y2 = Wm + W.c2n; b.h2 = Wm + W.c2; b.mean2 = Wm + W.c2_mean; b.rstd2 = Wm + W.c2_rstd; b.g2 = Pm + P.cls_g[1];
         b.w2 = Pm + P.cls_w[1];
         b.y1 = Wm + W.c1n; b.h1 = Wm + W.c1; b.mean1 = Wm + W.c1_mean; b.rstd1 = Wm + W.c1_rstd; b.g1 = Pm + P.cls_g[0];

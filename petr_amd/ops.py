@@ -195,6 +195,10 @@ def branch_bwd(fwd, w1, w2, w3=None, d_out=None, d_y2=None, ln1=None, ln2=None):
         d_out = _f32(d_out).contiguous()
         a.w3, a.d_out, a.n_out = ptr(i), _ptr(d_out), w3.shape[1]
         keep.append(d_out)
+        dw3 = torch.zeros((G, flat.shape[1]), dtype=torch.float32, device=dev)      # dW3 / db3 at the group stride of w3
+        db3 = torch.zeros((G, flat.shape[1]), dtype=torch.float32, device=dev)
+        a.dw3, a.db3 = dw3.data_ptr() + 4 * offs[i], db3.data_ptr() + 4 * offs[i]
+        keep += [dw3, db3]
         i += 1
     else:
         d_y2 = _f32(d_y2).contiguous()
@@ -217,6 +221,10 @@ def branch_bwd(fwd, w1, w2, w3=None, d_out=None, d_y2=None, ln1=None, ln2=None):
     a.d_h2, a.d_h1, a.d_x = _ptr(res['d_h2']), _ptr(res['d_h1']), _ptr(res['d_x'])
     a.rows, a.groups = rows, G
     _C.check(_C.lib().petr_branch_bwd(C.byref(a), _stream()), 'petr_branch_bwd')
+    if w3 is not None:
+        n3 = w3.shape[1]
+        res['dw3'] = dw3[:, offs[2]:offs[2] + n3 * Cc].view(G, n3, Cc)
+        res['db3'] = db3[:, offs[2]:offs[2] + n3]
     res['_keep'] = keep
     res['_launch'] = lambda: _C.check(_C.lib().petr_branch_bwd(C.byref(a), _stream()), 'petr_branch_bwd')
     return res

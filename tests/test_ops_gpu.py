@@ -258,9 +258,12 @@ def test_branch_bwd(ops, G, rows, n_out, ln):
         h2 = y1 @ d(w2).T + d(b2)
         h2.retain_grad()
         y2 = (F.layer_norm(h2, (256,), gam2, bet2, 1e-5) if ln else h2) * m2
-        top = (y2 @ d(w3).T + d(b3)) if n_out else y2
+        w3d, b3d = (d(w3).requires_grad_(True), d(b3).requires_grad_(True)) if n_out else (None, None)
+        top = (y2 @ w3d.T + b3d) if n_out else y2
         top.backward(d(d_top))
         want = {'d_x': xd.grad, 'd_h1': h1.grad, 'd_h2': h2.grad}
+        if n_out:
+            want.update(dw3=w3d.grad, db3=b3d.grad)
         if ln:
             want.update(dg1=gam1.grad, dbe1=bet1.grad, dg2=gam2.grad, dbe2=bet2.grad)
         for k, v in want.items():

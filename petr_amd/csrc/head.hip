@@ -1789,26 +1789,36 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
             (void)hipEventRecord(ev_q[i], ln.ctx->side[i]);
           }
       }
+      // With side streams the whole chain (seven small launches, 86 us at c5 / 117 us at p4-1600) runs on side stream 0: nothing on
+      // the main stream depends on it, and standing in the main stream it delayed the position-embedding input gradients - and
+      // with them the token-sized weight gradients that end the step - by its full length (PETR_QE_SIDE=0: main stream)
+      static const bool qe_side_env = petr_tune("PETR_QE_SIDE", 1) != 0;
       auto query_embedding_bwd = [&](bool early) -> int {
         petr_gemm_args g;
-        if (early) {
+        const bool on_side = early && qe_side_env && ln.ctx && ln.ctx->n_side >= 2;
+        void* sq = on_side ? (void*)ln.ctx->side[0] : s;
+        if (on_side) {
+          if (ev_q[1]) (void)hipStreamWaitEvent((hipStream_t)sq, ev_q[1], 0);      // (ev_q[0] was recorded on this very stream)
+        } else if (early) {
           for (int i = 0; i < 2; ++i)
             if (ev_q[i]) (void)hipStreamWaitEvent(ln.main, ev_q[i], 0);
         } else {
           ln.join(0);
           ln.join(1);
         }
-        RUN(petr_reduce_batch(Wm + W.d_e_slab, 2 * d.NL * d.B, d.Q, C, Wm + W.d_e, 0, s));
-        // query_embedding MLP + pos2posemb3d (petr_head.py:422-423)
-        RUN(wgrad(lin_wgrad(Wm + W.d_e, C, Wm + W.qe_h, C, Gp + P.qe_w2, Gp + P.qe_b2, d.Q, C, C)));
+        RUN(petr_reduce_batch(Wm + W.d_e_slab, 2 * d.NL * d.B, d.Q, C, Wm + W.d_e, 0, sq));
+        // query_embedding MLP + pos2posemb3d (petr_head.py:422-423); on the side stream its weight gradients follow in order
+        g = lin_wgrad(Wm + W.d_e, C, Wm + W.qe_h, C, Gp + P.qe_w2, Gp + P.qe_b2, d.Q, C, C);
+        if (on_side) RUN(petr_gemm(&g, sq)); else RUN(wgrad(g));
         g = lin_dgrad(Wm + W.d_e, Pm + P.qe_w2, Wm + W.d_qe_h, d.Q, C, C);
         g.flags = PETR_GEMM_RELU_MASK; g.r = Wm + W.qe_h; g.ldr = C;
-        RUN(petr_gemm(&g, s));
-        RUN(wgrad(lin_wgrad(Wm + W.d_qe_h, C, Wm + W.posemb, C * 3 / 2, Gp + P.qe_w1, Gp + P.qe_b1, d.Q, C, C * 3 / 2)));
+        RUN(petr_gemm(&g, sq));
+        g = lin_wgrad(Wm + W.d_qe_h, C, Wm + W.posemb, C * 3 / 2, Gp + P.qe_w1, Gp + P.qe_b1, d.Q, C, C * 3 / 2);
+        if (on_side) RUN(petr_gemm(&g, sq)); else RUN(wgrad(g));
         g = lin_dgrad(Wm + W.d_qe_h, Pm + P.qe_w1, Wm + W.d_posemb, d.Q, C, C * 3 / 2);
-        RUN(petr_gemm(&g, s));
-        RUN(petr_posemb3d_bwd(Pm + P.ref, io->dim_t, Wm + W.d_posemb, Wm + W.d_ref_tmp, d.Q, C / 2, s));
-        RUN(petr_axpy(Gp + P.ref, Wm + W.d_ref_tmp, 1.f, (long)d.Q * 3, s));
+        RUN(petr_gemm(&g, sq));
+        RUN(petr_posemb3d_bwd(Pm + P.ref, io->dim_t, Wm + W.d_posemb, Wm + W.d_ref_tmp, d.Q, C / 2, sq));
+        RUN(petr_axpy(Gp + P.ref, Wm + W.d_ref_tmp, 1.f, (long)d.Q * 3, sq));
         return PETR_OK;
       };
       // (opt-in schedule) the K/V projection backward of every layer ran on the side streams behind its layer: wait for it
@@ -1861,6 +1871,18 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         g = L16(g);
         RUN(petr_gemm(&g, s));
       }
+      // input_proj's weight gradient as soon as d_mem is final: it is the slowest of the stage's token-sized weight gradients
+      // (one 256 x 256 tile set over all tokens: 158 us at 24 000 tokens) and used to be queued last, where it ended the step
+      {
+        petr_gemm_args g = gemm0();        // dW[C, Cin] += sum_{view,hw} d_mem[view*HW+hw][o] * x[view][ci][hw]
+        g.a = Wm + W.d_mem; g.lda = C; g.a_kcontig = 0;
+        g.b = io->feats; g.ldb = d.HW; g.b_kcontig = 1;
+        g.c = Gp + P.in_w; g.ldc = d.Cin; g.a_colsum = Gp + P.in_b;
+        g.M = C; g.N = d.Cin; g.K = V * d.HW;
+        g.k_seg = d.HW; g.a_seg_stride = (long)d.HW * C; g.b_seg_stride = (long)d.Cin * d.HW;
+        g.flags = PETR_GEMM_ATOMIC; g.split_k = 16;
+        RUN(wgrad(L16(g)));
+      }
       // position_encoder and adapt_pos3d (inputs carry no gradient)
       for (int which = 0; which < 2; ++which) {
         const long w1 = which == 0 ? P.pe_w1 : P.ad_w1, b1 = which == 0 ? P.pe_b1 : P.ad_b1;
@@ -1889,14 +1911,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       }
       // input_proj
       {
-        petr_gemm_args g = gemm0();        // dW[C, Cin] += sum_{view,hw} d_mem[view*HW+hw][o] * x[view][ci][hw]
-        g.a = Wm + W.d_mem; g.lda = C; g.a_kcontig = 0;
-        g.b = io->feats; g.ldb = d.HW; g.b_kcontig = 1;
-        g.c = Gp + P.in_w; g.ldc = d.Cin; g.a_colsum = Gp + P.in_b;
-        g.M = C; g.N = d.Cin; g.K = V * d.HW;
-        g.k_seg = d.HW; g.a_seg_stride = (long)d.HW * C; g.b_seg_stride = (long)d.Cin * d.HW;
-        g.flags = PETR_GEMM_ATOMIC; g.split_k = 16;
-        RUN(wgrad(L16(g)));
+        petr_gemm_args g;
         if (gr->d_feats) {
           g = gemm0();      // d_x[view][ci][hw] = sum_o W[o][ci] * d_mem[view*HW+hw][o]
           g.a = Wp(P.in_w); g.lda = d.Cin; g.a_kcontig = 0;

@@ -609,6 +609,198 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_deep_kernel(const petr_gemm_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Both operands K-major (x[k * ld + row]): the weight gradients over all tokens - dW = dY^T X with dY [tokens][out] and
+// X [tokens][in] exactly as they lie in memory (dW_k / dW_v of the K / V projections, the second position-embedding
+// convolutions).  The kernel above stages such a tile with sixteen 2- or 4-byte loads per thread and operand and K step
+// (one element of sixteen consecutive k for one row) - 130-215 TFLOP/s on 24 000-token shapes whose HBM floor is 6-8x lower.
+// Here the LDS image KEEPS the memory layout, [k][row] at a pitch of 144 elements: a thread stages 16 consecutive rows of ONE k
+// with 16-byte loads (two for a bf16 source, four for fp32) and two 16-byte LDS stores, and the MFMA fragments - 8 consecutive k
+// of one row per lane - come out of that image through ds_read_b64_tr_b16 (the transposing LDS read of gfx950; the lane / k
+// mapping is the one mha_bwd_bf16.hip uses for its dV / dK products, identical for both operands, so the permuted k order
+// inside a 16-deep block cancels).  Pitch 144: the four rows of a 4 x 16 transposed block fall 8 banks apart.
+// Needs M, N multiples of 128, 16-byte aligned rows, PETR_GEMM_ATOMIC accumulation (K slices over workgroups); a_colsum as in
+// the general kernel.  Everything else (K segments, two batch dims) follows petr_gemm_args.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int KM_PITCH = 144;
+typedef short km_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ km_s16x4 km_tr16(const uint16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((km_s16x4 __attribute__((address_space(3)))*)p);
+}
+__device__ __forceinline__ hbf16x8 km_cat8(km_s16x4 lo, km_s16x4 hi) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(hbf16x8, v);
+}
+
+// 16 consecutive rows of one k, as they come from memory (S16: bf16, else fp32)
+template <bool S16>
+struct KmStage {
+  uint4 x[S16 ? 2 : 4];
+  __device__ __forceinline__ void load(const char* base, long ld, int k, int row) {      // base in bytes, ld / row in elements
+    constexpr int E = S16 ? 2 : 4;
+    const uint4* src = reinterpret_cast<const uint4*>(base + ((long)k * ld + row) * E);
+#pragma unroll
+    for (int i = 0; i < (S16 ? 2 : 4); ++i) x[i] = src[i];
+  }
+  __device__ __forceinline__ void store(uint16_t* dst, bool ok) const {
+    uint4 a, b;
+    if (S16) {
+      a = x[0]; b = x[1];
+    } else {
+      const float4 f0 = __builtin_bit_cast(float4, x[0]), f1 = __builtin_bit_cast(float4, x[1]);
+      const float4 f2 = __builtin_bit_cast(float4, x[2 % (S16 ? 2 : 4)]), f3 = __builtin_bit_cast(float4, x[3 % (S16 ? 2 : 4)]);
+      const uint2 p0 = pack4(f0.x, f0.y, f0.z, f0.w), p1 = pack4(f1.x, f1.y, f1.z, f1.w);
+      const uint2 p2 = pack4(f2.x, f2.y, f2.z, f2.w), p3 = pack4(f3.x, f3.y, f3.z, f3.w);
+      a = make_uint4(p0.x, p0.y, p1.x, p1.y);
+      b = make_uint4(p2.x, p2.y, p3.x, p3.y);
+    }
+    if (!ok) a = b = make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint4*>(dst)[0] = a;
+    reinterpret_cast<uint4*>(dst)[1] = b;
+  }
+  // the 16 values as floats (column sums)
+  __device__ __forceinline__ void add_to(float (&s)[16]) const {
+    if (S16) {
+      const uint32_t w[8] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[2 * j] += __uint_as_float(w[j] << 16); s[2 * j + 1] += __uint_as_float(w[j] & 0xFFFF0000u); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 f = __builtin_bit_cast(float4, x[i % (S16 ? 2 : 4)]);
+        s[4 * i] += f.x; s[4 * i + 1] += f.y; s[4 * i + 2] += f.z; s[4 * i + 3] += f.w;
+      }
+    }
+  }
+};
+
+template <bool A16, bool B16>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_km_kernel(const petr_gemm_args g, const int tiles_m, const int tiles_n) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2][2 * GB_BK * KM_PITCH];      // [buffer][A image | B image], 36 KB
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int h = lane >> 5, c = lane & 31;
+  const int zn = g.nb0 * g.nb1 * g.split_k;
+  const int lin = xcd_remap(blockIdx.x, tiles_m * tiles_n * zn);
+  const int tile = lin / zn;
+  const int tm_i = tile / tiles_n, tn_i = tile - tm_i * tiles_n;
+  const int m0 = tm_i * GB_BM, n0 = tn_i * GB_BN;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  int z = lin - tile * zn;
+  const int ks = z % g.split_k;
+  z /= g.split_k;
+  const int z1 = z % g.nb1, z0 = z / g.nb1;
+  constexpr int AE = A16 ? 2 : 4, BE = B16 ? 2 : 4;
+  const char* Ab = reinterpret_cast<const char*>(g.a) + (z0 * g.a_bs0 + z1 * g.a_bs1) * AE;
+  const char* Bb = reinterpret_cast<const char*>(g.b) + (z0 * g.b_bs0 + z1 * g.b_bs1) * BE;
+
+  const int kseg = g.k_seg > 0 ? g.k_seg : g.K;
+  const int nseg = g.k_seg > 0 ? g.K / g.k_seg : 1;
+  const int tps = (kseg + GB_BK - 1) / GB_BK;
+  const int ktiles = nseg * tps;
+  const int kt_per = (ktiles + g.split_k - 1) / g.split_k;
+  const int kt_begin = ks * kt_per;
+  const int kt_end = min(ktiles, kt_begin + kt_per);
+
+  // staging role: k = t >> 3 of the step, rows 16 (t & 7) .. + 15 of the tile
+  const int sk = t >> 3, sr = 16 * (t & 7);
+  KmStage<A16> sa;
+  KmStage<B16> sb;
+  bool ok_nxt = true;
+  auto gload = [&](int kt, bool& ok) {
+    const int seg = kt / tps;
+    const int k = (kt - seg * tps) * GB_BK + sk;
+    ok = k < kseg;
+    const int kc = min(k, kseg - 1);                       // past the segment: a valid row, zero-filled at the store
+    sa.load(Ab + (long)seg * g.a_seg_stride * AE, g.lda, kc, m0 + sr);
+    sb.load(Bb + (long)seg * g.b_seg_stride * BE, g.ldb, kc, n0 + sr);
+  };
+  const bool do_colsum = g.a_colsum != nullptr && tn_i == 0;
+  float colacc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) colacc[e] = 0.f;
+  auto lstore = [&](int buf, bool ok) {
+    if (do_colsum && ok) sa.add_to(colacc);
+    sa.store(lds[buf] + sk * KM_PITCH + sr, ok);
+    sb.store(lds[buf] + GB_BK * KM_PITCH + sk * KM_PITCH + sr, ok);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposed-read lane constants (mha_bwd_bf16.hip): lane l of a 16-lane group supplies row (l & 15) >> 2, columns 4 (l & 3) ..
+  // of a 4 x 16 block and receives column l & 15 of its four rows; lanes 16-31 take the next 16 columns, the upper half wave
+  // the next 4 k
+  const int tr_q = (lane & 15) >> 2;
+  const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  (void)c;
+
+  const int nk = kt_end - kt_begin;
+  if (nk > 0) {
+    bool ok_cur;
+    gload(kt_begin, ok_cur);
+    lstore(0, ok_cur);
+    if (nk > 1) gload(kt_begin + 1, ok_nxt);
+    for (int it = 0; it < nk; ++it) {
+      const int buf = it & 1;
+      __syncthreads();                       // image `buf` complete; the other one is free again
+      if (it + 1 < nk) {
+        lstore(buf ^ 1, ok_nxt);
+        if (it + 2 < nk) gload(kt_begin + it + 2, ok_nxt);
+      }
+      const uint16_t* As = lds[buf];
+      const uint16_t* Bs = As + GB_BK * KM_PITCH;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {          // two 16-deep chunks of the K step
+        hbf16x8 fa[2], fb[2];
+        const int r0 = (16 * j + 4 * h + tr_q) * KM_PITCH + tr_col, r1 = r0 + 8 * KM_PITCH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[i] = km_cat8(km_tr16(As + r0 + wm + 32 * i), km_tr16(As + r1 + wm + 32 * i));
+          fb[i] = km_cat8(km_tr16(Bs + r0 + wn + 32 * i), km_tr16(Bs + r1 + wn + 32 * i));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
+      }
+    }
+  }
+
+  if (do_colsum) {        // the 32 k-threads of a 16-row group: sum through the (now free) LDS, one atomic per row
+    __syncthreads();
+    float* cs = reinterpret_cast<float*>(&lds[0][0]);                 // [32 k][128 rows + 4] floats = 16.9 KB
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cs[sk * 132 + sr + e] = colacc[e];
+    __syncthreads();
+    if (t < GB_BM) {
+      float v = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < GB_BK; ++k) v += cs[k * 132 + t];
+      atomicAdd(g.a_colsum + z0 * g.cs_bs0 + z1 * g.cs_bs1 + m0 + t, v);
+    }
+  }
+
+  // ---- epilogue: float atomics (M, N multiples of 128: no ragged tile) ----
+  float* C = g.c + z0 * g.c_bs0 + z1 * g.c_bs1;
+#pragma unroll
+  for (int jn = 0; jn < 2; ++jn) {
+    const int n = n0 + wn + 32 * jn + c;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + 32 * i + mfma32_row(r, h);
+        atomicAdd(C + (long)m * g.ldc + n, acc[i][jn][r] * g.alpha);
+      }
+  }
+}
 }  // namespace
 
 // called by petr_gemm() for PETR_GEMM_BF16 requests that gemm.hip's plain-epilogue kernels do not take
@@ -633,6 +825,28 @@ int petr_gemm_bf16_general(const petr_gemm_args& g, hipStream_t s) {
              PETR_ERR_UNSUPPORTED, "gemm: PETR_GEMM_BF16 operand batch/segment must span < 2^31 elements");
   const int tm = (int)cdiv(g.M, GB_BM), tn = (int)cdiv(g.N, GB_BN);
   const bool a16 = (g.flags & PETR_GEMM_A_BF16) != 0, b16 = (g.flags & PETR_GEMM_B_BF16) != 0;
+  // both operands K-major, full 128 x 128 tiles, 16-byte rows, atomic accumulation: the transposed-read kernel
+  // (PETR_GEMM16_KM=0, diagnostic builds: the general kernel)
+  {
+    const int am = a16 ? 7 : 3, bm = b16 ? 7 : 3;
+    const int other = g.flags & ~(PETR_GEMM_BF16 | PETR_GEMM_A_BF16 | PETR_GEMM_B_BF16 | PETR_GEMM_ATOMIC);
+    static const bool km_on = petr_tune("PETR_GEMM16_KM", 1) != 0;
+    if (km_on && !g.a_kcontig && !g.b_kcontig && (g.flags & PETR_GEMM_ATOMIC) && !other && !g.bias && !g.r && g.c_nblk <= 0 &&
+        !(g.M % GB_BM) && !(g.N % GB_BN) && !(g.lda & am) && !(g.ldb & bm) && !(g.a_bs0 & am) && !(g.a_bs1 & am) && !(g.b_bs0 & bm) &&
+        !(g.b_bs1 & bm) && !(g.a_seg_stride & am) && !(g.b_seg_stride & bm) && aligned16(g.a) && aligned16(g.b)) {
+      DropDev dd;
+      memcpy(&dd, &g.drop, sizeof dd);
+      if (!dd.thr) {
+        dim3 grid(tm * tn * g.nb0 * g.nb1 * g.split_k), block(256);
+        if (a16 && b16) hipLaunchKernelGGL((gemm_bf16_km_kernel<true, true>), grid, block, 0, s, g, tm, tn);
+        else if (a16) hipLaunchKernelGGL((gemm_bf16_km_kernel<true, false>), grid, block, 0, s, g, tm, tn);
+        else if (b16) hipLaunchKernelGGL((gemm_bf16_km_kernel<false, true>), grid, block, 0, s, g, tm, tn);
+        else hipLaunchKernelGGL((gemm_bf16_km_kernel<false, false>), grid, block, 0, s, g, tm, tn);
+        PETR_LAUNCH_CHECK("gemm_bf16_km");
+        return PETR_OK;
+      }
+    }
+  }
   // the deep-step kernel (K step 128, LDS epilogue) is the default; PETR_GEMM16_DEEP=0 selects the K-step-32 kernel
   static const bool deep_on = petr_tune("PETR_GEMM16_DEEP", 1) != 0;
   // K slices: only short ones (<= 4 deep steps per slice: the split FFN contractions of the 900-row chain); long slices

@@ -798,6 +798,31 @@ def test_mha_bwd_bf16(ops, B, H, Q, L, masked, drop):
     assert torch.isfinite(dq).all() and torch.isfinite(dk).all() and torch.isfinite(dv).all()
 
 
+@pytest.mark.parametrize('a16,b16', [(False, False), (True, False), (False, True), (True, True)])
+def test_gemm_bf16_kmajor_weight_gradient_batched(ops, a16, b16):
+    """The transposed-LDS-read kernel (both operands K-major, 128 x 128 tiles, float atomics): three batched weight gradients
+    (the per-layer dW_k of the K projections) over K = 2 segments of 1 500 rows (ragged last K step), cut into 7 K slices,
+    fp32 / bf16 sources, with the column sums of A."""
+    from petr_amd import _C
+    g = torch.Generator().manual_seed(31 + 2 * a16 + b16)
+    NB, Mo, No, seg, nseg = 3, 256, 384, 1500, 2
+    dy = torch.randn(nseg, NB, seg, Mo, generator=g)          # [segment][batch][k][m]
+    x = torch.randn(nseg, seg, No, generator=g)               # [segment][k][n], shared by the batch
+    dw = torch.zeros(NB, Mo, No, device='cuda')
+    db = torch.zeros(NB, Mo, device='cuda')
+    fl = _C.GEMM_BF16 | _C.GEMM_ATOMIC | (_C.GEMM_A_BF16 if a16 else 0) | (_C.GEMM_B_BF16 if b16 else 0)
+    a_dev = dy.cuda().bfloat16() if a16 else dy.cuda()
+    b_dev = x.cuda().bfloat16() if b16 else x.cuda()
+    ops.gemm_raw(a=a_dev, lda=Mo, a_kcontig=0, a_bs0=seg * Mo, b=b_dev, ldb=No, b_kcontig=0, b_bs0=0, c=dw, ldc=No, c_bs0=Mo * No,
+                 M=Mo, N=No, K=nseg * seg, k_seg=seg, a_seg_stride=NB * seg * Mo, b_seg_stride=seg * No, split_k=7, a_colsum=db,
+                 cs_bs0=Mo, flags=fl, alpha=1.0, nb0=NB, nb1=1)
+    for bi in range(NB):
+        want = sum(_bf(dy[sg, bi]).T @ _bf(x[sg]) for sg in range(nseg))
+        assert relerr(dw[bi], want) < 3e-5, (bi, relerr(dw[bi], want))
+        col = (_bf(dy[:, bi]) if a16 else dy[:, bi].double()).sum((0, 1))
+        assert relerr(db[bi], col) < 1e-5
+
+
 def test_gemm_bf16_sources(ops):
     """PETR_GEMM_A_BF16 / _B_BF16 / _R_BF16: operands already stored as bf16 (the activations a producing epilogue wrote with
     PETR_GEMM_STORE_BF16, the bf16 dK / dV of the attention backward).  Bit-for-bit the same product as rounding the fp32

@@ -676,9 +676,14 @@ struct KmStage {
   }
 };
 
-template <bool A16, bool B16>
+// BKC: the B operand is K-CONTIGUOUS instead (x[row * ld + k]: an NCHW map read as [channel][pixel] - the first convolutions'
+// and input_proj's weight gradients, dW = dY^T X with X the [view][c][hw] planes).  Its tile is staged like the general
+// kernel's ([row][32 k] image, pitch 40) and its fragments are read as TWO 8-byte pieces per 16-deep chunk, at k = 4 h and
+// 8 + 4 h - the k order the transposed reads of A produce; N may be ragged (192 = 3 D channels).
+template <bool A16, bool B16, bool BKC>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_km_kernel(const petr_gemm_args g, const int tiles_m, const int tiles_n) {
-  __shared__ __attribute__((aligned(16))) uint16_t lds[2][2 * GB_BK * KM_PITCH];      // [buffer][A image | B image], 36 KB
+  constexpr int B_IMG = BKC ? GB_BN * GB_PITCH : GB_BK * KM_PITCH;                  // elements of a B image
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2][GB_BK * KM_PITCH + B_IMG];   // [buffer][A image | B image]
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int h = lane >> 5, c = lane & 31;
   const int zn = g.nb0 * g.nb1 * g.split_k;
@@ -707,23 +712,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_km_kernel(const petr_gemm_ar
   const int sk = t >> 3, sr = 16 * (t & 7);
   KmStage<A16> sa;
   KmStage<B16> sb;
+  typename StageSel<true, B16>::type sbk;                  // BKC
+  if (BKC) sbk.init(g.ldb, n0, g.N);
+  const bool rows_ragged_b = BKC && n0 + GB_BN > g.N;
   bool ok_nxt = true;
-  auto gload = [&](int kt, bool& ok) {
+  int k0_nxt = 0;
+  auto gload = [&](int kt, bool& ok, int& k0_out) {
     const int seg = kt / tps;
-    const int k = (kt - seg * tps) * GB_BK + sk;
+    const int k0 = (kt - seg * tps) * GB_BK;
+    const int k = k0 + sk;
+    k0_out = k0;
     ok = k < kseg;
     const int kc = min(k, kseg - 1);                       // past the segment: a valid row, zero-filled at the store
     sa.load(Ab + (long)seg * g.a_seg_stride * AE, g.lda, kc, m0 + sr);
-    sb.load(Bb + (long)seg * g.b_seg_stride * BE, g.ldb, kc, n0 + sr);
+    if (BKC) sbk.load(reinterpret_cast<const float*>(Bb + (long)seg * g.b_seg_stride * BE), g.ldb, k0, kseg);
+    else sb.load(Bb + (long)seg * g.b_seg_stride * BE, g.ldb, kc, n0 + sr);
   };
   const bool do_colsum = g.a_colsum != nullptr && tn_i == 0;
   float colacc[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) colacc[e] = 0.f;
-  auto lstore = [&](int buf, bool ok) {
+  auto lstore = [&](int buf, bool ok, int k0) {
     if (do_colsum && ok) sa.add_to(colacc);
     sa.store(lds[buf] + sk * KM_PITCH + sr, ok);
-    sb.store(lds[buf] + GB_BK * KM_PITCH + sk * KM_PITCH + sr, ok);
+    if (BKC) sbk.store(lds[buf] + GB_BK * KM_PITCH, rows_ragged_b || k0 + GB_BK > kseg, k0, kseg);
+    else sb.store(lds[buf] + GB_BK * KM_PITCH + sk * KM_PITCH + sr, ok);
   };
 
   f32x16 acc[2][2];
@@ -739,20 +752,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_km_kernel(const petr_gemm_ar
   // the next 4 k
   const int tr_q = (lane & 15) >> 2;
   const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  (void)c;
 
   const int nk = kt_end - kt_begin;
   if (nk > 0) {
     bool ok_cur;
-    gload(kt_begin, ok_cur);
-    lstore(0, ok_cur);
-    if (nk > 1) gload(kt_begin + 1, ok_nxt);
+    int k0_cur;
+    gload(kt_begin, ok_cur, k0_cur);
+    lstore(0, ok_cur, k0_cur);
+    if (nk > 1) gload(kt_begin + 1, ok_nxt, k0_nxt);
     for (int it = 0; it < nk; ++it) {
       const int buf = it & 1;
       __syncthreads();                       // image `buf` complete; the other one is free again
       if (it + 1 < nk) {
-        lstore(buf ^ 1, ok_nxt);
-        if (it + 2 < nk) gload(kt_begin + it + 2, ok_nxt);
+        lstore(buf ^ 1, ok_nxt, k0_nxt);
+        if (it + 2 < nk) gload(kt_begin + it + 2, ok_nxt, k0_nxt);
       }
       const uint16_t* As = lds[buf];
       const uint16_t* Bs = As + GB_BK * KM_PITCH;
@@ -763,7 +776,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_km_kernel(const petr_gemm_ar
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           fa[i] = km_cat8(km_tr16(As + r0 + wm + 32 * i), km_tr16(As + r1 + wm + 32 * i));
-          fb[i] = km_cat8(km_tr16(Bs + r0 + wn + 32 * i), km_tr16(Bs + r1 + wn + 32 * i));
+          if (BKC) {
+            const uint16_t* br = Bs + (wn + 32 * i + c) * GB_PITCH + 16 * j + 4 * h;
+            const uint2 lo = *reinterpret_cast<const uint2*>(br), hi = *reinterpret_cast<const uint2*>(br + 8);
+            fb[i] = __builtin_bit_cast(hbf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+          } else {
+            fb[i] = km_cat8(km_tr16(Bs + r0 + wn + 32 * i), km_tr16(Bs + r1 + wn + 32 * i));
+          }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -787,11 +806,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_km_kernel(const petr_gemm_ar
     }
   }
 
-  // ---- epilogue: float atomics (M, N multiples of 128: no ragged tile) ----
+  // ---- epilogue: float atomics (M a multiple of 128; N too unless B is K-contiguous) ----
   float* C = g.c + z0 * g.c_bs0 + z1 * g.c_bs1;
 #pragma unroll
   for (int jn = 0; jn < 2; ++jn) {
     const int n = n0 + wn + 32 * jn + c;
+    if (BKC && n >= g.N) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -831,17 +851,23 @@ int petr_gemm_bf16_general(const petr_gemm_args& g, hipStream_t s) {
     const int am = a16 ? 7 : 3, bm = b16 ? 7 : 3;
     const int other = g.flags & ~(PETR_GEMM_BF16 | PETR_GEMM_A_BF16 | PETR_GEMM_B_BF16 | PETR_GEMM_ATOMIC);
     static const bool km_on = petr_tune("PETR_GEMM16_KM", 1) != 0;
-    if (km_on && !g.a_kcontig && !g.b_kcontig && (g.flags & PETR_GEMM_ATOMIC) && !other && !g.bias && !g.r && g.c_nblk <= 0 &&
-        !(g.M % GB_BM) && !(g.N % GB_BN) && !(g.lda & am) && !(g.ldb & bm) && !(g.a_bs0 & am) && !(g.a_bs1 & am) && !(g.b_bs0 & bm) &&
+    // (a K-contiguous B has passed the alignment checks above; its N may be ragged)
+    if (km_on && !g.a_kcontig && (g.flags & PETR_GEMM_ATOMIC) && !other && !g.bias && !g.r && g.c_nblk <= 0 && !(g.M % GB_BM) &&
+        (g.b_kcontig || !(g.N % GB_BN)) && !(g.lda & am) && !(g.ldb & bm) && !(g.a_bs0 & am) && !(g.a_bs1 & am) && !(g.b_bs0 & bm) &&
         !(g.b_bs1 & bm) && !(g.a_seg_stride & am) && !(g.b_seg_stride & bm) && aligned16(g.a) && aligned16(g.b)) {
       DropDev dd;
       memcpy(&dd, &g.drop, sizeof dd);
       if (!dd.thr) {
         dim3 grid(tm * tn * g.nb0 * g.nb1 * g.split_k), block(256);
-        if (a16 && b16) hipLaunchKernelGGL((gemm_bf16_km_kernel<true, true>), grid, block, 0, s, g, tm, tn);
-        else if (a16) hipLaunchKernelGGL((gemm_bf16_km_kernel<true, false>), grid, block, 0, s, g, tm, tn);
-        else if (b16) hipLaunchKernelGGL((gemm_bf16_km_kernel<false, true>), grid, block, 0, s, g, tm, tn);
-        else hipLaunchKernelGGL((gemm_bf16_km_kernel<false, false>), grid, block, 0, s, g, tm, tn);
+#define PETR_KM(BKC)                                                                                              \
+  do {                                                                                                            \
+    if (a16 && b16) hipLaunchKernelGGL((gemm_bf16_km_kernel<true, true, BKC>), grid, block, 0, s, g, tm, tn);     \
+    else if (a16) hipLaunchKernelGGL((gemm_bf16_km_kernel<true, false, BKC>), grid, block, 0, s, g, tm, tn);      \
+    else if (b16) hipLaunchKernelGGL((gemm_bf16_km_kernel<false, true, BKC>), grid, block, 0, s, g, tm, tn);      \
+    else hipLaunchKernelGGL((gemm_bf16_km_kernel<false, false, BKC>), grid, block, 0, s, g, tm, tn);              \
+  } while (0)
+        if (g.b_kcontig) PETR_KM(true); else PETR_KM(false);
+#undef PETR_KM
         PETR_LAUNCH_CHECK("gemm_bf16_km");
         return PETR_OK;
       }

@@ -823,6 +823,27 @@ def test_gemm_bf16_kmajor_weight_gradient_batched(ops, a16, b16):
         assert relerr(db[bi], col) < 1e-5
 
 
+@pytest.mark.parametrize('a16,Mo,Cin,V,HW', [(True, 1024, 192, 3, 1000), (False, 256, 256, 2, 704), (True, 1024, 384, 2, 4000),
+                                             (False, 1024, 192, 2, 700)])
+def test_gemm_bf16_weight_gradient_nchw_operand(ops, a16, Mo, Cin, V, HW):
+    """dW[Mo, Cin] += sum_{view, hw} dY[view*HW + hw][o] X[view][c][hw]: A K-major (tokens x outputs, fp32 or bf16), B the NCHW
+    planes read K-CONTIGUOUS (one K segment per view), float atomics, K slices, column sums - the first position-embedding
+    convolutions' and input_proj's weight gradients (head.hip final stage).  Cin = 192: ragged N tile; HW = 700: ragged K step."""
+    from petr_amd import _C
+    g = torch.Generator().manual_seed(Mo + Cin + HW)
+    dy = torch.randn(V * HW, Mo, generator=g)
+    x = torch.randn(V, Cin, HW, generator=g)
+    dw = torch.zeros(Mo, Cin, device='cuda')
+    db = torch.zeros(Mo, device='cuda')
+    a_dev = dy.cuda().bfloat16() if a16 else dy.cuda()
+    ops.gemm_raw(a=a_dev, lda=Mo, a_kcontig=0, b=x.cuda(), ldb=HW, b_kcontig=1, c=dw, ldc=Cin, a_colsum=db, M=Mo, N=Cin, K=V * HW,
+                 k_seg=HW, a_seg_stride=HW * Mo, b_seg_stride=Cin * HW, split_k=8, alpha=1.0, nb0=1, nb1=1,
+                 flags=_C.GEMM_BF16 | _C.GEMM_ATOMIC | (_C.GEMM_A_BF16 if a16 else 0))
+    want = _bf(dy).T @ _bf(x.permute(0, 2, 1).reshape(V * HW, Cin))
+    assert relerr(dw, want) < 3e-5, relerr(dw, want)
+    assert relerr(db, (_bf(dy) if a16 else dy.double()).sum(0)) < 1e-5
+
+
 def test_gemm_bf16_sources(ops):
     """PETR_GEMM_A_BF16 / _B_BF16 / _R_BF16: operands already stored as bf16 (the activations a producing epilogue wrote with
     PETR_GEMM_STORE_BF16, the bf16 dK / dV of the attention backward).  Bit-for-bit the same product as rounding the fp32

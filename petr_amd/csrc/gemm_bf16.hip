@@ -358,6 +358,61 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_gen_kernel(const petr_gemm_a
   }
 }
 
+// ---- K-major operand tiles kept in their memory layout [k][row], fragments through ds_read_b64_tr_b16 (see
+//      gemm_bf16_km_kernel below for the full story) ----
+constexpr int KM_PITCH = 144;
+typedef short km_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ km_s16x4 km_tr16(const uint16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((km_s16x4 __attribute__((address_space(3)))*)p);
+}
+__device__ __forceinline__ hbf16x8 km_cat8(km_s16x4 lo, km_s16x4 hi) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(hbf16x8, v);
+}
+
+// 16 consecutive rows of one k, as they come from memory (S16: bf16, else fp32)
+template <bool S16>
+struct KmStage {
+  uint4 x[S16 ? 2 : 4];
+  __device__ __forceinline__ void load(const char* base, long ld, int k, int row) {      // base in bytes, ld / row in elements
+    constexpr int E = S16 ? 2 : 4;
+    const uint4* src = reinterpret_cast<const uint4*>(base + ((long)k * ld + row) * E);
+#pragma unroll
+    for (int i = 0; i < (S16 ? 2 : 4); ++i) x[i] = src[i];
+  }
+  __device__ __forceinline__ void store(uint16_t* dst, bool ok) const {
+    uint4 a, b;
+    if (S16) {
+      a = x[0]; b = x[1];
+    } else {
+      const float4 f0 = __builtin_bit_cast(float4, x[0]), f1 = __builtin_bit_cast(float4, x[1]);
+      const float4 f2 = __builtin_bit_cast(float4, x[2 % (S16 ? 2 : 4)]), f3 = __builtin_bit_cast(float4, x[3 % (S16 ? 2 : 4)]);
+      const uint2 p0 = pack4(f0.x, f0.y, f0.z, f0.w), p1 = pack4(f1.x, f1.y, f1.z, f1.w);
+      const uint2 p2 = pack4(f2.x, f2.y, f2.z, f2.w), p3 = pack4(f3.x, f3.y, f3.z, f3.w);
+      a = make_uint4(p0.x, p0.y, p1.x, p1.y);
+      b = make_uint4(p2.x, p2.y, p3.x, p3.y);
+    }
+    if (!ok) a = b = make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint4*>(dst)[0] = a;
+    reinterpret_cast<uint4*>(dst)[1] = b;
+  }
+  // the 16 values as floats (column sums)
+  __device__ __forceinline__ void add_to(float (&s)[16]) const {
+    if (S16) {
+      const uint32_t w[8] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[2 * j] += __uint_as_float(w[j] << 16); s[2 * j + 1] += __uint_as_float(w[j] & 0xFFFF0000u); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 f = __builtin_bit_cast(float4, x[i % (S16 ? 2 : 4)]);
+        s[4 * i] += f.x; s[4 * i + 1] += f.y; s[4 * i + 2] += f.z; s[4 * i + 3] += f.w;
+      }
+    }
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // Deep-step version of the kernel above: K step 128 instead of 32, the whole step of both operands in flight at once.
 //
@@ -376,9 +431,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_gen_kernel(const petr_gemm_a
 constexpr int GD_BK = 128, GD_PITCH = 136, GD_CP = 132;
 constexpr size_t GD_LDS_BYTES = (size_t)(GB_BM + GB_BN) * GD_PITCH * 2;      // 69 632 >= 128 * 132 * 4 = 67 584
 
-template <bool AKC, bool BKC, bool A16, bool B16>
+// TR: a K-major operand (x[k * ld + row]: the NCHW maps of the forward's first convolutions, the weights of every input gradient)
+// keeps its memory layout in LDS - [128 k][rows] at pitch 144, staged with 16-byte loads of 16 consecutive rows - and its
+// fragments are transposed reads (ds_read_b64_tr_b16); the K-contiguous operand next to it is then read as two 8-byte pieces
+// per chunk, at the k the transposed read delivers (4 h .. and 8 + 4 h ..).  Without TR such a tile is staged with sixteen 2- /
+// 4-byte loads per thread and 32-k group.  Needs 16-byte aligned rows in multiples of 16 (host check); no a_colsum.
+template <bool AKC, bool BKC, bool A16, bool B16, bool TR = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_deep_kernel(const petr_gemm_args g, const int tiles_m, const int tiles_n,
                                                                 const int vec_epi) {
+  constexpr bool AT = TR && !AKC, BT = TR && !BKC, PERM = AT || BT;
+  constexpr int A_IMG = AT ? GD_BK * KM_PITCH : GB_BM * GD_PITCH;
   extern __shared__ __attribute__((aligned(16))) uint16_t dlds[];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int h = lane >> 5, c = lane & 31;
@@ -428,7 +490,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_deep_kernel(const petr_gemm_
   float colacc = 0.f;
 
   uint16_t* As = dlds;
-  uint16_t* Bs = dlds + GB_BM * GD_PITCH;
+  uint16_t* Bs = dlds + A_IMG;
+  // transposed-read staging role: k = t >> 3 of a 32-k group, rows 16 (t & 7) .. + 15 of the tile (clamped to a valid chunk,
+  // zero-filled at the store when the chunk lies beyond the operand's rows)
+  const int sk = t >> 3, sr = 16 * (t & 7);
+  KmStage<A16> sat[AT ? 4 : 1];
+  KmStage<B16> sbt[BT ? 4 : 1];
+  const bool arow_ok = m0 + sr < g.M, brow_ok = n0 + sr < g.N;
+  const int arow = arow_ok ? m0 + sr : 0, brow = brow_ok ? n0 + sr : 0;
+  const int tr_q = (lane & 15) >> 2;
+  const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   int k0_cur = 0, k0_nxt = 0;
   auto gload = [&](int kt, int& k0_out) {
     const int seg = kt / tps;
@@ -439,8 +510,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_deep_kernel(const petr_gemm_
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (k0 + 32 * q < kseg) {           // uniform: 32-k groups beyond the segment are neither loaded nor multiplied
-        sa[q].load(ab, g.lda, k0 + 32 * q, kseg);
-        sb[q].load(bb, g.ldb, k0 + 32 * q, kseg);
+        if constexpr (AT) sat[q].load(reinterpret_cast<const char*>(ab), g.lda, min(k0 + 32 * q + sk, kseg - 1), arow);
+        else sa[q].load(ab, g.lda, k0 + 32 * q, kseg);
+        if constexpr (BT) sbt[q].load(reinterpret_cast<const char*>(bb), g.ldb, min(k0 + 32 * q + sk, kseg - 1), brow);
+        else sb[q].load(bb, g.ldb, k0 + 32 * q, kseg);
       }
   };
   auto lstore = [&](int k0) {
@@ -449,7 +522,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_deep_kernel(const petr_gemm_
       const int kq = k0 + 32 * q;
       if (kq < kseg) {
         const bool kr = kq + 32 > kseg;
-        if (!AKC && do_colsum) {
+        if constexpr (AT) sat[q].store(As + (32 * q + sk) * KM_PITCH + sr, arow_ok && kq + sk < kseg);
+        if constexpr (BT) sbt[q].store(Bs + (32 * q + sk) * KM_PITCH + sr, brow_ok && kq + sk < kseg);
+        if (!AKC && !AT && do_colsum) {
           if constexpr (A16) {
             colacc += sa[q].ksum(kq, kseg);
           } else {
@@ -460,8 +535,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_deep_kernel(const petr_gemm_
             colacc += sum;
           }
         }
-        sa[q].template store<GD_PITCH>(As + 32 * q, rows_ragged_a || kr, kq, kseg);
-        sb[q].template store<GD_PITCH>(Bs + 32 * q, rows_ragged_b || kr, kq, kseg);
+        if constexpr (!AT) sa[q].template store<GD_PITCH>(As + 32 * q, rows_ragged_a || kr, kq, kseg);
+        if constexpr (!BT) sb[q].template store<GD_PITCH>(Bs + 32 * q, rows_ragged_b || kr, kq, kseg);
       }
     }
   };
@@ -479,18 +554,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_deep_kernel(const petr_gemm_
         k0_cur = k0_nxt;
       }
       for (int j = 0; j < chunks; ++j) {     // 16-deep chunks of the K step
-        uint4 fa[2], fb[2];
+        hbf16x8 fa[2], fb[2];
+        // one operand's fragment for rows r0 .. r0 + 31: transposed read of a [k][row] image, or a [row][k] image read at the
+        // plain (8 h) or the permuted (4 h | 8 + 4 h) k positions
+        auto frag = [&](const uint16_t* img, int r0, auto tr_c) -> hbf16x8 {
+          if constexpr (decltype(tr_c)::value) {
+            const uint16_t* p = img + (16 * j + 4 * h + tr_q) * KM_PITCH + tr_col + r0;
+            return km_cat8(km_tr16(p), km_tr16(p + 8 * KM_PITCH));
+          } else if constexpr (PERM) {
+            const uint16_t* p = img + (r0 + c) * GD_PITCH + 16 * j + 4 * h;
+            const uint2 lo = *reinterpret_cast<const uint2*>(p), hi = *reinterpret_cast<const uint2*>(p + 8);
+            return __builtin_bit_cast(hbf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+          } else {
+            return __builtin_bit_cast(hbf16x8, *reinterpret_cast<const uint4*>(img + (r0 + c) * GD_PITCH + 16 * j + 8 * h));
+          }
+        };
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          fa[i] = *reinterpret_cast<const uint4*>(As + (wm + 32 * i + c) * GD_PITCH + 16 * j + 8 * h);
-          fb[i] = *reinterpret_cast<const uint4*>(Bs + (wn + 32 * i + c) * GD_PITCH + 16 * j + 8 * h);
+          fa[i] = frag(As, wm + 32 * i, std::integral_constant<bool, AT>{});
+          fb[i] = frag(Bs, wn + 32 * i, std::integral_constant<bool, BT>{});
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int jn = 0; jn < 2; ++jn)
-            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, fa[i]),
-                                                                 __builtin_bit_cast(hbf16x8, fb[jn]), acc[i][jn], 0, 0, 0);
+          for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
       }
     }
   }
@@ -623,59 +710,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_deep_kernel(const petr_gemm_
 // Needs M, N multiples of 128, 16-byte aligned rows, PETR_GEMM_ATOMIC accumulation (K slices over workgroups); a_colsum as in
 // the general kernel.  Everything else (K segments, two batch dims) follows petr_gemm_args.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int KM_PITCH = 144;
-typedef short km_s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ km_s16x4 km_tr16(const uint16_t* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((km_s16x4 __attribute__((address_space(3)))*)p);
-}
-__device__ __forceinline__ hbf16x8 km_cat8(km_s16x4 lo, km_s16x4 hi) {
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(hbf16x8, v);
-}
-
-// 16 consecutive rows of one k, as they come from memory (S16: bf16, else fp32)
-template <bool S16>
-struct KmStage {
-  uint4 x[S16 ? 2 : 4];
-  __device__ __forceinline__ void load(const char* base, long ld, int k, int row) {      // base in bytes, ld / row in elements
-    constexpr int E = S16 ? 2 : 4;
-    const uint4* src = reinterpret_cast<const uint4*>(base + ((long)k * ld + row) * E);
-#pragma unroll
-    for (int i = 0; i < (S16 ? 2 : 4); ++i) x[i] = src[i];
-  }
-  __device__ __forceinline__ void store(uint16_t* dst, bool ok) const {
-    uint4 a, b;
-    if (S16) {
-      a = x[0]; b = x[1];
-    } else {
-      const float4 f0 = __builtin_bit_cast(float4, x[0]), f1 = __builtin_bit_cast(float4, x[1]);
-      const float4 f2 = __builtin_bit_cast(float4, x[2 % (S16 ? 2 : 4)]), f3 = __builtin_bit_cast(float4, x[3 % (S16 ? 2 : 4)]);
-      const uint2 p0 = pack4(f0.x, f0.y, f0.z, f0.w), p1 = pack4(f1.x, f1.y, f1.z, f1.w);
-      const uint2 p2 = pack4(f2.x, f2.y, f2.z, f2.w), p3 = pack4(f3.x, f3.y, f3.z, f3.w);
-      a = make_uint4(p0.x, p0.y, p1.x, p1.y);
-      b = make_uint4(p2.x, p2.y, p3.x, p3.y);
-    }
-    if (!ok) a = b = make_uint4(0, 0, 0, 0);
-    reinterpret_cast<uint4*>(dst)[0] = a;
-    reinterpret_cast<uint4*>(dst)[1] = b;
-  }
-  // the 16 values as floats (column sums)
-  __device__ __forceinline__ void add_to(float (&s)[16]) const {
-    if (S16) {
-      const uint32_t w[8] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { s[2 * j] += __uint_as_float(w[j] << 16); s[2 * j + 1] += __uint_as_float(w[j] & 0xFFFF0000u); }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 f = __builtin_bit_cast(float4, x[i % (S16 ? 2 : 4)]);
-        s[4 * i] += f.x; s[4 * i + 1] += f.y; s[4 * i + 2] += f.z; s[4 * i + 3] += f.w;
-      }
-    }
-  }
-};
-
 // BKC: the B operand is K-CONTIGUOUS instead (x[row * ld + k]: an NCHW map read as [channel][pixel] - the first convolutions'
 // and input_proj's weight gradients, dW = dY^T X with X the [view][c][hw] planes).  Its tile is staged like the general
 // kernel's ([row][32 k] image, pitch 40) and its fragments are read as TWO 8-byte pieces per 16-deep chunk, at k = 4 h and
@@ -889,24 +923,35 @@ int petr_gemm_bf16_general(const petr_gemm_args& g, hipStream_t s) {
         (!g.bias || (aligned16(g.bias) && !(g.bias_bs0 & 3) && !(g.bias_bs1 & 3))) &&
         (!g.r || (!(g.ldr & 3) && !(g.r_bs0 & 3) && !(g.r_bs1 & 3) && !((uintptr_t)g.r & rmask)));
     dim3 grid(tm * tn * g.nb0 * g.nb1 * g.split_k), block(256);
-#define PETR_GD(AKC, BKC, A16, B16)                                                                                      \
+    // transposed-read path for the K-major operand(s): 16-byte rows in multiples of 16, no column sums
+    // (PETR_GEMM16_TR=0, diagnostic builds: the scalar-load staging)
+    static const bool tr_on = petr_tune("PETR_GEMM16_TR", 1) != 0;
+    const int am = a16 ? 7 : 3, bm = b16 ? 7 : 3;
+    const bool a_tr_ok = g.a_kcontig || (!(g.lda & am) && !(g.a_bs0 & am) && !(g.a_bs1 & am) && !(g.a_seg_stride & am) && aligned16(g.a) &&
+                                         !(g.M & 15));
+    const bool b_tr_ok = g.b_kcontig || (!(g.ldb & bm) && !(g.b_bs0 & bm) && !(g.b_bs1 & bm) && !(g.b_seg_stride & bm) && aligned16(g.b) &&
+                                         !(g.N & 15));
+    const bool tr = tr_on && !(g.a_kcontig && g.b_kcontig) && a_tr_ok && b_tr_ok && !g.a_colsum;
+#define PETR_GD(AKC, BKC, A16, B16, TR)                                                                                  \
   do {                                                                                                                   \
-    auto kern = gemm_bf16_deep_kernel<AKC, BKC, A16, B16>;                                                               \
+    auto kern = gemm_bf16_deep_kernel<AKC, BKC, A16, B16, TR>;                                                           \
+    constexpr size_t img = ((TR && !(AKC) ? GD_BK * KM_PITCH : GB_BM * GD_PITCH) + (TR && !(BKC) ? GD_BK * KM_PITCH : GB_BN * GD_PITCH)) * 2; \
+    constexpr size_t bytes = img > GD_LDS_BYTES ? img : GD_LDS_BYTES;                                                    \
     static PetrLdsLimit lds_limit;                                                                                       \
-    petr_raise_lds_limit(lds_limit, (const void*)kern, (int)GD_LDS_BYTES);                                               \
-    hipLaunchKernelGGL(kern, grid, block, GD_LDS_BYTES, s, g, tm, tn, vec_epi);                                          \
+    petr_raise_lds_limit(lds_limit, (const void*)kern, (int)bytes);                                                      \
+    hipLaunchKernelGGL(kern, grid, block, bytes, s, g, tm, tn, vec_epi);                                                 \
   } while (0)
-#define PETR_GD2(AKC, BKC)                                  \
+#define PETR_GD2(AKC, BKC, TR)                              \
   do {                                                      \
-    if (a16 && b16) PETR_GD(AKC, BKC, true, true);          \
-    else if (a16) PETR_GD(AKC, BKC, true, false);           \
-    else if (b16) PETR_GD(AKC, BKC, false, true);           \
-    else PETR_GD(AKC, BKC, false, false);                   \
+    if (a16 && b16) PETR_GD(AKC, BKC, true, true, TR);      \
+    else if (a16) PETR_GD(AKC, BKC, true, false, TR);       \
+    else if (b16) PETR_GD(AKC, BKC, false, true, TR);       \
+    else PETR_GD(AKC, BKC, false, false, TR);               \
   } while (0)
-    if (g.a_kcontig && g.b_kcontig) PETR_GD2(true, true);
-    else if (g.a_kcontig) PETR_GD2(true, false);
-    else if (g.b_kcontig) PETR_GD2(false, true);
-    else PETR_GD2(false, false);
+    if (g.a_kcontig && g.b_kcontig) PETR_GD2(true, true, false);
+    else if (g.a_kcontig) { if (tr) PETR_GD2(true, false, true); else PETR_GD2(true, false, false); }
+    else if (g.b_kcontig) { if (tr) PETR_GD2(false, true, true); else PETR_GD2(false, true, false); }
+    else { if (tr) PETR_GD2(false, false, true); else PETR_GD2(false, false, false); }
 #undef PETR_GD2
 #undef PETR_GD
     PETR_LAUNCH_CHECK("gemm_bf16_deep");

@@ -735,6 +735,30 @@ typedef struct {
 } petr_branch_bwd_args;
 int petr_branch_bwd(const petr_branch_bwd_args* a, void* stream);
 
+/* PETRv2's RegLayer task heads (petrv2_head.py:81-95: `heads` = 5 x (Linear, ReLU, Linear -> group_reg_dims (2,1,3,2,2)), outputs
+ * concatenated), the SECOND Linear of all heads in one launch: out[r, cols[t] + o] = h_t[r,:] . W2_t[o,:] + b2_t[o], o < dims[t].
+ * As five contractions with 1-3 output columns they were scalar-load launches of 12-14 us each at the end of the forward and
+ * 18-40 us each (input gradient) + 20-40 us each (weight gradient) at the start of the backward.  h / d_h: [groups][heads][rows][256];
+ * head t of group g reads its parameters at + g * param_gs + t * head_stride ([dims[t]][256] weights, [dims[t]] bias).
+ * _bwd: d_h = (h > 0) * (d_out_t W2_t)  (the ReLU in front of the Linear folded in), dW2 / db2 ADDED with float atomics.   */
+typedef struct {
+  const float* h; const float* w2; const float* b2;
+  long param_gs, head_stride;
+  float* out; int ld_out;                                /* [groups * rows, ld_out]                                 */
+  int rows, groups, heads;
+  int dims[8]; int cols[8];
+} petr_task_heads_fwd_args;
+int petr_task_heads_fwd(const petr_task_heads_fwd_args* a, void* stream);
+typedef struct {
+  const float* d_out; int ld_out;
+  const float* h; const float* w2;
+  long param_gs, head_stride;
+  float* d_h; float* dw2; float* db2;
+  int rows, groups, heads;
+  int dims[8]; int cols[8];
+} petr_task_heads_bwd_args;
+int petr_task_heads_bwd(const petr_task_heads_bwd_args* a, void* stream);
+
 /* named views into the forward workspace, for tests and for the per-module Python API
  * ("memory", "pos_embed", "query_embed", "outs_dec", "coords3d", "sine", "k_all", "v_all", ...)   */
 int petr_head_ws_view(const petr_head_config* cfg, const char* name, long* offset_floats, long* numel);

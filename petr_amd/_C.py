@@ -161,6 +161,18 @@ class BranchBwdArgs(C.Structure):    # petr_branch_bwd_args
                        ('rows', C.c_int), ('groups', C.c_int), ('dw3', C.c_void_p), ('db3', C.c_void_p))
 
 
+class TaskHeadsFwdArgs(C.Structure):    # petr_task_heads_fwd_args
+    _fields_ = _fields(('h', C.c_void_p), ('w2', C.c_void_p), ('b2', C.c_void_p), ('param_gs', C.c_long), ('head_stride', C.c_long),
+                       ('out', C.c_void_p), ('ld_out', C.c_int), ('rows', C.c_int), ('groups', C.c_int), ('heads', C.c_int),
+                       ('dims', C.c_int * 8), ('cols', C.c_int * 8))
+
+
+class TaskHeadsBwdArgs(C.Structure):    # petr_task_heads_bwd_args
+    _fields_ = _fields(('d_out', C.c_void_p), ('ld_out', C.c_int), ('h', C.c_void_p), ('w2', C.c_void_p), ('param_gs', C.c_long),
+                       ('head_stride', C.c_long), ('d_h', C.c_void_p), ('dw2', C.c_void_p), ('db2', C.c_void_p),
+                       ('rows', C.c_int), ('groups', C.c_int), ('heads', C.c_int), ('dims', C.c_int * 8), ('cols', C.c_int * 8))
+
+
 class MhaBwdArgs(C.Structure):
     _fields_ = _fields(
         ('q', C.c_void_p), ('q_bs', C.c_long), ('q_hs', C.c_long), ('q_rs', C.c_long),
@@ -306,6 +318,8 @@ def lib():
     L.petr_wgrad_grouped.argtypes = [C.POINTER(WgradItem), C.c_int, C.c_void_p]
     L.petr_branch_fwd.argtypes = [C.POINTER(BranchFwdArgs), C.c_void_p]
     L.petr_branch_bwd.argtypes = [C.POINTER(BranchBwdArgs), C.c_void_p]
+    L.petr_task_heads_fwd.argtypes = [C.POINTER(TaskHeadsFwdArgs), C.c_void_p]
+    L.petr_task_heads_bwd.argtypes = [C.POINTER(TaskHeadsBwdArgs), C.c_void_p]
     L.petr_fpn_upsample_add.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
     L.petr_axpy.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_long, C.c_void_p]
     L.petr_reduce_partials.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
@@ -343,7 +357,7 @@ EXPORTS = [
     'petr_reduce_partials', 'petr_reduce_batch', 'petr_head_layout', 'petr_head_workspace_bytes', 'petr_head_fwd',
     'petr_head_bwd_num_stages', 'petr_head_bwd_stage_range', 'petr_head_bwd', 'petr_head_ws_view',
     'petr_ctx_create', 'petr_ctx_destroy', 'petr_ctx_join_into', 'petr_ctx_side_stream', 'petr_dropout_mask', 'petr_dropout_bits_words', 'petr_dropout_bits', 'petr_loss_workspace_bytes', 'petr_loss_fwd_bwd',
-    'petr_decode_boxes', 'petr_decode_topk', 'petr_fpn_upsample_add', 'petr_wgrad_grouped', 'petr_branch_fwd', 'petr_branch_bwd', 'petr_fpn_upsample_add_bwd', 'petr_nchw_to_padded_nhwc', 'petr_add_rows2', 'petr_add_rows2_bf16',
+    'petr_decode_boxes', 'petr_decode_topk', 'petr_fpn_upsample_add', 'petr_wgrad_grouped', 'petr_branch_fwd', 'petr_branch_bwd', 'petr_task_heads_fwd', 'petr_task_heads_bwd', 'petr_fpn_upsample_add_bwd', 'petr_nchw_to_padded_nhwc', 'petr_add_rows2', 'petr_add_rows2_bf16',
 ]
 
 

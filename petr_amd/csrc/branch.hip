@@ -347,6 +347,154 @@ __global__ __launch_bounds__(512) void branch_bwd_kernel(const BbParams p) {
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// petr_task_heads_fwd / _bwd (petr_hip.h): the 1-3 column Linear that ends each of PETRv2's five RegLayer heads.  Vector work, not
+// matrix work: workgroup = 32 rows of one (group, head), thread = (row t >> 3, 32-channel slice t & 7): eight lanes of a row read
+// its 1 KB contiguously, dot products are finished with three xor shuffles.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int TH_MAXD = 4;      // outputs per head (reference: <= 3)
+
+__global__ __launch_bounds__(256) void task_heads_fwd_kernel(const petr_task_heads_fwd_args a) {
+  const int t = threadIdx.x, r = t >> 3, part = t & 7;
+  const int gh = blockIdx.y, grp = gh / a.heads, hd = gh - grp * a.heads;
+  const int m = blockIdx.x * 32 + r;
+  const int nd = a.dims[hd];
+  const float* hrow = a.h + ((long)gh * a.rows + min(m, a.rows - 1)) * 256 + 32 * part;
+  const float* w = a.w2 + (long)grp * a.param_gs + (long)hd * a.head_stride + 32 * part;
+  float4 hv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hv[i] = reinterpret_cast<const float4*>(hrow)[i];
+  for (int o = 0; o < nd; ++o) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 wv = reinterpret_cast<const float4*>(w + (long)o * 256)[i];
+      s += hv[i].x * wv.x + hv[i].y * wv.y + hv[i].z * wv.z + hv[i].w * wv.w;
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (part == 0 && m < a.rows)
+      a.out[((long)grp * a.rows + m) * a.ld_out + a.cols[hd] + o] = s + (a.b2 ? a.b2[(long)grp * a.param_gs + (long)hd * a.head_stride + o] : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void task_heads_bwd_kernel(const petr_task_heads_bwd_args a) {
+  // a workgroup walks row blocks blockIdx.x, + gridDim.x, .. of its (group, head) and keeps its share of dW2 / db2 in registers:
+  // one pass over the rows, gridDim.x float atomics per parameter at the end (one atomic per 32-row block and element - the first
+  // version - queued 116 adders on each of 2 560 addresses: 312 us)
+  __shared__ float red[4][TH_MAXD][256 + 8];
+  const int t = threadIdx.x, r = t >> 3, part = t & 7, wave = t >> 6;
+  const int gh = blockIdx.y, grp = gh / a.heads, hd = gh - grp * a.heads;
+  const int nd = a.dims[hd];
+  const long prow = (long)grp * a.param_gs + (long)hd * a.head_stride;
+  const float* w = a.w2 + prow + 32 * part;
+  float4 acc[TH_MAXD][8];
+  float bacc[TH_MAXD];
+#pragma unroll
+  for (int o = 0; o < TH_MAXD; ++o) {
+    bacc[o] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[o][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int nrb = (a.rows + 31) >> 5;
+  for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    const int m = rb * 32 + r;
+    const bool ok = m < a.rows;
+    const long hoff = ((long)gh * a.rows + min(m, a.rows - 1)) * 256 + 32 * part;
+    float dv[TH_MAXD];
+#pragma unroll
+    for (int o = 0; o < TH_MAXD; ++o)
+      dv[o] = (ok && o < nd) ? a.d_out[((long)grp * a.rows + m) * a.ld_out + a.cols[hd] + o] : 0.f;
+    float4 hv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hv[i] = reinterpret_cast<const float4*>(a.h + hoff)[i];
+    if (a.d_h) {       // input gradient of the Linear with the ReLU in front of it folded in
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int o = 0; o < TH_MAXD; ++o)
+          if (o < nd) {
+            const float4 wv = reinterpret_cast<const float4*>(w + (long)o * 256)[i];
+            g.x += dv[o] * wv.x; g.y += dv[o] * wv.y; g.z += dv[o] * wv.z; g.w += dv[o] * wv.w;
+          }
+        g.x = hv[i].x > 0.f ? g.x : 0.f; g.y = hv[i].y > 0.f ? g.y : 0.f; g.z = hv[i].z > 0.f ? g.z : 0.f; g.w = hv[i].w > 0.f ? g.w : 0.f;
+        if (ok) reinterpret_cast<float4*>(a.d_h + hoff)[i] = g;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < TH_MAXD; ++o) {
+      bacc[o] += dv[o];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        acc[o][i].x += dv[o] * hv[i].x; acc[o][i].y += dv[o] * hv[i].y; acc[o][i].z += dv[o] * hv[i].z; acc[o][i].w += dv[o] * hv[i].w;
+      }
+    }
+  }
+  if (!a.dw2 && !a.db2) return;
+  // the 8 rows of a wave by xor shuffles (lane = 8 row + part), the four waves through LDS
+#pragma unroll
+  for (int o = 0; o < TH_MAXD; ++o) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float4 p = acc[o][i];
+#pragma unroll
+      for (int sh = 8; sh < 64; sh <<= 1) {
+        p.x += __shfl_xor(p.x, sh, 64); p.y += __shfl_xor(p.y, sh, 64); p.z += __shfl_xor(p.z, sh, 64); p.w += __shfl_xor(p.w, sh, 64);
+      }
+      if ((t & 63) < 8) *reinterpret_cast<float4*>(&red[wave][o][32 * part + 4 * i]) = p;
+    }
+    float sb = part == 0 ? bacc[o] : 0.f;
+#pragma unroll
+    for (int sh = 8; sh < 64; sh <<= 1) sb += __shfl_xor(sb, sh, 64);
+    if ((t & 63) == 0) red[wave][o][256] = sb;
+  }
+  __syncthreads();
+  for (int o = 0; o < nd; ++o) {
+    if (a.dw2) atomicAdd(a.dw2 + prow + (long)o * 256 + t, red[0][o][t] + red[1][o][t] + red[2][o][t] + red[3][o][t]);
+    if (a.db2 && t == 0) atomicAdd(a.db2 + prow + o, red[0][o][256] + red[1][o][256] + red[2][o][256] + red[3][o][256]);
+  }
+}
+}  // namespace
+
+static int task_heads_check(const float* h, const float* w2, long param_gs, long head_stride, int rows, int groups, int heads, const int* dims,
+                            const int* cols, int ld_out, const char* who) {
+  PETR_CHECK(h && w2 && rows > 0 && groups > 0 && heads > 0 && heads <= 8 && ld_out > 0, PETR_ERR_INVALID, "%s: bad arguments", who);
+  PETR_CHECK(aligned16(h) && aligned16(w2) && !(param_gs & 3) && !(head_stride & 3), PETR_ERR_INVALID,
+             "%s: h / w2 must be 16-byte aligned, parameter strides multiples of 4", who);
+  for (int t = 0; t < heads; ++t)
+    PETR_CHECK(dims[t] >= 1 && dims[t] <= TH_MAXD && cols[t] >= 0 && cols[t] + dims[t] <= ld_out, PETR_ERR_UNSUPPORTED,
+               "%s: head %d: dims=%d (1..%d), cols=%d", who, t, dims[t], TH_MAXD, cols[t]);
+  PETR_CHECK((long)groups * heads <= 65535, PETR_ERR_UNSUPPORTED, "%s: too many (group, head) pairs", who);
+  return PETR_OK;
+}
+
+extern "C" int petr_task_heads_fwd(const petr_task_heads_fwd_args* ap, void* stream) {
+  PETR_CHECK(ap && ap->out, PETR_ERR_INVALID, "task_heads_fwd: null pointer");
+  const petr_task_heads_fwd_args& a = *ap;
+  if (int rc = task_heads_check(a.h, a.w2, a.param_gs, a.head_stride, a.rows, a.groups, a.heads, a.dims, a.cols, a.ld_out, "task_heads_fwd")) return rc;
+  hipLaunchKernelGGL(task_heads_fwd_kernel, dim3((unsigned)cdiv(a.rows, 32), (unsigned)(a.groups * a.heads)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  PETR_LAUNCH_CHECK("task_heads_fwd");
+  return PETR_OK;
+}
+
+extern "C" int petr_task_heads_bwd(const petr_task_heads_bwd_args* ap, void* stream) {
+  PETR_CHECK(ap && ap->d_out && (ap->d_h || ap->dw2), PETR_ERR_INVALID, "task_heads_bwd: null pointer");
+  const petr_task_heads_bwd_args& a = *ap;
+  if (int rc = task_heads_check(a.h, a.w2, a.param_gs, a.head_stride, a.rows, a.groups, a.heads, a.dims, a.cols, a.ld_out, "task_heads_bwd")) return rc;
+  PETR_CHECK(!a.d_h || aligned16(a.d_h), PETR_ERR_INVALID, "task_heads_bwd: d_h must be 16-byte aligned");
+  // row-block chunks per (group, head): enough workgroups to fill the chip, few adders per parameter
+  const long nrb = cdiv(a.rows, 32);
+  long chunks = cdiv(512, (long)a.groups * a.heads);
+  if (chunks > nrb) chunks = nrb;
+  hipLaunchKernelGGL(task_heads_bwd_kernel, dim3((unsigned)chunks, (unsigned)(a.groups * a.heads)), dim3(256), 0, (hipStream_t)stream, a);
+  PETR_LAUNCH_CHECK("task_heads_bwd");
+  return PETR_OK;
+}
+
 extern "C" int petr_branch_bwd(const petr_branch_bwd_args* ap, void* stream) {
   PETR_CHECK(ap && ap->y2 && ap->w2 && ap->y1 && ap->w1 && ap->d_x && ap->rows > 0 && ap->groups > 0 &&
                  ((ap->w3 && ap->d_out) || (!ap->w3 && ap->d_y2)),

@@ -1248,6 +1248,14 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
       g.flags = PETR_GEMM_RELU;
       RUN(petr_gemm(&g, s1));
       static const int TH_DIMS[5] = {2, 1, 3, 2, 2}, TH_COL[5] = {0, 2, 3, 6, 8};
+      if (C == 256 && petr_tune("PETR_TASK_HEADS_FUSED", 1) != 0) {       // the five 1-3 column Linears in one launch
+        petr_task_heads_fwd_args ta;
+        memset(&ta, 0, sizeof ta);
+        ta.h = Wm + W.th_h; ta.w2 = Pm + P.th_w2; ta.b2 = Pm + P.th_b2; ta.param_gs = P.br_stride; ta.head_stride = P.th_stride;
+        ta.out = Wm + W.reg_raw; ta.ld_out = d.code; ta.rows = (int)RG; ta.groups = G; ta.heads = 5;
+        for (int t = 0; t < 5; ++t) { ta.dims[t] = TH_DIMS[t]; ta.cols[t] = TH_COL[t]; }
+        RUN(petr_task_heads_fwd(&ta, s1));
+      } else
       for (int t = 0; t < 5; ++t) {
         g = grouped(lin_fwd(Wm + W.th_h + (long)t * RG * C, Pm + P.th_w2 + t * P.th_stride, Pm + P.th_b2 + t * P.th_stride,
                             Wm + W.reg_raw + TH_COL[t], RG, TH_DIMS[t], C), 5 * C, d.code);
@@ -1485,6 +1493,15 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       } else {
         static const int TH_DIMS[5] = {2, 1, 3, 2, 2}, TH_COL[5] = {0, 2, 3, 6, 8};
         float* d_th = Wm + W.d_th_h;
+        if (C == 256 && petr_tune("PETR_TASK_HEADS_FUSED", 1) != 0) {     // input, weight and bias gradients of the five in one launch
+          petr_task_heads_bwd_args tb;
+          memset(&tb, 0, sizeof tb);
+          tb.d_out = d_raw; tb.ld_out = d.code; tb.h = Wm + W.th_h; tb.w2 = Pm + P.th_w2; tb.param_gs = P.br_stride;
+          tb.head_stride = P.th_stride; tb.d_h = d_th; tb.dw2 = Gp + P.th_w2; tb.db2 = Gp + P.th_b2;
+          tb.rows = (int)RG; tb.groups = G; tb.heads = 5;
+          for (int t = 0; t < 5; ++t) { tb.dims[t] = TH_DIMS[t]; tb.cols[t] = TH_COL[t]; }
+          RUN(petr_task_heads_bwd(&tb, s));
+        } else
         for (int t = 0; t < 5; ++t) {
           RUN(wgrad(gw(lin_wgrad(d_raw + TH_COL[t], d.code, Wm + W.th_h + (long)t * RG * C, C, Gp + P.th_w2 + t * P.th_stride,
                                  Gp + P.th_b2 + t * P.th_stride, RG, TH_DIMS[t], C), d.code, 5 * C)));

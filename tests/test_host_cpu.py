@@ -50,7 +50,7 @@ def test_ctypes_struct_sizes_match_header(lib_path, tmp_path):
     names = ['petr_coords3d_args', 'petr_sine3d_args', 'petr_gemm_args', 'petr_layernorm_args',
              'petr_layernorm_bwd_args', 'petr_mha_fwd_args', 'petr_mha_bwd_args', 'petr_bbox_args', 'petr_head_config',
              'petr_head_layout_t', 'petr_head_io', 'petr_head_grads', 'petr_mha_bwd_bf16_args', 'petr_mha_fwd_bf16_args',
-             'petr_decode_topk_args', 'petr_decode_args', 'petr_loss_args', 'petr_attn_out_ln_args', 'petr_ln_proj_args', 'petr_ln_bwd_proj_args', 'petr_ffn_fwd_args', 'petr_ffn_bwd_args', 'petr_wgrad_item', 'petr_branch_fwd_args', 'petr_branch_bwd_args']
+             'petr_decode_topk_args', 'petr_decode_args', 'petr_loss_args', 'petr_attn_out_ln_args', 'petr_ln_proj_args', 'petr_ln_bwd_proj_args', 'petr_ffn_fwd_args', 'petr_ffn_bwd_args', 'petr_wgrad_item', 'petr_branch_fwd_args', 'petr_branch_bwd_args', 'petr_task_heads_fwd_args', 'petr_task_heads_bwd_args']
     body = '\n'.join(f'printf("%zu\\n", sizeof({n}));' for n in names)
     src.write_text(f'#include <stdio.h>\n#include "petr_hip.h"\nint main(){{{body} return 0;}}')
     exe = tmp_path / 'sz'
@@ -58,7 +58,7 @@ def test_ctypes_struct_sizes_match_header(lib_path, tmp_path):
     sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     mirrors = [_C.Coords3dArgs, _C.Sine3dArgs, _C.GemmArgs, _C.LayerNormArgs, _C.LayerNormBwdArgs, _C.MhaFwdArgs,
                _C.MhaBwdArgs, _C.BboxArgs, _C.HeadConfig, _C.HeadLayout, _C.HeadIO, _C.HeadGrads, _C.MhaBwdBf16Args, _C.MhaFwdArgs,
-               _C.DecodeTopkArgs, _C.DecodeArgs, _C.LossArgs, _C.AttnOutLnArgs, _C.LnProjArgs, _C.LnBwdProjArgs, _C.FfnFwdArgs, _C.FfnBwdArgs, _C.WgradItem, _C.BranchFwdArgs, _C.BranchBwdArgs]
+               _C.DecodeTopkArgs, _C.DecodeArgs, _C.LossArgs, _C.AttnOutLnArgs, _C.LnProjArgs, _C.LnBwdProjArgs, _C.FfnFwdArgs, _C.FfnBwdArgs, _C.WgradItem, _C.BranchFwdArgs, _C.BranchBwdArgs, _C.TaskHeadsFwdArgs, _C.TaskHeadsBwdArgs]
     for n, s, m in zip(names, sizes, mirrors):
         assert ctypes.sizeof(m) == s, f'{n}: C says {s}, ctypes says {ctypes.sizeof(m)}'
 

@@ -273,6 +273,46 @@ def test_branch_bwd(ops, G, rows, n_out, ln):
             assert err < (2e-5 if k.startswith('d_') else 1e-4), (gi, k, err)      # parameter sums: 5 400 float atomics
 
 
+@pytest.mark.parametrize('G,rows', [(6, 900), (1, 70), (2, 33)])
+def test_task_heads_fwd_bwd(ops, G, rows):
+    """petr_task_heads_fwd / _bwd: the 1-3 column Linear that ends each of PETRv2's five RegLayer heads (petrv2_head.py:81-95), all
+    heads and groups in one launch, against float64: outputs concatenated at columns (0, 2, 3, 6, 8); input gradient with the ReLU
+    in front folded in; weight / bias gradients."""
+    from petr_amd import _C
+    import ctypes as C
+    dims, cols, H = [2, 1, 3, 2, 2], [0, 2, 3, 6, 8], 5
+    g = torch.Generator().manual_seed(40 + rows)
+    h = torch.relu(torch.randn(G, H, rows, 256, generator=g))            # hidden activations (post-ReLU: zeros included)
+    slot = 3 * 256 + 8                                                    # per-head parameter slot: [3 x 256] weights, then the bias
+    params = torch.zeros(G, H, slot)
+    for t in range(H):
+        params[:, t, :dims[t] * 256] = torch.randn(G, dims[t] * 256, generator=g) / 16
+        params[:, t, 768:768 + dims[t]] = torch.randn(G, dims[t], generator=g)
+    d_out = torch.randn(G, rows, 10, generator=g)
+    hd, pd, dd = h.cuda(), params.cuda(), d_out.cuda()
+    out = torch.full((G, rows, 10), float('nan'), device='cuda')
+    fa = _C.TaskHeadsFwdArgs(hd.data_ptr(), pd.data_ptr(), pd.data_ptr() + 4 * 768, H * slot, slot, out.data_ptr(), 10, rows, G, H,
+                             (C.c_int * 8)(*dims, 0, 0, 0), (C.c_int * 8)(*cols, 0, 0, 0))
+    _C.check(_C.lib().petr_task_heads_fwd(C.byref(fa), ops._stream()), 'petr_task_heads_fwd')
+    d_h = torch.empty_like(hd)
+    gp = torch.zeros_like(pd)
+    ba = _C.TaskHeadsBwdArgs(dd.data_ptr(), 10, hd.data_ptr(), pd.data_ptr(), H * slot, slot, d_h.data_ptr(), gp.data_ptr(),
+                             gp.data_ptr() + 4 * 768, rows, G, H, (C.c_int * 8)(*dims, 0, 0, 0), (C.c_int * 8)(*cols, 0, 0, 0))
+    _C.check(_C.lib().petr_task_heads_bwd(C.byref(ba), ops._stream()), 'petr_task_heads_bwd')
+    for gi in range(G):
+        for t in range(H):
+            w = params[gi, t, :dims[t] * 256].view(dims[t], 256).double()
+            b = params[gi, t, 768:768 + dims[t]].double()
+            hh = h[gi, t].double()
+            want = hh @ w.T + b
+            assert relerr(out[gi, :, cols[t]:cols[t] + dims[t]], want) < 1e-5
+            dy = d_out[gi, :, cols[t]:cols[t] + dims[t]].double()
+            assert relerr(d_h[gi, t], (dy @ w) * (hh > 0)) < 1e-5
+            assert relerr(gp[gi, t, :dims[t] * 256].view(dims[t], 256), dy.T @ hh) < 2e-5
+            assert relerr(gp[gi, t, 768:768 + dims[t]], dy.sum(0)) < 2e-5
+    assert not torch.isnan(out).any()
+
+
 def test_wgrad_grouped(ops):
     """petr_wgrad_grouped: the weight / bias gradients of one decoder layer's linear maps in one launch (strided operand
     views as the executor passes them, ragged K = 900, a K-split item with atomics) against fp64, accumulating (+=)."""

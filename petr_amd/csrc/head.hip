@@ -250,7 +250,7 @@ static void build_layout(const petr_head_config* c, POff* P, petr_head_layout_t*
 // workspace layout (activations kept for backward + scratch), offsets in floats
 // ---------------------------------------------------------------------------------------------
 struct LayerW {
-  long qkv, ao_s, lse_s, z0, mean0, rstd0, x1, xe1, qc, ao_c, lse_c, z1, mean1, rstd1, x2, hff, z2, mean2, rstd2, xe_in;
+  long qkv, qkv16, ao_s, lse_s, z0, mean0, rstd0, x1, xe1, qc, ao_c, lse_c, z1, mean1, rstd1, x2, hff, z2, mean2, rstd2, xe_in;
 };
 struct WOff {
   long posemb, qe_h, qe, vol, sine, mem, h1, h2, pos, pos2, mempos, p16, k_all, v_all, x0;
@@ -325,6 +325,7 @@ static void build_ws(const petr_head_config* c, WOff* Wf, WsBuilder* wb_out) {
     LayerW& lw = W.lay[l];
     lw.xe_in = wb.add("xe_in", d.BQ * C);
     lw.qkv = wb.add("qkv_self", d.BQ * 3 * C);
+    lw.qkv16 = wb.add("qkv_self_bf16", d.BQ * 3 * C / 2);      // bf16 mode: the self-attention's K / V rows as bf16 (same indexing)
     lw.ao_s = wb.add("attn_self", d.BQ * C);
     lw.lse_s = wb.add("lse_self", (long)d.B * d.NH * d.Q);
     lw.z0 = wb.add("z0", d.BQ * C);
@@ -619,7 +620,7 @@ static int mha_b(const float* q, long q_bs, long q_rs, const float* k, long k_bs
 static int mha_b_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, long k_bs, long k_rs, const uint16_t* v,
                       const float* o, const float* d_o, const float* lse, const uint8_t* kpm, float* dq, uint16_t* dk,
                       uint16_t* dv, bool dkv16, const Dims& d, int L, void* s, const petr_dropout* drop = nullptr,
-                      const uint32_t* bits = nullptr) {
+                      const uint32_t* bits = nullptr, bool overwrite = true) {
   petr_mha_bwd_bf16_args a;
   memset(&a, 0, sizeof a);
   if (drop) a.drop = *drop;
@@ -634,7 +635,7 @@ static int mha_b_bf16(const float* q, long q_bs, long q_rs, const uint16_t* k, l
   a.dv = reinterpret_cast<float*>(dv); a.dv_bs = k_bs; a.dv_hs = 32; a.dv_rs = k_rs;
   a.B = d.B; a.H = d.NH; a.Q = d.Q; a.L = L;
   a.scale = 1.0f / sqrtf(32.f);
-  a.dkv_overwrite = 1;       // dK_l / dV_l are stored, not accumulated: the executor does not zero them in this mode
+  a.dkv_overwrite = overwrite ? 1 : 0;   // cross: dK_l / dV_l are stored, not accumulated (the executor does not zero them in this mode)
   a.drop_bits = bits;
   a.dkv_bf16 = dkv16;        // ... and as bf16: the K/V-projection backward rounds them to bf16 anyway (PETR_GEMM_A_BF16)
   return petr_mha_bwd_bf16(&a, s);
@@ -1085,6 +1086,8 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
   static const bool fuse_env = env_on("PETR_FUSE_OUT_LN");
   const bool fuse_out = fuse_env && C == 256 && d.NH == 8;
   const int ns_self = petr_mha_choose_split(d.B, d.NH, d.Q, d.Q);
+  // (PETR_SELF_BF16=0, diagnostic builds: the self-attention stays on the fp32 kernels in bf16 mode)
+  const bool self16 = attn_bf16 && fuse_out && petr_tune("PETR_SELF_BF16", 1) != 0;
   const int ns_cross = attn_bf16 ? petr_mha_fwd_bf16_choose_split(d.B, d.NH, d.Q, (int)d.L) : petr_mha_choose_split(d.B, d.NH, d.Q, (int)d.L);
   for (int l = 0; l < d.NL; ++l) {
     const LayerP& lp = P.lay[l];
@@ -1098,6 +1101,13 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
     if (fuse_out) {
       // attention with its L-split partials left in the workspace, then ONE launch: merge + out-projection + dropout +
       // identity (petr_transformer.py:367) + LayerNorm + query_pos add
+      if (self16) {     // bf16 mode: the self-attention on the bf16 kernels too (K / V rows of qkv rounded once; q, output, LSE fp32)
+        uint16_t* q16 = reinterpret_cast<uint16_t*>(Wm + lw.qkv16);
+        RUN(petr_cast_bf16(Wm + lw.qkv, q16, d.BQ * 3 * C, s));
+        RUN(mha_f_bf16(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, q16 + C, (long)d.Q * 3 * C, 3 * C, q16 + 2 * C, Wm + lw.ao_s,
+                       Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, s, training ? &dr_sp : nullptr,
+                       use_bits ? bits_ptr(l, 1) : nullptr, ns_self, 1));
+      } else
       RUN(mha_f(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
                 Wm + lw.ao_s, Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, sched, s, training ? &dr_sp : nullptr,
                 use_bits ? bits_ptr(l, 1) : nullptr, ns_self, 1));
@@ -1381,6 +1391,8 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   // io->attn_bf16: the token-sized gradient contractions (K/V projections, position-embedding MLPs, input_proj,
   // PETRv2's feature-guided PE) and the cross-attention backward run on the bf16 matrix cores, like their forwards
   const bool bf16 = io->attn_bf16 != 0;
+  // the forward's condition for the bf16 self-attention (head_fwd: self16)
+  const bool self16_b = bf16 && env_on("PETR_FUSE_OUT_LN") && C == 256 && d.NH == 8 && petr_tune("PETR_SELF_BF16", 1) != 0;
   const bool hid16 = hidden_bf16(io);
   const bool tok16 = token_bf16(cfg, io);
   const uint16_t* p16 = reinterpret_cast<const uint16_t*>(Wm + W.p16);        // made by the forward (same parameters)
@@ -1766,6 +1778,12 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       static const int flush_early = petr_tune("PETR_WGRAD_FLUSH_EARLY", 1);
       if (defer && flush_early == 1) RUN(flush_wgrads());
       float* d_qkv = Wm + W.d_qkv + (long)l * d.BQ * 3 * C;
+      if (self16_b) {      // the forward ran the bf16 kernel on the bf16 K / V copy it left in qkv16: its gradient kernel, fp32 += outputs
+        const uint16_t* q16 = reinterpret_cast<const uint16_t*>(Wm + lw.qkv16);
+        RUN(mha_b_bf16(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, q16 + C, (long)d.Q * 3 * C, 3 * C, q16 + 2 * C, Wm + lw.ao_s, d_ao_s,
+                       Wm + lw.lse_s, nullptr, d_qkv, reinterpret_cast<uint16_t*>(d_qkv + C), reinterpret_cast<uint16_t*>(d_qkv + 2 * C),
+                       false, d, d.Q, s, training ? &dr[0] : nullptr, use_bits ? bits_ptr(l, 1) : nullptr, false));
+      } else
       RUN(mha_b(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + C, (long)d.Q * 3 * C, 3 * C, Wm + lw.qkv + 2 * C,
                 Wm + lw.ao_s, d_ao_s, Wm + lw.lse_s, nullptr, d_qkv, d_qkv + C, d_qkv + 2 * C, d, d.Q, mws, W.mha_ws_bytes, s,
                 training ? &dr[0] : nullptr, use_bits ? bits_ptr(l, 1) : nullptr));

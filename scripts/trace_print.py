@@ -6,7 +6,12 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'coords3d_kernel' in r['Kernel_Name']]
 a, b = idx[-2], idx[-1]
-step = rows[a - 3:b - 3]
+# a step = from the gradient zero-fill (torch's elementwise fill in front of the forward) to the next one; without such a
+# kernel in the trace (inference loops) fall back to a fixed offset in front of coords3d
+fills = [i for i, r in enumerate(rows) if 'vectorized_elementwise_kernel' in r['Kernel_Name'] and 'Fill' in r['Kernel_Name']]
+fa = [i for i in fills if i < a and a - i < 12]
+fb = [i for i in fills if i < b and b - i < 12]
+step = rows[fa[-1]:fb[-1]] if fa and fb else rows[a - 3:b - 3]
 t0 = int(step[0]['Start_Timestamp'])
 lo = float(sys.argv[2]) if len(sys.argv) > 2 else -1e9
 hi = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9

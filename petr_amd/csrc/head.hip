@@ -1392,6 +1392,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
   // PETRv2's feature-guided PE) and the cross-attention backward run on the bf16 matrix cores, like their forwards
   const bool bf16 = io->attn_bf16 != 0;
   // the forward's condition for the bf16 self-attention (head_fwd: self16)
+  const bool slab_tiled = petr_tune("PETR_SLAB_TILED", bf16 ? 1 : 0) != 0;      // query_pos slab contractions: see the layer stages
   const bool self16_b = bf16 && env_on("PETR_FUSE_OUT_LN") && C == 256 && d.NH == 8 && petr_tune("PETR_SELF_BF16", 1) != 0;
   const bool hid16 = hidden_bf16(io);
   const bool tok16 = token_bf16(cfg, io);
@@ -1746,8 +1747,15 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
       // query_pos gradient, this layer's share: d(q-proj input) of the cross-attention into slab [0][l].  It only feeds the
       // query-embedding MLP in the final stage, so it rides with the weight gradients on the side streams instead of
       // standing (NL + 1 launches, ~180 us at 900 queries) at the end of the critical chain.
-      RUN(wgrad(dgrad_t ? lin_dgrad_t(d_qc, Wm + wt.ca_q, Wm + W.d_e_slab + (long)l * d.BQ * C, d.BQ, C, C)
-                        : lin_dgrad(d_qc, Pm + lp.ca_in_w, Wm + W.d_e_slab + (long)l * d.BQ * C, d.BQ, C, C)));
+      {
+        petr_gemm_args gs = dgrad_t ? lin_dgrad_t(d_qc, Wm + wt.ca_q, Wm + W.d_e_slab + (long)l * d.BQ * C, d.BQ, C, C)
+                                    : lin_dgrad(d_qc, Pm + lp.ca_in_w, Wm + W.d_e_slab + (long)l * d.BQ * C, d.BQ, C, C);
+        // bf16 mode: through the TILED contraction (60 workgroups of 256 threads; a single K segment selects it) instead of the
+        // 232 x 512-thread latency kernel - beside the bf16 attention backward (one workgroup per CU, three rounds) the slabs' CU
+        // slots are what it waits for: every bf16 step 1.6-1.9 % faster, every fp32 step 0.2-0.5 % slower (same-box A/B)
+        if (slab_tiled) gs.k_seg = gs.K;
+        RUN(wgrad(gs));
+      }
       float* d_x1 = Wm + lg.d_x1;
       if (!fuse_bwd) {       // (fused: the leading product of the LayerNorm-0 backward kernel below)
         g = dgrad_t ? lin_dgrad_t(d_qc, Wm + wt.ca_q, d_x1, d.BQ, C, C) : lin_dgrad(d_qc, Pm + lp.ca_in_w, d_x1, d.BQ, C, C);
@@ -1794,6 +1802,7 @@ extern "C" int petr_head_bwd(const petr_head_config* cfg, const petr_head_io* io
         petr_gemm_args ge = dgrad_t ? lin_dgrad_t(d_qkv, Wm + wt.sa_in, slab, d.BQ, 2 * C, C) : lin_dgrad(d_qkv, Pm + lp.sa_in_w, slab, d.BQ, 2 * C, C);
         ge.lda = 3 * C;
         if (dgrad_t) ge.ldb = 3 * C;          // rows of the transposed [C][3C] in_proj; K = the first 2C columns
+        if (slab_tiled) ge.k_seg = ge.K;
         RUN(wgrad(ge));
       }
       RUN(wgrad(lin_wgrad(d_qkv + 2 * C, 3 * C, x_in, C, Gp + lp.sa_in_w + (long)2 * C * C, Gp + lp.sa_in_b + 2 * C, d.BQ, C,

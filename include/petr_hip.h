@@ -331,6 +331,8 @@ typedef struct {
   float* y2; const float* add2; int add2_rows;
   int M;
   const float* w2T; const float* bias2; float* out2; int n2, n2_pos;
+  uint16_t* out2_bf16;                    /* optional (new LAST field): a bf16 copy of out2, same [M, 256 n2] indexing - bf16 mode's
+                                           * self-attention reads its K / V rows from it (no cast pass between the two launches) */
 } petr_ln_proj_args;
 int petr_ln_proj(const petr_ln_proj_args* a, void* stream);
 

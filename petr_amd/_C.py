@@ -110,7 +110,8 @@ class LnProjArgs(C.Structure):
         ('drop', Dropout), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('eps', C.c_float),
         ('z', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('y', C.c_void_p),
         ('y2', C.c_void_p), ('add2', C.c_void_p), ('add2_rows', C.c_int), ('M', C.c_int),
-        ('w2T', C.c_void_p), ('bias2', C.c_void_p), ('out2', C.c_void_p), ('n2', C.c_int), ('n2_pos', C.c_int))
+        ('w2T', C.c_void_p), ('bias2', C.c_void_p), ('out2', C.c_void_p), ('n2', C.c_int), ('n2_pos', C.c_int),
+        ('out2_bf16', C.c_void_p))
 
 
 class LnBwdProjArgs(C.Structure):

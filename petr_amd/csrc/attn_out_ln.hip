@@ -347,7 +347,13 @@ __global__ __launch_bounds__(512) void ln_proj_kernel(const LpParams p) {
   for (int i = 0; i < 4; ++i) {
     const int mo = m0 + 4 * q4 + i;
     if (mo >= a.M) continue;
-    *reinterpret_cast<float2*>(a.out2 + (long)mo * ld2 + n0) = make_float2(acc[0][0][i] + bb0, acc[0][1][i] + bb1);
+    const float o0 = acc[0][0][i] + bb0, o1 = acc[0][1][i] + bb1;
+    *reinterpret_cast<float2*>(a.out2 + (long)mo * ld2 + n0) = make_float2(o0, o1);
+    if (a.out2_bf16) {
+      typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+      const bf2 pk = {(__bf16)o0, (__bf16)o1};
+      *reinterpret_cast<uint32_t*>(a.out2_bf16 + (long)mo * ld2 + n0) = __builtin_bit_cast(uint32_t, pk);
+    }
   }
 }
 

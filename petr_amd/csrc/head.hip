@@ -1103,7 +1103,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
       // identity (petr_transformer.py:367) + LayerNorm + query_pos add
       if (self16) {     // bf16 mode: the self-attention on the bf16 kernels too (K / V rows of qkv rounded once; q, output, LSE fp32)
         uint16_t* q16 = reinterpret_cast<uint16_t*>(Wm + lw.qkv16);
-        RUN(petr_cast_bf16(Wm + lw.qkv, q16, d.BQ * 3 * C, s));
+        if (l == 0) RUN(petr_cast_bf16(Wm + lw.qkv, q16, d.BQ * 3 * C, s));      // layers 1..: written by the previous layer's petr_ln_proj
         RUN(mha_f_bf16(Wm + lw.qkv, (long)d.Q * 3 * C, 3 * C, q16 + C, (long)d.Q * 3 * C, 3 * C, q16 + 2 * C, Wm + lw.ao_s,
                        Wm + lw.lse_s, nullptr, d, d.Q, mws, W.mha_ws_bytes, s, training ? &dr_sp : nullptr,
                        use_bits ? bits_ptr(l, 1) : nullptr, ns_self, 1));
@@ -1202,6 +1202,7 @@ extern "C" int petr_head_fwd(const petr_head_config* cfg, const petr_head_io* io
       q.z = slabs ? Wm + lw.z2 : nullptr; q.mean = Wm + lw.mean2; q.rstd = Wm + lw.rstd2; q.y = xs_l;
       q.y2 = xe_next; q.add2 = E; q.add2_rows = d.Q; q.M = (int)d.BQ;
       q.w2T = Wm + W.wt[l + 1].sa_in; q.bias2 = Pm + P.lay[l + 1].sa_in_b; q.out2 = Wm + W.lay[l + 1].qkv; q.n2 = 3; q.n2_pos = 2;
+      if (self16) q.out2_bf16 = reinterpret_cast<uint16_t*>(Wm + W.lay[l + 1].qkv16);      // the bf16 self-attention's K / V copy
       RUN(petr_ln_proj(&q, s));
     } else if (!slabs) {
       RUN(ln_fwd(Wm + lw.z2, 1, 0, nullptr, nullptr, Pm + lp.n_g[2], Pm + lp.n_b[2], xs_l, nullptr, Wm + lw.mean2,

@@ -446,6 +446,34 @@ def test_head_bf16_training_toy_batch2_masked(pa):
     _bf16_grad_case(pa, head, oracle, feats, metas, g_cls, g_box, masks, out_bar=2e-2)
 
 
+@pytest.mark.parametrize('attn_dtype', ['fp32', 'bf16'])
+def test_forward_projected_equals_forward_batch2_masked(pa, attn_dtype):
+    """PETRHead.forward_projected (memory_in of the C ABI: the producer already applied input_proj) on the memory the ordinary
+    forward made: two samples, a padding mask, c5-sized maps - everything behind petr_head.py:390 is the same launch sequence on the
+    same values, so the outputs must be EQUAL (fp32; bf16 mode rounds the same memory to the same bf16 image)."""
+    oracle = O.seeded_head(5, 78, num_query=64)
+    head = make_pair(pa, oracle, num_query=64).eval()
+    head.attn_dtype = attn_dtype
+    metas = O.synthetic_img_metas(2, 6, (512, 1408), (400, 1200), seed=6)
+    g = torch.Generator().manual_seed(6)
+    feats = torch.randn(2, 6, 256, 16, 44, generator=g).cuda()
+    with torch.no_grad():
+        ref = head([feats], metas)
+        if attn_dtype == 'fp32':
+            mem = head.workspace_view('memory').clone().view(2, 6, 16, 44, 256)
+        else:       # the workspace holds the bf16 image in bf16 mode: recompute the fp32 memory the producer would hand over
+            w = head.input_proj.weight.view(256, 256)
+            mem = (torch.einsum('bnchw,oc->bnhwo', feats, w) + head.input_proj.bias).contiguous()
+        got = head.forward_projected(mem, metas)
+    for k in ('all_cls_scores', 'all_bbox_preds'):
+        if attn_dtype == 'fp32':
+            assert torch.equal(got[k], ref[k]), k
+        else:
+            d = (got[k] - ref[k]).abs().max().item()
+            assert d <= 3e-2 * max(1.0, ref[k].abs().max().item()), (k, d)
+    head.attn_dtype = 'fp32'
+
+
 def test_head_p4_1408_bf16_training_step(pa):
     """BASELINE configs[2] as stated: 6x256x32x88 (L = 16 896), 900 queries, bf16, forward AND backward, eval-mode
     (dropout off) so that the float64 oracle needs no 16 896-wide mask tensors."""

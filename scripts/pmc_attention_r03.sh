@@ -2,8 +2,8 @@
 # MFMA / VALU / LDS utilisation counters of the four cross-attention kernels on the shapes bench.py times:
 # rocprofv3 --pmc passes (counters only, never with a trace domain; program directly after "--") over the timed-only bench
 # command for the headline (c5 fp32: mha_fwd_kernel, mha_bwd_sk_kernel) and for p4_1600 bf16 (mha_fwd_bf16_kernel,
-# mha_bwd_bf16_kernel).  Cross-attention launches are told from self-attention ones by the key count carried in the grid
-# (the parser keeps the launches with the largest grid of each kernel name).  Writes gpurun_out/r03_pmc_attention.txt.
+# mha_bwd_bf16_kernel).  Cross-attention launches are told from self-attention ones by their position in the dispatch order
+# (they alternate; see the parser).  Writes gpurun_out/r03_pmc_attention.txt.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/r03_pmc_attention.txt
@@ -35,14 +35,21 @@ def short(n):
         if k in n:
             return k
     return None
+# cross- and self-attention launches of a kernel alternate in dispatch order (forward: self, cross; backward: cross, self - in
+# bf16 mode both attentions run the bf16 kernels, and the fp32 forward uses the same grid for both): per counter, order the
+# launches by dispatch id and keep every second one
+per = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = short(r['Kernel_Name'])
     if k:
-        grid[k] = max(grid[k], int(r['Grid_Size']))
-for r in rows:
-    k = short(r['Kernel_Name'])
-    if k and int(r['Grid_Size']) == grid[k]:
-        vals[k][r['Counter_Name']].append(float(r['Counter_Value']))
+        per[k][r['Counter_Name']].append((int(r['Dispatch_Id']), float(r['Counter_Value']), int(r['Grid_Size'])))
+for k, cs in per.items():
+    first = 1 if 'fwd' in k else 0
+    for c, lst in cs.items():
+        lst.sort()
+        sel = lst[first::2]
+        vals[k][c] = [v for _, v, _ in sel]
+        grid[k] = sel[0][2] if sel else 0
 cyc_per_mfma = {'mha_fwd_kernel': 64, 'mha_bwd_kernel': 64, 'mha_bwd_sk_kernel': 64, 'mha_fwd_bf16_kernel': 32, 'mha_bwd_bf16_kernel': 32}
 for k, cs in vals.items():
     if (dt == 'fp32') != ('bf16' not in k):

@@ -10,7 +10,7 @@ out = {'_how': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in SEPARATE passes
                '--dtype D --steps 4 --warmup 2 --timed-only` (MI355X; scripts/pmc_traffic_' + ROUND + '.sh).  Counter unit KiB; '
                'traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE counts half of a wide coalesced read). '
                'Cross- and self-attention launches of the fp32 kernels alternate in dispatch order (forward: self, cross; backward: '
-               'cross, self); the bf16 kernels only run the cross-attention.  Medians over the launches of 6 steps.  '
+               'cross, self), and so do those of the bf16 kernels in bf16 mode.  Medians over the launches of 6 steps.  '
                'dropout_mask_bytes: the packed keep-mask the training forward writes for the backward (inside WRITE_SIZE, outside '
                'algorithmic_min_bytes).'}
 for wl, dt in (('c5', 'fp32'), ('p4_1600', 'bf16')):
@@ -32,14 +32,14 @@ for wl, dt in (('c5', 'fp32'), ('p4_1600', 'bf16')):
             elif 'mha_bwd_kernel' in name or 'mha_bwd_sk_kernel' in name: key = 'bwd'
             elif 'coords3d_kernel' in name: key = 'coords3d'
             if dt == 'bf16' and key in ('fwd', 'bwd'):
-                continue                      # bf16 mode: the fp32 attention kernels only run the 900-key self-attention
+                continue                      # (bf16 mode: no fp32 attention launches since the self-attention moved to the bf16 kernels)
             if key:
                 per.setdefault(key, []).append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
         for k, lst in per.items():
             lst.sort()
             v = [x for _, x in lst]
-            if k == 'fwd': v = v[1::2]        # self, cross, self, cross ...
-            if k == 'bwd': v = v[0::2]        # cross, self, ...
+            if k in ('fwd', 'fwd16'): v = v[1::2]        # self, cross, self, cross ...  (bf16 mode: both attentions run the bf16 kernels)
+            if k in ('bwd', 'bwd16'): v = v[0::2]        # cross, self, ...
             vals.setdefault(k, {})[c] = statistics.median(v)
     Ltok = SHAPES[wl]
     ent = {}
